@@ -1,0 +1,163 @@
+/*
+ * daccord_hip.h — C ABI of libdaccord_hip.so, the MI355X-native replacement for
+ * daccord's per-window local de Bruijn consensus path.
+ *
+ * The reference (gt1/daccord v0.0.14) exposes no FFI for this path.  The entry
+ * points below replace, batch-granular, exactly these reference interfaces:
+ *
+ *   dacc_create / dacc_destroy   <- HandleContext::HandleContext(...)          src/HandleContext.hpp:332-380
+ *                                   (one context per worker thread)             src/daccord.cpp:1989-2023
+ *   dacc_set_error_profile       <- computeOffsetLikely(w,p_i,p_d) + KmerLimit  src/daccord.cpp:1867-1913, 1981-1988
+ *   dacc_load_db                 <- DatabaseFile -> RAM + DecodedReadContainer  src/daccord.cpp:1328-1369,
+ *                                                                               src/DecodedReadContainer.hpp:160-199
+ *   dacc_submit_piles            <- HandleContext::operator()(out,err,ita,ite)  src/HandleContext.hpp:1699-2901
+ *                                   called per A-read from the OpenMP loop      src/daccord.cpp:2107-2112, 2402-2414
+ *   dacc_collect / dacc_release  <- the `out` stream of operator() (FASTA       src/HandleContext.hpp:2710-2724
+ *                                   records) before wellcounter numbering       src/daccord.cpp:2481-2534
+ *   dacc_last_error              <- LibMausException::what() logged by caller   src/daccord.cpp:2466-2478
+ *
+ * Conventions: every call returns 0 or a negative DACC_E* code and never throws
+ * across the ABI.  A pile that fails internally yields zero fragments (mirrors
+ * the reference's per-read try/catch that logs and skips, daccord.cpp:2466-2478).
+ * Inputs are borrowed until the call returns.  One host thread per context.
+ * There is NO CPU fallback: without a usable HIP device dacc_create fails.
+ */
+#ifndef DACCORD_HIP_H
+#define DACCORD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DACC_OK          0
+#define DACC_EINVAL     -1   /* bad argument / unsupported parameter combination */
+#define DACC_ENODEV     -2   /* no usable HIP device (the library never falls back to the CPU) */
+#define DACC_ENOMEM     -3
+#define DACC_ESTATE     -4   /* call order violated (e.g. submit before load_db) */
+#define DACC_EHIP       -5   /* HIP runtime error, see dacc_last_error */
+#define DACC_ENOTSUP    -6   /* input outside the kernel's capacity (depth / tspace / k) */
+
+/* Run parameters: the daccord command line options that shape the path
+ * (src/daccord.cpp:101-169 defaults, :1282-1305 parsing). */
+typedef struct dacc_params {
+	uint32_t w;              /* -w window size            (default 40) */
+	uint32_t a;              /* -a advance size           (default 10) */
+	uint32_t klow, khigh;    /* -k single value or lo,hi  (default 8,8); 3 <= k <= 16 */
+	int32_t  minfilterfreq;  /* --minfilterfreq           (default 0) */
+	int32_t  maxfilterfreq;  /* --maxfilterfreq           (default 2) */
+	uint32_t minwindowcov;   /* -m                        (default 3) */
+	uint64_t maxalign;       /* -d max depth              (default UINT64_MAX) */
+	uint64_t eminrate;       /* -e max window error       (default UINT64_MAX) */
+	uint64_t minlen;         /* -l min output length      (default 0) */
+	int32_t  producefull;    /* -f                        (default 0) */
+	int32_t  tspace;         /* trace point spacing of the .las (AlignmentFile::getTSpace, daccord.cpp:1375) */
+	int32_t  device;         /* HIP device ordinal */
+	int32_t  verbose;
+} dacc_params;
+
+/* One DALIGNER overlap record (the 40-byte on-disk Overlap),
+ * in the field meaning of libmaus2::dazzler::align::OverlapDataInterface as used at
+ * src/HandleContext.hpp:1750-1962.  bbpos/bepos are coordinates in the
+ * reverse-complemented B read when (flags & 1). */
+typedef struct dacc_overlap {
+	int32_t  aread, bread;
+	uint32_t flags;          /* bit 0: B is reverse complemented (isInverse) */
+	int32_t  abpos, aepos, bbpos, bepos;
+	int32_t  diffs;
+	int32_t  tlen;           /* number of trace values = 2 * number of tspace blocks */
+	uint32_t reserved;
+	uint64_t trace_off;      /* index of this overlap's first trace value in the trace array */
+} dacc_overlap;
+
+/* One pile = all overlaps of one A read, already selected (top-D) and sorted by
+ * abpos exactly as the reference's caller does (src/daccord.cpp:2166-2288). */
+typedef struct dacc_pile {
+	int32_t  aread;
+	uint32_t novl;
+	uint64_t first_ovl;      /* index into the overlap array */
+} dacc_pile;
+
+/* One corrected fragment = one FASTA record of the reference
+ * (">{aread+1}/{well}/{first}_{first+len} A=[{first},{last}]", HandleContext.hpp:2712).
+ * The `well` field is numbered by the caller after ordered collection. */
+typedef struct dacc_fragment {
+	int32_t  aread;
+	uint32_t first, last;    /* A=[first,last] */
+	uint32_t len;            /* number of bases */
+	uint64_t seq_off;        /* offset of the bases in the buffer returned by dacc_collect */
+} dacc_fragment;
+
+typedef struct dacc_ctx dacc_ctx;
+
+int  dacc_create(dacc_ctx **ctx, const dacc_params *params);
+void dacc_destroy(dacc_ctx *ctx);
+
+/* Error profile -> OffsetLikely tables + KmerLimit tables, built on the host once
+ * and uploaded (never recomputed on the device). */
+int  dacc_set_error_profile(dacc_ctx *ctx, double p_i, double p_d, double est_cor);
+
+/* 2-bit read store in the Dazzler .bps layout: 4 bases per byte, first base in the
+ * two most significant bits, A,C,G,T = 0,1,2,3; read i occupies ceil(rlen[i]/4)
+ * bytes starting at boff[i].  Copied to HBM and kept resident. */
+int  dacc_load_db(dacc_ctx *ctx, const uint8_t *bps, uint64_t bps_bytes,
+                  const uint64_t *boff, const uint32_t *rlen, uint64_t nreads);
+
+/* Process a batch of piles on the device.  `trace` holds trace_bytes (1 or 2)
+ * bytes per value, pairs (diffs_i, blen_i) per tspace block. */
+int  dacc_submit_piles(dacc_ctx *ctx,
+                       const dacc_pile *piles, uint64_t npiles,
+                       const dacc_overlap *ovl, uint64_t novl,
+                       const void *trace, uint64_t ntrace, int trace_bytes);
+
+/* Fragments of the last submitted batch, ordered by (pile index, first).
+ * Library-owned until dacc_release / next submit. */
+int  dacc_collect(dacc_ctx *ctx, const dacc_fragment **frags, uint64_t *nfrags,
+                  const char **bases, uint64_t *nbases);
+void dacc_release(dacc_ctx *ctx);
+
+const char *dacc_last_error(dacc_ctx *ctx);
+
+/* ---- measurement hooks (bench.py / profiling; not part of the data path) ---- */
+
+/* Timings of the last dacc_submit_piles in milliseconds, measured with HIP events
+ * on the stream the kernels are launched on. */
+typedef struct dacc_timing {
+	float h2d_ms;            /* upload of piles/overlaps/trace */
+	float trace_ms;          /* trace-point block alignment kernel */
+	float window_ms;         /* per-window de Bruijn consensus kernel */
+	float vote_ms;           /* pile vote kernel(s) */
+	float d2h_ms;            /* download of fragments */
+	float total_ms;          /* first kernel start -> last kernel end */
+	uint64_t nwindows;       /* windows processed */
+	uint64_t nblocks;        /* trace blocks aligned */
+	uint64_t algo_bytes;     /* algorithmic bytes of the batch */
+} dacc_timing;
+int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
+
+/* Re-run only the device part of the last submitted batch (inputs already resident
+ * in HBM); used by bench.py so the timed region excludes H2D. */
+int  dacc_rerun_resident(dacc_ctx *ctx);
+
+/* Debug/parity hook: per-window results of the last batch.
+ * For window i: status (0 insufficient depth, 1 consensus found, 2 path failed),
+ * consensus length and bases (<= 64), number of strings, elength. */
+typedef struct dacc_window_result {
+	int32_t  pile;           /* pile index in the batch */
+	int32_t  y;              /* window index */
+	int32_t  status;
+	int32_t  mao;            /* number of strings in the window (A included) */
+	int32_t  elength;
+	int32_t  k;              /* k of the accepted graph */
+	int32_t  filterfreq;     /* filter frequency at which the consensus was found */
+	int32_t  conslen;
+	uint64_t minrate;        /* summed edit distance of the consensus */
+	char     cons[80];
+} dacc_window_result;
+int  dacc_debug_windows(dacc_ctx *ctx, dacc_window_result *out, uint64_t cap, uint64_t *nwin);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
