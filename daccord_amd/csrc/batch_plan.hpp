@@ -1,0 +1,148 @@
+/*
+ * Host-side planning of one batch of piles (pure C++): derives the device records
+ * (DevPile / DevOvl), the window schedule of every pile (Windows, HandleContext.hpp:382-447),
+ * the window range in which each overlap is active (HandleContext.hpp:1904-1977), the
+ * normalised error keys that order the active set (:1780-1790, :1955-1957), task and table
+ * offsets, and the scratch capacities.  No consensus arithmetic happens here.
+ */
+#ifndef DACC_BATCH_PLAN_HPP
+#define DACC_BATCH_PLAN_HPP
+#include <vector>
+#include <string>
+#include <limits>
+#include <algorithm>
+#include <cstdint>
+#include "../../include/daccord_hip.h"
+#include "dev_types.hpp"
+
+namespace dacc {
+
+static inline uint32_t hostNextPow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
+
+// Windows::computeN (HandleContext.hpp:390-408)
+static inline uint32_t windowsN(uint64_t const l, uint64_t const a, uint64_t const w)
+{
+	uint64_t const npre = (l+a >= w) ? ((l+a-w)/a) : 0;
+	if ( npre ) return ((npre-1)*a+w == l) ? npre : npre+1;
+	return l >= w ? 1 : 0;
+}
+static inline void windowIv(uint64_t const l, uint64_t const a, uint64_t const w, uint64_t const y, uint64_t & s, uint64_t & e)
+{
+	if ( y*a+w <= l ) { s = y*a; e = s+w; } else { s = l-w; e = l; }
+}
+
+struct BatchPlan
+{
+	std::vector<DevPile> piles;
+	std::vector<DevOvl> ovl;
+	std::vector<uint32_t> ovl_pile;
+	std::vector<uint64_t> fragbase;
+	uint64_t nwindows, nblocks, nwt, npos, nfragslots, algo_bytes;
+	uint32_t maxdepth, maxcols;
+	ArenaCaps caps;
+
+	int plan(dacc_params const & par, dacc_pile const * P, uint64_t const np, dacc_overlap const * O, uint64_t const no,
+		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err)
+	{
+		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear();
+		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0;
+		if ( trace_bytes != 1 ) { err = "only 1-byte trace values (tspace <= 125) are supported by the kernels"; return DACC_ENOTSUP; }
+		if ( par.tspace <= 0 || par.tspace > 128 ) { err = "tspace must be in [1,128]"; return DACC_ENOTSUP; }
+		uint8_t const * tr = static_cast<uint8_t const *>(trace);
+		std::vector<int32_t> diff;
+		for ( uint64_t pi = 0; pi < np; ++pi )
+		{
+			dacc_pile const & p = P[pi];
+			if ( p.aread < 0 || static_cast<uint64_t>(p.aread) >= nreads || p.first_ovl + p.novl > no ) { err = "pile out of range"; return DACC_EINVAL; }
+			DevPile d; d.aread = p.aread; d.novl = p.novl; d.first_ovl = ovl.size();
+			dacc_overlap const * ita = O + p.first_ovl;
+			uint64_t maxaepos = 0;
+			double maxerate = 0.0, minerate = 1.0;
+			for ( uint32_t z = 0; z < p.novl; ++z )
+			{
+				dacc_overlap const & o = ita[z];
+				if ( o.aread != p.aread || o.bread < 0 || static_cast<uint64_t>(o.bread) >= nreads || o.abpos < 0 || o.aepos <= o.abpos ||
+				     static_cast<uint32_t>(o.aepos) > rlen[o.aread] || o.bbpos < 0 || o.bepos < o.bbpos || static_cast<uint32_t>(o.bepos) > rlen[o.bread] ||
+				     (z && ita[z-1].abpos > o.abpos) )
+				{ err = "malformed overlap record (ranges / not sorted by abpos)"; return DACC_EINVAL; }
+				if ( static_cast<uint64_t>(o.aepos) > maxaepos ) maxaepos = o.aepos;
+				double const erate = static_cast<double>(o.diffs) / static_cast<double>(o.aepos-o.abpos);
+				if ( erate > maxerate ) maxerate = erate;
+				if ( erate < minerate ) minerate = erate;
+			}
+			double const ediv = (maxerate > minerate) ? (maxerate-minerate) : 1.0;
+			d.l = maxaepos; d.nwin = p.novl ? windowsN(maxaepos,par.a,par.w) : 0;
+			d.winbase = nwindows; d.posbase = npos; d.rl = rlen[p.aread]; d.pad = 0;
+			uint64_t const pilepos = std::max<uint64_t>(d.l,d.rl)+1;
+			diff.assign(d.nwin+2,0);
+			algo_bytes += (d.rl+3)/4;
+			for ( uint32_t z = 0; z < p.novl; ++z )
+			{
+				dacc_overlap const & o = ita[z];
+				DevOvl v;
+				v.bread = o.bread; v.flags = o.flags; v.abpos = o.abpos; v.aepos = o.aepos; v.bbpos = o.bbpos; v.bepos = o.bepos;
+				double const erate = static_cast<double>(o.diffs) / static_cast<double>(o.aepos-o.abpos);
+				uint64_t const escore = static_cast<uint64_t>(((erate-minerate)/ediv) * std::numeric_limits<uint32_t>::max());
+				v.ekey = static_cast<uint32_t>(escore);
+				int64_t const ts = par.tspace;
+				int64_t const nblk = (o.aepos + ts - 1)/ts - o.abpos/ts;
+				if ( o.tlen != 2*nblk || o.trace_off + o.tlen > ntrace ) { err = "trace length does not match the overlap's tspace blocks"; return DACC_EINVAL; }
+				v.nblk = nblk; v.blk0 = nblocks; v.trace_off = o.trace_off;
+				uint64_t bsum = 0;
+				for ( int64_t b = 0; b < nblk; ++b )
+				{
+					uint32_t const bl = tr[o.trace_off+2*b+1];
+					bsum += bl; if ( bl > maxcols ) maxcols = bl;
+				}
+				if ( static_cast<int64_t>(bsum) != o.bepos-o.bbpos ) { err = "trace B lengths do not sum to bepos-bbpos"; return DACC_EINVAL; }
+				nblocks += nblk;
+				algo_bytes += 40 + static_cast<uint64_t>(o.tlen)*trace_bytes + (o.bepos-o.bbpos+3)/4;
+				// active window range [y0,y0+ny): start(y) >= abpos and end(y) <= aepos
+				uint32_t y0 = d.nwin, ny = 0;
+				if ( d.nwin )
+				{
+					uint64_t y = std::min<uint64_t>((static_cast<uint64_t>(o.abpos)+par.a-1)/par.a,d.nwin-1);
+					uint64_t s, e;
+					while ( y > 0 ) { windowIv(d.l,par.a,par.w,y-1,s,e); if ( s >= static_cast<uint64_t>(o.abpos) ) --y; else break; }
+					windowIv(d.l,par.a,par.w,y,s,e);
+					if ( s >= static_cast<uint64_t>(o.abpos) )
+					{
+						uint64_t yl = y; bool any = false;
+						for ( uint64_t q = y; q < d.nwin; ++q )
+						{
+							windowIv(d.l,par.a,par.w,q,s,e);
+							if ( e <= static_cast<uint64_t>(o.aepos) ) { yl = q; any = true; } else break;
+						}
+						if ( any ) { y0 = y; ny = yl-y+1; }
+					}
+				}
+				v.y0 = y0; v.ny = ny; v.wtoff = nwt; nwt += ny;
+				if ( ny ) { diff[y0] += 1; diff[y0+ny] -= 1; }
+				ovl.push_back(v); ovl_pile.push_back(pi);
+			}
+			int32_t cur = 0;
+			for ( uint32_t y = 0; y < d.nwin; ++y ) { cur += diff[y]; if ( static_cast<uint32_t>(cur) > maxdepth ) maxdepth = cur; }
+			nwindows += d.nwin; npos += pilepos;
+			fragbase.push_back(nfragslots); nfragslots += pilepos/100 + 2;
+			piles.push_back(d);
+		}
+		// scratch capacities
+		uint64_t const depthcap = std::min<uint64_t>(static_cast<uint64_t>(maxdepth)+1, par.maxalign ? par.maxalign : 1);
+		caps.maxs = std::max<uint32_t>(2,static_cast<uint32_t>(std::min<uint64_t>(depthcap,4096)));
+		caps.precap = hostNextPow2(std::max<uint32_t>(256,std::max<uint32_t>(caps.maxs*72,maxdepth+1)));
+		caps.nodecap = caps.precap;
+		caps.fcap = caps.nodecap*24;
+		caps.strcap = 2*caps.precap;
+		caps.linkcap = 8*caps.precap;
+		caps.sfcap = 8*caps.strcap;
+		caps.rlcap = 2*caps.strcap;
+		caps.poolcap = 8192;
+		caps.blcap = 256;
+		caps.conscap = 32768 + MAXCONS;
+		caps.pad = 0; caps.bytes = 0;
+		return DACC_OK;
+	}
+};
+
+}
+#endif

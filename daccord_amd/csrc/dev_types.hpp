@@ -1,0 +1,91 @@
+/*
+ * Device-side data layout shared by the kernels and the host driver (plain structs, HBM
+ * resident).  See DESIGN.md "Data layout in HBM".
+ */
+#ifndef DACC_DEV_TYPES_HPP
+#define DACC_DEV_TYPES_HPP
+#include <stdint.h>
+
+namespace dacc {
+
+// flattened, zero padded OffsetLikely + KmerLimit tables (built on the host once, host_tables.cpp)
+struct DevTables
+{
+	int32_t nrows;               // maxl+1 rows (reference positions), OffsetLikely::size()
+	int32_t nsup;                // number of read positions covered (Vsupport.size())
+	int32_t kln;                 // entries per k in klim
+	int32_t pad;
+	double const * dpnorm;       // [nrows][nsup]  DPnorm[i][pos], 0 outside the row's support
+	double const * dpsq;         // [nrows][nsup]  DPnormSquare[i].V, addressed by absolute pos
+	uint64_t const * dpsq_vs;    // [nrows][nsup]  DPnormSquare[i].VS (2^32 fixed point)
+	uint16_t const * dpsq_first; // [nrows] firstsign of DPnormSquare[i]
+	uint16_t const * dpsq_size;  // [nrows] V.size()
+	uint16_t const * suplo;      // [nsup] Vsupport[pos].first
+	uint16_t const * suphi;      // [nsup] Vsupport[pos].second
+	uint32_t const * klim;       // [khigh-klow+1][kln] KmerLimit::getLimit(n)
+};
+
+struct DevParams
+{
+	uint32_t w, a, klow, khigh;
+	int32_t minff, maxff;
+	uint32_t minwindowcov;
+	int32_t checklim;            // est_cor != 0 (DebruijnGraph::p, setupAddHeap)
+	uint64_t maxalign, eminrate;
+	int32_t tspace;
+	int32_t producefull;
+	uint64_t minlen;
+};
+
+// one overlap, device form
+struct DevOvl
+{
+	int32_t bread; uint32_t flags;
+	int32_t abpos, aepos, bbpos, bepos;
+	uint32_t ekey;               // uint32(((erate-min)/ediv)*UINT32_MAX), HandleContext.hpp:1955
+	int32_t y0, ny;              // windows [y0,y0+ny) in which the overlap is active
+	int32_t nblk;                // number of trace blocks
+	uint64_t wtoff;              // offset of its window table rows
+	uint64_t blk0;               // id of its first trace block task
+	uint64_t trace_off;
+};
+
+struct DevPile
+{
+	int32_t aread; uint32_t novl;
+	uint64_t first_ovl;
+	uint32_t l;                  // max aepos = window schedule length (HandleContext.hpp:1773-1776,1852)
+	uint32_t nwin;
+	uint64_t winbase;            // index of its first window
+	uint64_t posbase;            // index of its first position slot (vote kernel)
+	uint32_t rl;                 // A read length
+	uint32_t pad;
+};
+
+// capacities of the per-wavefront scratch arena (chosen by the host from the batch)
+struct ArenaCaps
+{
+	uint32_t maxs;      // strings per window (A included)
+	uint32_t precap;    // prenodes (power of two)
+	uint32_t nodecap;   // nodes
+	uint32_t fcap;      // feasible-position entries (each direction)
+	uint32_t strcap;    // stretches
+	uint32_t linkcap;   // stretch link words
+	uint32_t sfcap;     // stretch feasibility objects (each direction)
+	uint32_t rlcap;     // reverse stretch links
+	uint32_t poolcap;   // path pool entries (each direction)
+	uint32_t blcap;     // distinct base lengths (heaps per length)
+	uint32_t conscap;   // candidate text bytes
+	uint32_t pad;
+	uint64_t bytes;     // total arena bytes per wavefront (filled by arena_layout)
+};
+
+enum { LSTR = 128 };       // max window string length held by the kernel
+enum { WREC = 256 };       // bytes per window output record
+enum { MAXCONS = 96 };     // max consensus length
+
+// window status / flags
+enum { WS_INSUFFICIENT = 0, WS_OK = 1, WS_FAILED = 2, WS_OVERFLOW = 3 };
+
+}
+#endif

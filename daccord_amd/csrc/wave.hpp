@@ -1,0 +1,152 @@
+/*
+ * Wavefront-cooperative primitives for the gfx950 kernels (64-lane wavefronts, one wavefront
+ * per workgroup in the window kernel).
+ *
+ * DACC_EMUL: the container this is developed in has no GPU, so the kernel LOGIC is also
+ * unit-tested by compiling the same device headers with g++ as a 1-lane "wavefront"
+ * (WSZ == 1, lane == 0).  That build exists only under tests/emul/ as a test harness; it is
+ * never part of libdaccord_hip.so, which contains gfx950 code only and refuses to run
+ * without a HIP device.
+ */
+#ifndef DACC_WAVE_HPP
+#define DACC_WAVE_HPP
+#include <stdint.h>
+
+#if defined(DACC_EMUL)
+  #define DEV inline
+  #define WSZ 1
+  namespace dacc {
+  static inline int wv_lane() { return 0; }
+  static inline void wv_sync() {}
+  static inline uint32_t wv_scan_excl(uint32_t v, uint32_t & total) { total = v; return 0; }
+  static inline uint32_t wv_sum(uint32_t v) { return v; }
+  static inline uint64_t wv_sum64(uint64_t v) { return v; }
+  static inline uint32_t wv_max(uint32_t v) { return v; }
+  static inline uint64_t wv_max64(uint64_t v) { return v; }
+  static inline uint64_t wv_min64(uint64_t v) { return v; }
+  static inline int wv_any(int p) { return p; }
+  static inline uint32_t wv_or(uint32_t v) { return v; }
+  static inline uint32_t wv_bcast(uint32_t v, int) { return v; }
+  static inline uint64_t wv_bcast64(uint64_t v, int) { return v; }
+  static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
+  static inline void atomicOrFlag(uint32_t * f) { *f |= 1u; }
+  }
+#else
+  #include <hip/hip_runtime.h>
+  #define DEV __device__ __forceinline__
+  #define WSZ 64
+  namespace dacc {
+  DEV int wv_lane() { return threadIdx.x & 63; }
+  // one wavefront per workgroup: barrier + LDS/global visibility inside the wavefront
+  DEV void wv_sync() { __syncthreads(); }
+  DEV uint32_t wv_scan_excl(uint32_t v, uint32_t & total)
+  {
+	uint32_t x = v;
+	int const lane = wv_lane();
+	#pragma unroll
+	for ( int d = 1; d < 64; d <<= 1 )
+	{
+		uint32_t const y = __shfl_up(x,d,64);
+		if ( lane >= d ) x += y;
+	}
+	total = __shfl(x,63,64);
+	return x - v;
+  }
+  DEV uint32_t wv_sum(uint32_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) v += __shfl_xor(v,d,64);
+	return v;
+  }
+  DEV uint64_t wv_sum64(uint64_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) v += __shfl_xor(v,d,64);
+	return v;
+  }
+  DEV uint32_t wv_max(uint32_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) { uint32_t const o = __shfl_xor(v,d,64); v = o > v ? o : v; }
+	return v;
+  }
+  DEV uint64_t wv_max64(uint64_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) { uint64_t const o = __shfl_xor(v,d,64); v = o > v ? o : v; }
+	return v;
+  }
+  DEV uint64_t wv_min64(uint64_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) { uint64_t const o = __shfl_xor(v,d,64); v = o < v ? o : v; }
+	return v;
+  }
+  DEV int wv_any(int p) { return __any(p); }
+  DEV uint32_t wv_or(uint32_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
+	return v;
+  }
+  DEV uint32_t wv_bcast(uint32_t v, int src) { return __shfl(v,src,64); }
+  DEV uint64_t wv_bcast64(uint64_t v, int src) { return __shfl(v,src,64); }
+  DEV int dacc_popc64(uint64_t v) { return __popcll(v); }
+  DEV void atomicOrFlag(uint32_t * f) { atomicOr(f,1u); }
+  }
+#endif
+
+namespace dacc {
+
+// ascending bitonic sort of n64 (power of two) 64-bit keys in memory; all lanes call
+DEV void wv_bitonic_sort(uint64_t * A, uint32_t const n)
+{
+	int const lane = wv_lane();
+	for ( uint32_t k = 2; k <= n; k <<= 1 )
+		for ( uint32_t j = k>>1; j > 0; j >>= 1 )
+		{
+			for ( uint32_t t = lane; t < (n>>1); t += WSZ )
+			{
+				// t-th compare-exchange pair of this stage
+				uint32_t const i = ((t & ~(j-1)) << 1) | (t & (j-1));
+				uint32_t const l = i | j;
+				uint64_t const a = A[i], b = A[l];
+				bool const up = ((i & k) == 0);
+				if ( (a > b) == up ) { A[i] = b; A[l] = a; }
+			}
+			wv_sync();
+		}
+}
+
+// ascending bitonic sort of n (power of two) indices by (key[idx], idx); 0xFFFFFFFF pads sort last
+DEV void wv_bitonic_sort_idx(uint32_t * I, uint64_t const * K, uint32_t const n)
+{
+	int const lane = wv_lane();
+	for ( uint32_t k = 2; k <= n; k <<= 1 )
+		for ( uint32_t j = k>>1; j > 0; j >>= 1 )
+		{
+			for ( uint32_t t = lane; t < (n>>1); t += WSZ )
+			{
+				uint32_t const i = ((t & ~(j-1)) << 1) | (t & (j-1));
+				uint32_t const l = i | j;
+				uint32_t const a = I[i], b = I[l];
+				bool gt;
+				if ( a == 0xFFFFFFFFu ) gt = (b != 0xFFFFFFFFu);
+				else if ( b == 0xFFFFFFFFu ) gt = false;
+				else { uint64_t const ka = K[a], kb = K[b]; gt = (ka > kb) || (ka == kb && a > b); }
+				bool const up = ((i & k) == 0);
+				if ( gt == up ) { I[i] = b; I[l] = a; }
+			}
+			wv_sync();
+		}
+}
+
+DEV uint32_t next_pow2(uint32_t v)
+{
+	uint32_t p = 1;
+	while ( p < v ) p <<= 1;
+	return p;
+}
+
+}
+#endif

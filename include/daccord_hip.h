@@ -119,6 +119,11 @@ void dacc_release(dacc_ctx *ctx);
 
 const char *dacc_last_error(dacc_ctx *ctx);
 
+/* Pile loader selection step (host): keep <= maxinput overlaps of one pile (records in .las
+ * order) and sort them by abpos exactly as src/daccord.cpp:2120-2288 does; `out` must hold n records. */
+int  dacc_pile_select(const dacc_overlap *in, uint64_t n, int trace_bytes, uint64_t maxinput,
+                      dacc_overlap *out, uint64_t *nout);
+
 /* ---- measurement hooks (bench.py / profiling; not part of the data path) ---- */
 
 /* Timings of the last dacc_submit_piles in milliseconds, measured with HIP events
@@ -156,6 +161,10 @@ typedef struct dacc_window_result {
 	char     cons[80];
 } dacc_window_result;
 int  dacc_debug_windows(dacc_ctx *ctx, dacc_window_result *out, uint64_t cap, uint64_t *nwin);
+
+/* Debug/parity hook: canonical serialisation of the OffsetLikely / KmerLimit tables built by
+ * dacc_set_error_profile (compared bit for bit with the oracle's). */
+int  dacc_debug_tables(dacc_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *n, uint64_t klimit_n);
 
 #ifdef __cplusplus
 }

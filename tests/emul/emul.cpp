@@ -1,0 +1,190 @@
+/*
+ * TEST HARNESS ONLY (never part of libdaccord_hip.so): compiles the kernel device headers
+ * with g++ as a 1-lane wavefront (DACC_EMUL, see daccord_amd/csrc/wave.hpp) and drives them
+ * with plain loops, so that the kernel LOGIC can be compared with the oracle in the build
+ * container, which has no GPU.  The real library has no such path: it is gfx950 code only.
+ */
+#define DACC_EMUL 1
+#include <vector>
+#include <string>
+#include <cstring>
+#include <cstdlib>
+#include "../../daccord_amd/csrc/batch_plan.hpp"
+#include "../../daccord_amd/csrc/host_tables.hpp"
+#include "../../daccord_amd/csrc/window_main.hpp"
+#include "../../daccord_amd/csrc/trace_kernel.hpp"
+#include "../../daccord_amd/csrc/vote_kernel.hpp"
+
+using namespace dacc;
+
+struct EmulCtx
+{
+	dacc_params par;
+	HostTables H;
+	bool haveprofile;
+	double est_cor;
+	std::vector<uint8_t> bps; std::vector<uint64_t> boff; std::vector<uint32_t> rlen;
+	std::vector<dacc_fragment> frags; std::string bases;
+	std::vector<dacc_window_result> windows;
+	std::string err;
+};
+
+static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
+{
+	dacc_params const & p = c.par;
+	P.w = p.w; P.a = p.a; P.klow = p.klow; P.khigh = p.khigh; P.minff = p.minfilterfreq; P.maxff = p.maxfilterfreq;
+	P.minwindowcov = p.minwindowcov; P.checklim = (c.est_cor != 0.0); P.maxalign = p.maxalign; P.eminrate = p.eminrate;
+	P.tspace = p.tspace; P.producefull = p.producefull; P.minlen = p.minlen;
+	T.nrows = c.H.nrows; T.nsup = c.H.nsup; T.kln = c.H.kln; T.pad = 0;
+	T.dpnorm = c.H.dpnorm.data(); T.dpsq = c.H.dpsq.data(); T.dpsq_vs = c.H.dpsq_vs.data();
+	T.dpsq_first = c.H.dpsq_first.data(); T.dpsq_size = c.H.dpsq_size.data(); T.suplo = c.H.suplo.data(); T.suphi = c.H.suphi.data();
+	T.klim = c.H.klim.data();
+}
+
+extern "C" {
+
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; return c; }
+void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
+char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
+
+int emul_set_error_profile(void * v, double p_i, double p_d, double est_cor)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	buildHostTables(c->H,c->par.w,p_i,p_d,est_cor,c->par.klow,c->par.khigh,4200);
+	c->est_cor = est_cor; c->haveprofile = true;
+	return 0;
+}
+int emul_tables(void * v, uint64_t * out, uint64_t cap, uint64_t * n, uint64_t klimit_n)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	std::vector<uint64_t> B; serialiseHostTables(c->H,B,klimit_n);
+	*n = B.size();
+	if ( out ) std::memcpy(out,B.data(),8*std::min<uint64_t>(cap,B.size()));
+	return 0;
+}
+int emul_load_db(void * v, uint8_t const * bps, uint64_t nb, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	c->bps.assign(bps,bps+nb); c->bps.resize(nb+16,0); c->boff.assign(boff,boff+nreads); c->rlen.assign(rlen,rlen+nreads);
+	return 0;
+}
+
+int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	if ( !c->haveprofile ) return DACC_ESTATE;
+	BatchPlan BP;
+	int rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->rlen.data(),c->rlen.size(),c->err);
+	if ( rc ) return rc;
+	DevParams P; DevTables T; fillDev(*c,P,T);
+
+	// block tables (prep kernel equivalent)
+	std::vector<uint32_t> blk_ovl(BP.nblocks), blk_b0(BP.nblocks);
+	uint8_t const * tr = static_cast<uint8_t const *>(trace);
+	for ( uint64_t o = 0; o < BP.ovl.size(); ++o )
+	{
+		uint32_t b = BP.ovl[o].bbpos;
+		for ( int32_t i = 0; i < BP.ovl[o].nblk; ++i )
+		{
+			blk_ovl[BP.ovl[o].blk0+i] = o; blk_b0[BP.ovl[o].blk0+i] = b;
+			b += tr[BP.ovl[o].trace_off+2*i+1];
+		}
+	}
+	std::vector<uint32_t> wt_b(BP.nwt+1,0xDEADBEEF), wt_e(BP.nwt+1,0xDEADBEEF);
+	uint32_t errflag = 0;
+	{
+		TraceBatch TB;
+		TB.P = P; TB.bps = c->bps.data(); TB.boff = c->boff.data(); TB.rlen = c->rlen.data();
+		TB.piles = BP.piles.data(); TB.ovl = BP.ovl.data(); TB.ovl_pile = BP.ovl_pile.data(); TB.trace = tr;
+		TB.blk_ovl = blk_ovl.data(); TB.blk_b0 = blk_b0.data(); TB.nblocks = BP.nblocks;
+		TB.wt_b = wt_b.data(); TB.wt_e = wt_e.data();
+		std::vector<uint64_t> colv((BP.maxcols+2)*4); std::vector<uint16_t> colbot(BP.maxcols+2);
+		TB.colv = colv.data(); TB.colbot = colbot.data(); TB.maxcols = BP.maxcols; TB.nthreads = 1; TB.errflag = &errflag;
+		for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,0);
+	}
+	if ( errflag ) { c->err = "trace kernel capacity exceeded"; return DACC_ENOTSUP; }
+	for ( uint64_t i = 0; i < BP.nwt; ++i ) if ( wt_b[i] == 0xDEADBEEF || wt_e[i] == 0xDEADBEEF ) { c->err = "window table entry not written"; return DACC_EHIP; }
+
+	// window kernel
+	std::vector<uint8_t> wrec(BP.nwindows*WREC+WREC,0);
+	std::vector<WindowOut> wout(BP.nwindows+1);
+	{
+		Arena A; ArenaCaps caps = BP.caps;
+		caps.bytes = arena_carve(A,0,caps);
+		std::vector<uint8_t> arena(caps.bytes+64);
+		WindowBatch WB;
+		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
+		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
+		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data();
+		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) processWindow(WB,wdx,arena.data());
+	}
+	c->windows.clear();
+	bool overflow = false;
+	for ( uint64_t pi = 0; pi < BP.piles.size(); ++pi )
+		for ( uint32_t y = 0; y < BP.piles[pi].nwin; ++y )
+		{
+			uint64_t const wdx = BP.piles[pi].winbase+y;
+			WindowOut const & o = wout[wdx];
+			dacc_window_result r; std::memset(&r,0,sizeof(r));
+			r.pile = pi; r.y = y; r.status = o.status; r.mao = o.mao; r.elength = o.elength; r.k = o.k; r.filterfreq = o.filterfreq;
+			r.conslen = o.conslen; r.minrate = o.minrate;
+			if ( o.status == WS_OVERFLOW ) overflow = true;
+			if ( o.status == WS_OK )
+			{
+				uint8_t const * rec = wrec.data() + wdx*WREC;
+				uint8_t const * off = rec+1; uint8_t const * sym = rec+1+(P.w+2);
+				uint32_t cl = 0;
+				for ( uint32_t q = 0; q < off[P.w+1] && cl < 79; ++q ) if ( sym[q] < 4 ) r.cons[cl++] = "ACGT"[sym[q]];
+			}
+			else r.filterfreq = (o.status == WS_FAILED) ? 0 : 0;
+			c->windows.push_back(r);
+		}
+	if ( overflow ) { c->err = "window kernel scratch capacity exceeded"; return DACC_ENOTSUP; }
+
+	// vote
+	std::vector<uint8_t> has(BP.npos+1), oc(BP.npos+1); std::vector<uint16_t> ld0(BP.npos+1); std::vector<uint32_t> ocs(BP.npos+1);
+	std::vector<uint8_t> outsym(2*BP.npos + 64*BP.piles.size() + 64);
+	std::vector<VoteFragment> vf(BP.nfragslots+1); std::vector<uint32_t> nfrag(BP.piles.size()+1);
+	VoteBatch VB;
+	VB.P = P; VB.bps = c->bps.data(); VB.boff = c->boff.data(); VB.rlen = c->rlen.data(); VB.piles = BP.piles.data(); VB.npiles = BP.piles.size();
+	VB.wrec = wrec.data(); VB.has = has.data(); VB.ld0 = ld0.data(); VB.oc = oc.data(); VB.ocs = ocs.data(); VB.outsym = outsym.data();
+	VB.frags = vf.data(); VB.fragbase = BP.fragbase.data(); VB.nfrag = nfrag.data(); VB.errflag = &errflag;
+	c->frags.clear(); c->bases.clear();
+	for ( uint64_t pi = 0; pi < BP.piles.size(); ++pi )
+	{
+		DevPile const & pile = BP.piles[pi];
+		uint32_t const np = pileNpos(pile);
+		for ( uint32_t p = 0; p < np; ++p ) votePass1(VB,pile,p);
+		uint32_t run = 0;
+		for ( uint32_t p = 0; p < np; ++p ) { uint32_t const n = votePass2(VB,pile,p,0); oc[pile.posbase+p] = n; ocs[pile.posbase+p] = run; run += n; }
+		if ( run > 2*np+64 ) { c->err = "vote output capacity exceeded"; return DACC_ENOTSUP; }
+		uint64_t const symbase = 2*pile.posbase + 64ull*pi;
+		for ( uint32_t p = 0; p < np; ++p ) votePass2(VB,pile,p,outsym.data()+symbase+ocs[pile.posbase+p]);
+		voteRuns(VB,pile,pi);
+		for ( uint32_t f = 0; f < nfrag[pi]; ++f )
+		{
+			VoteFragment const & F = vf[BP.fragbase[pi]+f];
+			dacc_fragment g; g.aread = pile.aread; g.first = F.first; g.last = F.last; g.len = F.len; g.seq_off = c->bases.size();
+			for ( uint32_t i = 0; i < F.len; ++i ) c->bases.push_back("ACGTDacgt"[outsym[F.off+i]]);
+			c->frags.push_back(g);
+		}
+	}
+	if ( errflag ) { c->err = "vote kernel capacity exceeded"; return DACC_ENOTSUP; }
+	return 0;
+}
+
+int emul_collect(void * v, dacc_fragment const ** frags, uint64_t * nfrags, char const ** bases, uint64_t * nbases)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	*frags = c->frags.data(); *nfrags = c->frags.size(); *bases = c->bases.data(); *nbases = c->bases.size();
+	return 0;
+}
+int emul_windows(void * v, dacc_window_result * out, uint64_t cap, uint64_t * n)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	*n = c->windows.size();
+	if ( out ) std::memcpy(out,c->windows.data(),sizeof(dacc_window_result)*std::min<uint64_t>(cap,c->windows.size()));
+	return 0;
+}
+
+}
