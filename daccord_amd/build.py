@@ -1,0 +1,35 @@
+"""Build the in-tree native libraries.  libdaccord_hip.so is gfx950-only HIP code (hipcc
+cross-compiles without a GPU); there is no CPU build of the product."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libdaccord_hip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wno-unused-value"]
+
+
+def _newer(target, srcs):
+    return (not os.path.exists(target)) or os.path.getmtime(target) < max(os.path.getmtime(s) for s in srcs)
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "daccord_hip.h"))
+    if force or _newer(LIB, srcs):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "host_tables.cpp"),
+                                       os.path.join(CSRC, "host_piles.cpp")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_all(force=False, verbose=False):
+    from . import synth
+    build_hip(force, verbose)
+    synth.build(force)
+    return LIB

@@ -53,12 +53,12 @@ struct Arena
 	uint64_t * alpv; uint64_t * almv; uint16_t * albot; uint8_t * alops;
 };
 
-DEV uint64_t arena_align(uint64_t o) { return (o + 15) & ~static_cast<uint64_t>(15); }
+HDEV uint64_t arena_align(uint64_t o) { return (o + 15) & ~static_cast<uint64_t>(15); }
 
 #define DACC_CARVE(field,type,count) A.field = reinterpret_cast<type *>(base + o); o = arena_align(o + sizeof(type)*static_cast<uint64_t>(count));
 
 // carve the arena; returns total bytes (call with base = 0 to size it)
-DEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C)
+HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C)
 {
 	uint64_t o = 0;
 	uint32_t const keycap = next_pow2(C.maxs < 2 ? 2 : C.maxs);

@@ -1,0 +1,447 @@
+/*
+ * libdaccord_hip.so: C ABI (include/daccord_hip.h) + gfx950 kernels.
+ * Host side: device buffers, batch planning, launches on one HIP stream, HIP-event timing.
+ * There is no CPU fallback anywhere in this file: no device => DACC_ENODEV.
+ */
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include <cstring>
+#include <cstdio>
+#include <new>
+#include "../../include/daccord_hip.h"
+#include "batch_plan.hpp"
+#include "host_tables.hpp"
+#include "window_main.hpp"
+#include "trace_kernel.hpp"
+#include "vote_kernel.hpp"
+
+using namespace dacc;
+
+// ---------------------------------------------------------------- kernels
+
+struct PrepBatch
+{
+	DevOvl const * ovl; uint64_t novl; uint8_t const * trace;
+	uint32_t * blk_ovl; uint32_t * blk_b0;
+};
+
+// per overlap: block task table (overlap id, B start of every tspace block = prefix sum of the trace B lengths)
+__global__ void k_prep(PrepBatch B)
+{
+	uint64_t const o = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+	if ( o >= B.novl ) return;
+	DevOvl const ov = B.ovl[o];
+	uint32_t b = ov.bbpos;
+	for ( int32_t i = 0; i < ov.nblk; ++i )
+	{
+		B.blk_ovl[ov.blk0+i] = o; B.blk_b0[ov.blk0+i] = b;
+		b += B.trace[ov.trace_off+2*i+1];
+	}
+}
+
+__global__ void __launch_bounds__(256) k_trace(TraceBatch B)
+{
+	uint32_t const tid = blockIdx.x*blockDim.x + threadIdx.x;
+	for ( uint64_t task = tid; task < B.nblocks; task += B.nthreads )
+		traceBlock(B,task,tid);
+}
+
+// one wavefront per workgroup, grid-stride over windows.  Workgroup b lands on XCD b%8 (observed
+// placement, used for L2 affinity only): give every XCD a contiguous run of windows so that the
+// windows of one pile (which share the pile's overlaps and reads) hit one L2.
+__global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag)
+{
+	uint32_t const G = gridDim.x;
+	uint32_t const b = blockIdx.x;
+	uint32_t const perx = G >> 3;
+	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
+	uint8_t * arena = B.arena + static_cast<uint64_t>(b)*B.C.bytes;
+	for ( uint64_t base = 0; base < B.nwindows; base += G )
+	{
+		uint64_t const w = base + slot;
+		if ( w < B.nwindows )
+		{
+			processWindow(B,w,arena);
+			if ( threadIdx.x == 0 && B.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
+		}
+	}
+}
+
+// one workgroup per pile
+__global__ void __launch_bounds__(256) k_vote(VoteBatch B)
+{
+	__shared__ uint32_t part[256];
+	uint32_t const pi = blockIdx.x;
+	DevPile const pile = B.piles[pi];
+	uint32_t const np = pileNpos(pile);
+	uint32_t const tid = threadIdx.x;
+	for ( uint32_t p = tid; p < np; p += 256 ) votePass1(B,pile,p);
+	__syncthreads();
+	// contiguous chunk per thread: counts, then a block-wide exclusive scan
+	uint32_t const chunk = (np + 255)/256;
+	uint32_t const p0 = tid*chunk, p1 = (p0+chunk < np) ? (p0+chunk) : np;
+	uint32_t sum = 0;
+	for ( uint32_t p = p0; p < p1; ++p ) { uint32_t const n = votePass2(B,pile,p,0); B.oc[pile.posbase+p] = n; sum += n; }
+	part[tid] = sum;
+	__syncthreads();
+	if ( tid == 0 ) { uint32_t run = 0; for ( uint32_t i = 0; i < 256; ++i ) { uint32_t const t = part[i]; part[i] = run; run += t; } if ( run > 2*np+64 ) atomicOr(B.errflag,2u); }
+	__syncthreads();
+	uint32_t run = part[tid];
+	uint32_t const total = part[255] + ((tid == 255) ? 0 : 0);
+	(void)total;
+	uint64_t const symbase = 2*pile.posbase + 64ull*pi;
+	for ( uint32_t p = p0; p < p1; ++p ) { B.ocs[pile.posbase+p] = run; run += B.oc[pile.posbase+p]; }
+	__syncthreads();
+	bool const fits = (*B.errflag & 2u) == 0;
+	if ( fits )
+		for ( uint32_t p = p0; p < p1; ++p ) votePass2(B,pile,p,B.outsym+symbase+B.ocs[pile.posbase+p]);
+	__syncthreads();
+	if ( tid == 0 ) { if ( fits ) voteRuns(B,pile,pi); else B.nfrag[pi] = 0; }
+}
+
+// ---------------------------------------------------------------- host
+
+namespace {
+
+template<typename T>
+struct DevBuf
+{
+	T * p; size_t cap;
+	DevBuf() : p(0), cap(0) {}
+	hipError_t ensure(size_t n)
+	{
+		if ( n <= cap ) return hipSuccess;
+		if ( p ) { hipFree(p); p = 0; cap = 0; }
+		hipError_t const e = hipMalloc(reinterpret_cast<void **>(&p),n*sizeof(T));
+		if ( e == hipSuccess ) cap = n;
+		return e;
+	}
+	void release() { if ( p ) hipFree(p); p = 0; cap = 0; }
+};
+
+}
+
+struct dacc_ctx
+{
+	dacc_params par;
+	int device;
+	hipStream_t stream;
+	hipEvent_t ev[6];
+	std::string err;
+	bool haveprofile, havedb, havebatch;
+	double est_cor;
+	HostTables H;
+	DevTables T; DevParams P;
+	DevBuf<double> d_dpnorm, d_dpsq; DevBuf<uint64_t> d_vs; DevBuf<uint16_t> d_first, d_size, d_suplo, d_suphi; DevBuf<uint32_t> d_klim;
+	DevBuf<uint8_t> d_bps; DevBuf<uint64_t> d_boff; DevBuf<uint32_t> d_rlen;
+	std::vector<uint32_t> h_rlen;
+	BatchPlan BP;
+	DevBuf<DevPile> d_piles; DevBuf<DevOvl> d_ovl; DevBuf<uint32_t> d_ovl_pile; DevBuf<uint8_t> d_trace;
+	DevBuf<uint32_t> d_blk_ovl, d_blk_b0, d_wt_b, d_wt_e;
+	DevBuf<uint64_t> d_colv; DevBuf<uint16_t> d_colbot;
+	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
+	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
+	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase;
+	uint32_t tr_threads, win_grid;
+	std::vector<dacc_fragment> frags; std::string bases;
+	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
+	dacc_timing timing;
+};
+
+#define HIPCHK(call) do { hipError_t const e_ = (call); if ( e_ != hipSuccess ) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return DACC_EHIP; } } while (0)
+
+template<typename T>
+static int upload(dacc_ctx * c, DevBuf<T> & b, T const * src, size_t n)
+{
+	HIPCHK(b.ensure(n ? n : 1));
+	if ( n ) HIPCHK(hipMemcpyAsync(b.p,src,n*sizeof(T),hipMemcpyHostToDevice,c->stream));
+	return DACC_OK;
+}
+
+extern "C" {
+
+int dacc_create(dacc_ctx ** out, dacc_params const * p)
+{
+	if ( !out || !p ) return DACC_EINVAL;
+	*out = 0;
+	if ( p->klow < 3 || p->khigh > 16 || p->klow > p->khigh || !p->w || !p->a || p->w > 64 || p->minfilterfreq < 0 ||
+	     p->maxfilterfreq < p->minfilterfreq || p->tspace <= 0 )
+		return DACC_EINVAL;
+	int ndev = 0;
+	if ( hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev )
+		return DACC_ENODEV;
+	if ( hipSetDevice(p->device) != hipSuccess ) return DACC_ENODEV;
+	dacc_ctx * c = new (std::nothrow) dacc_ctx;
+	if ( !c ) return DACC_ENOMEM;
+	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0;
+	std::memset(&c->timing,0,sizeof(c->timing));
+	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
+	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
+	*out = c;
+	return DACC_OK;
+}
+
+void dacc_destroy(dacc_ctx * c)
+{
+	if ( !c ) return;
+	hipSetDevice(c->device);
+	hipStreamSynchronize(c->stream);
+	c->d_dpnorm.release(); c->d_dpsq.release(); c->d_vs.release(); c->d_first.release(); c->d_size.release(); c->d_suplo.release(); c->d_suphi.release(); c->d_klim.release();
+	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
+	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
+	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release();
+	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
+	hipStreamDestroy(c->stream);
+	delete c;
+}
+
+char const * dacc_last_error(dacc_ctx * c) { return c ? c->err.c_str() : "null context"; }
+
+int dacc_set_error_profile(dacc_ctx * c, double p_i, double p_d, double est_cor)
+{
+	if ( !c ) return DACC_EINVAL;
+	if ( !(p_i >= 0 && p_i < 1 && p_d >= 0 && p_d < 1 && est_cor >= 0 && est_cor <= 1) ) { c->err = "error profile out of range"; return DACC_EINVAL; }
+	hipSetDevice(c->device);
+	buildHostTables(c->H,c->par.w,p_i,p_d,est_cor,c->par.klow,c->par.khigh,4200);
+	c->est_cor = est_cor;
+	int rc;
+	if ( (rc = upload(c,c->d_dpnorm,c->H.dpnorm.data(),c->H.dpnorm.size())) ) return rc;
+	if ( (rc = upload(c,c->d_dpsq,c->H.dpsq.data(),c->H.dpsq.size())) ) return rc;
+	if ( (rc = upload(c,c->d_vs,c->H.dpsq_vs.data(),c->H.dpsq_vs.size())) ) return rc;
+	if ( (rc = upload(c,c->d_first,c->H.dpsq_first.data(),c->H.dpsq_first.size())) ) return rc;
+	if ( (rc = upload(c,c->d_size,c->H.dpsq_size.data(),c->H.dpsq_size.size())) ) return rc;
+	if ( (rc = upload(c,c->d_suplo,c->H.suplo.data(),c->H.suplo.size())) ) return rc;
+	if ( (rc = upload(c,c->d_suphi,c->H.suphi.data(),c->H.suphi.size())) ) return rc;
+	if ( (rc = upload(c,c->d_klim,c->H.klim.data(),c->H.klim.size())) ) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	DevTables & T = c->T;
+	T.nrows = c->H.nrows; T.nsup = c->H.nsup; T.kln = c->H.kln; T.pad = 0;
+	T.dpnorm = c->d_dpnorm.p; T.dpsq = c->d_dpsq.p; T.dpsq_vs = c->d_vs.p; T.dpsq_first = c->d_first.p; T.dpsq_size = c->d_size.p;
+	T.suplo = c->d_suplo.p; T.suphi = c->d_suphi.p; T.klim = c->d_klim.p;
+	dacc_params const & p = c->par;
+	DevParams & P = c->P;
+	P.w = p.w; P.a = p.a; P.klow = p.klow; P.khigh = p.khigh; P.minff = p.minfilterfreq; P.maxff = p.maxfilterfreq;
+	P.minwindowcov = p.minwindowcov; P.checklim = (est_cor != 0.0); P.maxalign = p.maxalign; P.eminrate = p.eminrate;
+	P.tspace = p.tspace; P.producefull = p.producefull; P.minlen = p.minlen;
+	c->haveprofile = true;
+	return DACC_OK;
+}
+
+int dacc_debug_tables(dacc_ctx * c, uint64_t * out, uint64_t cap, uint64_t * n, uint64_t klimit_n)
+{
+	if ( !c || !n ) return DACC_EINVAL;
+	if ( !c->haveprofile ) return DACC_ESTATE;
+	std::vector<uint64_t> B; serialiseHostTables(c->H,B,klimit_n);
+	*n = B.size();
+	if ( out ) std::memcpy(out,B.data(),8*std::min<uint64_t>(cap,B.size()));
+	return DACC_OK;
+}
+
+int dacc_load_db(dacc_ctx * c, uint8_t const * bps, uint64_t bps_bytes, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads)
+{
+	if ( !c || !bps || !boff || !rlen || !nreads ) return DACC_EINVAL;
+	hipSetDevice(c->device);
+	for ( uint64_t i = 0; i < nreads; ++i )
+		if ( boff[i] + (rlen[i]+3)/4 > bps_bytes ) { c->err = "read store offsets exceed the buffer"; return DACC_EINVAL; }
+	int rc;
+	HIPCHK(c->d_bps.ensure(bps_bytes+16));
+	HIPCHK(hipMemsetAsync(c->d_bps.p,0,bps_bytes+16,c->stream));
+	HIPCHK(hipMemcpyAsync(c->d_bps.p,bps,bps_bytes,hipMemcpyHostToDevice,c->stream));
+	if ( (rc = upload(c,c->d_boff,boff,nreads)) ) return rc;
+	if ( (rc = upload(c,c->d_rlen,rlen,nreads)) ) return rc;
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->h_rlen.assign(rlen,rlen+nreads);
+	c->havedb = true;
+	return DACC_OK;
+}
+
+static int runDevice(dacc_ctx * c)
+{
+	BatchPlan & BP = c->BP;
+	hipStream_t const s = c->stream;
+	HIPCHK(hipMemsetAsync(c->d_err.p,0,4*sizeof(uint32_t),s));
+	HIPCHK(hipEventRecord(c->ev[0],s));
+	if ( BP.ovl.size() )
+	{
+		PrepBatch PB; PB.ovl = c->d_ovl.p; PB.novl = BP.ovl.size(); PB.trace = c->d_trace.p; PB.blk_ovl = c->d_blk_ovl.p; PB.blk_b0 = c->d_blk_b0.p;
+		hipLaunchKernelGGL(k_prep,dim3((BP.ovl.size()+255)/256),dim3(256),0,s,PB);
+	}
+	if ( BP.nblocks )
+	{
+		TraceBatch TB;
+		TB.P = c->P; TB.bps = c->d_bps.p; TB.boff = c->d_boff.p; TB.rlen = c->d_rlen.p;
+		TB.piles = c->d_piles.p; TB.ovl = c->d_ovl.p; TB.ovl_pile = c->d_ovl_pile.p; TB.trace = c->d_trace.p;
+		TB.blk_ovl = c->d_blk_ovl.p; TB.blk_b0 = c->d_blk_b0.p; TB.nblocks = BP.nblocks; TB.wt_b = c->d_wt_b.p; TB.wt_e = c->d_wt_e.p;
+		TB.colv = c->d_colv.p; TB.colbot = c->d_colbot.p; TB.maxcols = BP.maxcols; TB.nthreads = c->tr_threads; TB.errflag = c->d_err.p + 2;
+		hipLaunchKernelGGL(k_trace,dim3(c->tr_threads/256),dim3(256),0,s,TB);
+	}
+	HIPCHK(hipEventRecord(c->ev[1],s));
+	if ( BP.nwindows )
+	{
+		WindowBatch WB;
+		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
+		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
+		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p;
+		hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p);
+	}
+	HIPCHK(hipEventRecord(c->ev[2],s));
+	if ( BP.piles.size() )
+	{
+		VoteBatch VB;
+		VB.P = c->P; VB.bps = c->d_bps.p; VB.boff = c->d_boff.p; VB.rlen = c->d_rlen.p; VB.piles = c->d_piles.p; VB.npiles = BP.piles.size();
+		VB.wrec = c->d_wrec.p; VB.has = c->d_has.p; VB.ld0 = c->d_ld0.p; VB.oc = c->d_oc.p; VB.ocs = c->d_ocs.p; VB.outsym = c->d_outsym.p;
+		VB.frags = c->d_frags.p; VB.fragbase = c->d_fragbase.p; VB.nfrag = c->d_nfrag.p; VB.errflag = c->d_err.p + 1;
+		hipLaunchKernelGGL(k_vote,dim3(BP.piles.size()),dim3(256),0,s,VB);
+	}
+	HIPCHK(hipEventRecord(c->ev[3],s));
+	HIPCHK(hipGetLastError());
+	// results
+	uint32_t herr[4] = {0,0,0,0};
+	size_t const symbytes = 2*BP.npos + 64*BP.piles.size() + 64;
+	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
+	HIPCHK(hipMemcpyAsync(herr,c->d_err.p,sizeof(herr),hipMemcpyDeviceToHost,s));
+	if ( BP.piles.size() )
+	{
+		HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
+		HIPCHK(hipMemcpyAsync(c->h_frags.data(),c->d_frags.p,BP.nfragslots*sizeof(VoteFragment),hipMemcpyDeviceToHost,s));
+		HIPCHK(hipMemcpyAsync(c->h_outsym.data(),c->d_outsym.p,symbytes,hipMemcpyDeviceToHost,s));
+	}
+	HIPCHK(hipEventRecord(c->ev[4],s));
+	HIPCHK(hipStreamSynchronize(s));
+	if ( herr[0] ) { c->err = "window kernel scratch capacity exceeded (depth / graph size); lower -d or use smaller piles"; return DACC_ENOTSUP; }
+	if ( herr[1] ) { c->err = "vote kernel capacity exceeded"; return DACC_ENOTSUP; }
+	if ( herr[2] ) { c->err = "trace kernel capacity exceeded (tspace block longer than 128 or B span > 255)"; return DACC_ENOTSUP; }
+	c->frags.clear(); c->bases.clear();
+	uint64_t nbases = 0;
+	for ( uint64_t pi = 0; pi < BP.piles.size(); ++pi )
+		for ( uint32_t f = 0; f < c->h_nfrag[pi]; ++f ) nbases += c->h_frags[BP.fragbase[pi]+f].len;
+	c->bases.reserve(nbases);
+	for ( uint64_t pi = 0; pi < BP.piles.size(); ++pi )
+		for ( uint32_t f = 0; f < c->h_nfrag[pi]; ++f )
+		{
+			VoteFragment const & F = c->h_frags[BP.fragbase[pi]+f];
+			dacc_fragment g; g.aread = BP.piles[pi].aread; g.first = F.first; g.last = F.last; g.len = F.len; g.seq_off = c->bases.size();
+			for ( uint32_t i = 0; i < F.len; ++i ) c->bases.push_back("ACGTDacgt"[c->h_outsym[F.off+i]]);
+			c->frags.push_back(g);
+		}
+	float ms = 0;
+	hipEventElapsedTime(&ms,c->ev[0],c->ev[1]); c->timing.trace_ms = ms;
+	hipEventElapsedTime(&ms,c->ev[1],c->ev[2]); c->timing.window_ms = ms;
+	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
+	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
+	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
+	c->timing.nwindows = BP.nwindows; c->timing.nblocks = BP.nblocks; c->timing.algo_bytes = BP.algo_bytes + nbases;
+	return DACC_OK;
+}
+
+int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl,
+	void const * trace, uint64_t ntrace, int trace_bytes)
+{
+	if ( !c ) return DACC_EINVAL;
+	if ( !c->haveprofile || !c->havedb ) { c->err = "dacc_set_error_profile and dacc_load_db must precede dacc_submit_piles"; return DACC_ESTATE; }
+	if ( (npiles && !piles) || (novl && (!ovl || !trace)) ) return DACC_EINVAL;
+	hipSetDevice(c->device);
+	c->havebatch = false;
+	BatchPlan & BP = c->BP;
+	int rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->h_rlen.data(),c->h_rlen.size(),c->err);
+	if ( rc ) return rc;
+	hipStream_t const s = c->stream;
+	HIPCHK(c->d_err.ensure(4));
+	HIPCHK(hipEventRecord(c->ev[5],s));
+	if ( (rc = upload(c,c->d_piles,BP.piles.data(),BP.piles.size())) ) return rc;
+	if ( (rc = upload(c,c->d_ovl,BP.ovl.data(),BP.ovl.size())) ) return rc;
+	if ( (rc = upload(c,c->d_ovl_pile,BP.ovl_pile.data(),BP.ovl_pile.size())) ) return rc;
+	if ( (rc = upload(c,c->d_trace,static_cast<uint8_t const *>(trace),ntrace*trace_bytes)) ) return rc;
+	if ( (rc = upload(c,c->d_fragbase,BP.fragbase.data(),BP.fragbase.size())) ) return rc;
+	HIPCHK(c->d_blk_ovl.ensure(BP.nblocks+1)); HIPCHK(c->d_blk_b0.ensure(BP.nblocks+1));
+	HIPCHK(c->d_wt_b.ensure(BP.nwt+1)); HIPCHK(c->d_wt_e.ensure(BP.nwt+1));
+	// trace kernel geometry + column slabs
+	uint64_t tthreads = ((BP.nblocks+255)/256)*256;
+	if ( tthreads > 256ull*1024 ) tthreads = 256ull*1024;
+	if ( tthreads < 256 ) tthreads = 256;
+	c->tr_threads = tthreads;
+	HIPCHK(c->d_colv.ensure(static_cast<size_t>(BP.maxcols+2)*tthreads*4));
+	HIPCHK(c->d_colbot.ensure(static_cast<size_t>(BP.maxcols+2)*tthreads));
+	// window kernel geometry + arenas
+	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
+	uint64_t wg = ((BP.nwindows+7)/8)*8;
+	uint64_t const maxwg = 256*12;
+	if ( wg > maxwg ) wg = maxwg;
+	if ( wg < 8 ) wg = 8;
+	c->win_grid = wg;
+	HIPCHK(c->d_arena.ensure(wg*BP.caps.bytes));
+	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
+	HIPCHK(c->d_has.ensure(BP.npos+1)); HIPCHK(c->d_oc.ensure(BP.npos+1)); HIPCHK(c->d_ld0.ensure(BP.npos+1)); HIPCHK(c->d_ocs.ensure(BP.npos+1));
+	HIPCHK(c->d_outsym.ensure(2*BP.npos + 64*BP.piles.size() + 64));
+	HIPCHK(c->d_nfrag.ensure(BP.piles.size()+1)); HIPCHK(c->d_frags.ensure(BP.nfragslots+1));
+	hipEvent_t h2dend; hipEventCreate(&h2dend); hipEventRecord(h2dend,s);
+	rc = runDevice(c);
+	float ms = 0; hipEventElapsedTime(&ms,c->ev[5],h2dend); c->timing.h2d_ms = ms; hipEventDestroy(h2dend);
+	if ( rc ) return rc;
+	c->havebatch = true;
+	return DACC_OK;
+}
+
+int dacc_rerun_resident(dacc_ctx * c)
+{
+	if ( !c ) return DACC_EINVAL;
+	if ( !c->havebatch ) { c->err = "no resident batch"; return DACC_ESTATE; }
+	hipSetDevice(c->device);
+	return runDevice(c);
+}
+
+int dacc_collect(dacc_ctx * c, dacc_fragment const ** frags, uint64_t * nfrags, char const ** bases, uint64_t * nbases)
+{
+	if ( !c || !frags || !nfrags || !bases || !nbases ) return DACC_EINVAL;
+	if ( !c->havebatch ) return DACC_ESTATE;
+	*frags = c->frags.data(); *nfrags = c->frags.size(); *bases = c->bases.data(); *nbases = c->bases.size();
+	return DACC_OK;
+}
+
+void dacc_release(dacc_ctx * c) { if ( c ) { c->frags.clear(); c->bases.clear(); } }
+
+int dacc_last_timing(dacc_ctx * c, dacc_timing * t)
+{
+	if ( !c || !t ) return DACC_EINVAL;
+	*t = c->timing;
+	return DACC_OK;
+}
+
+int dacc_debug_windows(dacc_ctx * c, dacc_window_result * out, uint64_t cap, uint64_t * nwin)
+{
+	if ( !c || !nwin ) return DACC_EINVAL;
+	if ( !c->havebatch ) return DACC_ESTATE;
+	BatchPlan & BP = c->BP;
+	*nwin = BP.nwindows;
+	if ( !out ) return DACC_OK;
+	hipSetDevice(c->device);
+	std::vector<WindowOut> wout(BP.nwindows); std::vector<uint8_t> wrec(BP.nwindows*WREC);
+	if ( BP.nwindows )
+	{
+		HIPCHK(hipMemcpy(wout.data(),c->d_wout.p,BP.nwindows*sizeof(WindowOut),hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(wrec.data(),c->d_wrec.p,BP.nwindows*WREC,hipMemcpyDeviceToHost));
+	}
+	uint64_t i = 0;
+	for ( uint64_t pi = 0; pi < BP.piles.size() && i < cap; ++pi )
+		for ( uint32_t y = 0; y < BP.piles[pi].nwin && i < cap; ++y, ++i )
+		{
+			uint64_t const wdx = BP.piles[pi].winbase+y;
+			WindowOut const & o = wout[wdx];
+			dacc_window_result r; std::memset(&r,0,sizeof(r));
+			r.pile = pi; r.y = y; r.status = o.status; r.mao = o.mao; r.elength = o.elength; r.k = o.k;
+			r.filterfreq = (o.status == WS_OK) ? o.filterfreq : 0; r.conslen = o.conslen; r.minrate = o.minrate;
+			if ( o.status == WS_OK )
+			{
+				uint8_t const * rec = wrec.data() + wdx*WREC;
+				uint8_t const * off = rec+1; uint8_t const * sym = rec+1+(c->P.w+2);
+				uint32_t cl = 0;
+				for ( uint32_t q = 0; q < off[c->P.w+1] && cl < 79; ++q ) if ( sym[q] < 4 ) r.cons[cl++] = "ACGT"[sym[q]];
+			}
+			out[i] = r;
+		}
+	return DACC_OK;
+}
+
+}

@@ -14,6 +14,7 @@
 
 #if defined(DACC_EMUL)
   #define DEV inline
+  #define HDEV inline
   #define WSZ 1
   namespace dacc {
   static inline int wv_lane() { return 0; }
@@ -34,6 +35,7 @@
 #else
   #include <hip/hip_runtime.h>
   #define DEV __device__ __forceinline__
+  #define HDEV __host__ __device__ __forceinline__
   #define WSZ 64
   namespace dacc {
   DEV int wv_lane() { return threadIdx.x & 63; }
@@ -141,7 +143,7 @@ DEV void wv_bitonic_sort_idx(uint32_t * I, uint64_t const * K, uint32_t const n)
 		}
 }
 
-DEV uint32_t next_pow2(uint32_t v)
+HDEV uint32_t next_pow2(uint32_t v)
 {
 	uint32_t p = 1;
 	while ( p < v ) p <<= 1;

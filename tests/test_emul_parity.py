@@ -1,0 +1,57 @@
+"""Kernel LOGIC vs oracle on the CPU: the device headers compiled as a 1-lane wavefront
+(tests/emul/emul.cpp, test harness only) must reproduce the oracle bit for bit -- tables, per-window
+consensus, fragments.  The real 64-lane gfx950 build is checked by test_gpu_parity.py (-m gpu)."""
+import pytest
+import pyoracle
+import emul_lib
+from daccord_amd._structs import default_params
+from daccord_amd.synth import SynthData
+from common import windows_equal, frags_equal
+
+
+def _both(d, ovl, piles, sel, **kw):
+    p = default_params(**kw)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[sel], ovl, d.trace, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[sel], ovl, d.trace)
+    return O, E, (fo, bo), (fe, be)
+
+
+def test_tables_bit_identical():
+    for kw in (dict(k=8), dict(klow=8, khigh=10), dict(k=14, w=32, a=8)):
+        p = default_params(**kw)
+        O = pyoracle.Oracle(p); E = emul_lib.Emul(p)
+        for prof in ((0.12, 0.02, 0.85), (0.05, 0.05, 0.85), (0.01, 0.002, 0.98)):
+            O.set_error_profile(*prof); E.set_error_profile(*prof)
+            assert (O.tables(200) == E.tables(200)).all()
+
+
+@pytest.mark.parametrize("kw", [dict(k=8), dict(k=14), dict(klow=8, khigh=9), dict(k=8, maxalign=6),
+                                dict(k=8, producefull=1), dict(k=10, w=32, a=8), dict(k=8, minlen=3000)])
+def test_windows_and_fragments(small_data, kw):
+    d, ovl, piles = small_data
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 3), **kw)
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)
+
+
+def test_high_error_exercises_gap_filling_and_failures():
+    d = SynthData(60000, 150, 3000, erate=0.30, seed=4)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 3), k=10)
+    wo = O.windows()
+    assert (wo["status"] == 2).any()                      # failed windows occur
+    assert ((wo["status"] == 1) & (wo["filterfreq"] == 0)).any()   # found only after gap filling
+    assert windows_equal(wo, E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)
+
+
+def test_empty_and_shallow_piles(small_data):
+    d, ovl, piles = small_data
+    p = piles[:2].copy()
+    p[0]["novl"] = 0                                       # empty pile: no windows, no fragments
+    p[1]["novl"] = 1                                       # A + 1 B = depth 2 < -m 3 everywhere
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, p, slice(0, 2), k=8)
+    assert len(fo) == 0 and frags_equal(fo, bo, fe, be)
+    assert windows_equal(O.windows(), E.windows()) == []

@@ -1,0 +1,117 @@
+"""Parity tests proper: the gfx950 kernels, called through the C ABI, against the oracle on the same
+seeded inputs -- bit-exact per-window consensus and FASTA.  Run with -m gpu on an MI355X."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+import pyoracle
+from daccord_amd import engine
+from daccord_amd._structs import default_params
+from daccord_amd.synth import SynthData
+from common import windows_equal, frags_equal, truth_error
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _pair(d, **kw):
+    p = default_params(**kw)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    return O, E
+
+
+def test_library_loaded_is_the_hip_one():
+    assert os.path.exists(engine._SO)
+    L = engine.lib()
+    assert hasattr(L, "dacc_rerun_resident")
+
+
+def test_tables_bit_identical():
+    p = default_params(klow=8, khigh=10)
+    O = pyoracle.Oracle(p); E = engine.Engine(p)
+    for prof in ((0.12, 0.02, 0.85), (0.05, 0.05, 0.85)):
+        O.set_error_profile(*prof); E.set_error_profile(*prof)
+        assert (O.tables(200) == E.tables(200)).all()
+
+
+@pytest.mark.parametrize("kw", [dict(k=8), dict(k=14), dict(klow=8, khigh=9), dict(k=8, maxalign=6),
+                                dict(k=8, producefull=1), dict(k=10, w=32, a=8), dict(k=16)])
+def test_windows_and_fragments(small_data, kw):
+    d, ovl, piles = small_data
+    O, E = _pair(d, **kw)
+    fo, bo = O.run(piles[:8], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:8], ovl, d.trace)
+    bad = windows_equal(O.windows(), E.debug_windows())
+    assert bad == [], (len(bad), bad[:5])
+    assert frags_equal(fo, bo, fx, bx)
+    assert engine.fasta(fx, bx) == pyoracle.fasta(fo, bo)
+
+
+def test_golden_fixture(small_data):
+    with open(os.path.join(HERE, "golden", "oracle_small.json")) as f:
+        G = json.load(f)
+    d, ovl, piles = small_data
+    E = engine.Engine(default_params(k=G["k"])); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E(piles[:G["npiles"]], ovl, d.trace)
+    assert hashlib.sha256(engine.fasta(fx, bx).encode()).hexdigest() == G["fasta_sha256"]
+
+
+def test_high_error_gap_filling_and_failures():
+    d = SynthData(60000, 150, 3000, erate=0.30, seed=4)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E = _pair(d, k=10)
+    fo, bo = O.run(piles[:12], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:12], ovl, d.trace)
+    wo = O.windows()
+    assert (wo["status"] == 2).any() and ((wo["status"] == 1) & (wo["filterfreq"] == 0)).any()
+    assert windows_equal(wo, E.debug_windows()) == []
+    assert frags_equal(fo, bo, fx, bx)
+
+
+def test_ont_like_profile_k_sweep():
+    d = SynthData(60000, 150, 3000, erate=0.15, ins_frac=1 / 3, del_frac=1 / 3, sub_frac=1 / 3, seed=5)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    for k in (10, 12, 14, 16):
+        O, E = _pair(d, k=k)
+        fo, bo = O.run(piles[:4], ovl, d.trace, nthreads=8, want_windows=True)
+        fx, bx = E(piles[:4], ovl, d.trace)
+        assert windows_equal(O.windows(), E.debug_windows()) == []
+        assert frags_equal(fo, bo, fx, bx)
+
+
+def test_empty_shallow_and_rerun(small_data):
+    d, ovl, piles = small_data
+    p = piles[:3].copy()
+    p[0]["novl"] = 0; p[1]["novl"] = 1
+    O, E = _pair(d, k=8)
+    fo, bo = O.run(p, ovl, d.trace, nthreads=4)
+    fx, bx = E(p, ovl, d.trace)
+    assert frags_equal(fo, bo, fx, bx)
+    E.rerun()                                             # idempotence on the resident batch
+    fy, by = E.collect()
+    assert frags_equal(fx, bx, fy, by)
+
+
+def test_perfect_piles_full_size_property():
+    """Size-independent property at a larger size: error-free piles return the reads themselves."""
+    d = SynthData(400000, 800, 5000, erate=0.0, seed=6)
+    ovl, piles = engine.pile_select(d.ovl, d.piles)
+    E = engine.Engine(default_params(k=8)); E.set_error_profile(0.12, 0.02, 0.85); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E(piles[:200], ovl, d.trace)
+    assert len(fx) >= 200
+    for f in fx[::7]:
+        rid = f["aread"]
+        read = bytes(b"ACGT"[(d.bps[d.boff[rid] + (i >> 2)] >> (6 - 2 * (i & 3))) & 3] for i in range(d.rlen[rid]))
+        assert bx[f["seq_off"]:f["seq_off"] + f["len"]] == read[f["first"]:f["last"] + 1]
+
+
+def test_accuracy_vs_truth_larger():
+    d = SynthData(400000, 800, 5000, seed=7)
+    ovl, piles = engine.pile_select(d.ovl, d.piles)
+    E = engine.Engine(default_params(k=8)); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E(piles[:100], ovl, d.trace)
+    L = pyoracle.lib()
+    ed, n = truth_error(d, fx[:40], bx, lambda a, b: L.oracle_edit_distance(a, len(a), b, len(b)))
+    assert n > 0 and ed / n < 0.02
