@@ -142,7 +142,7 @@ struct dacc_ctx
 	DevBuf<uint64_t> d_colv; DevBuf<uint16_t> d_colbot;
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
-	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase;
+	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
 	uint32_t tr_threads, win_grid;
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
@@ -191,7 +191,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -283,7 +283,7 @@ static int runDevice(dacc_ctx * c)
 		WindowBatch WB;
 		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
 		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
-		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p;
+		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = c->d_prof.p;
 		hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p);
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
@@ -349,6 +349,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	if ( rc ) return rc;
 	hipStream_t const s = c->stream;
 	HIPCHK(c->d_err.ensure(4));
+	HIPCHK(c->d_prof.ensure(32)); HIPCHK(hipMemsetAsync(c->d_prof.p,0,32*sizeof(uint64_t),s));
 	HIPCHK(hipEventRecord(c->ev[5],s));
 	if ( (rc = upload(c,c->d_piles,BP.piles.data(),BP.piles.size())) ) return rc;
 	if ( (rc = upload(c,c->d_ovl,BP.ovl.data(),BP.ovl.size())) ) return rc;
@@ -406,6 +407,16 @@ int dacc_last_timing(dacc_ctx * c, dacc_timing * t)
 {
 	if ( !c || !t ) return DACC_EINVAL;
 	*t = c->timing;
+	return DACC_OK;
+}
+
+// per-phase cycle counters of the window kernel (all zero unless built with -DDACC_PROFILE)
+int dacc_debug_profile(dacc_ctx * c, uint64_t * out32)
+{
+	if ( !c || !out32 ) return DACC_EINVAL;
+	if ( !c->havebatch ) return DACC_ESTATE;
+	hipSetDevice(c->device);
+	HIPCHK(hipMemcpy(out32,c->d_prof.p,32*sizeof(uint64_t),hipMemcpyDeviceToHost));
 	return DACC_OK;
 }
 

@@ -27,6 +27,15 @@ namespace dacc {
 
 #define DACC_DBL_MIN 2.2250738585072014e-308
 
+// optional per-phase cycle accounting (profiling builds only: -DDACC_PROFILE)
+#if defined(DACC_PROFILE) && !defined(DACC_EMUL)
+  #define PROF_T0 uint64_t _pt = clock64();
+  #define PROF(E_,id) { uint64_t const _n = clock64(); if ( (E_).lane == 0 && (E_).prof ) atomicAdd(reinterpret_cast<unsigned long long *>((E_).prof+(id)),static_cast<unsigned long long>(_n-_pt)); _pt = _n; }
+#else
+  #define PROF_T0
+  #define PROF(E_,id)
+#endif
+
 struct WindowOut
 {
 	int32_t status, mao, elength, k, filterfreq, conslen;
@@ -76,6 +85,7 @@ struct WindowEngine
 	DevTables T;
 	DevParams P;
 	int lane;
+	uint64_t * prof;
 	uint32_t flags;      // overflow flags (wave-uniform after wv_any)
 
 	// window strings
@@ -86,8 +96,15 @@ struct WindowEngine
 	uint32_t nmfirst, nmlast;
 	uint32_t nstretch, nlinks, nsf, ncsf, nrl;
 	uint32_t nrp, narp, np, nsiq, ncdh, nacc, conso;
+	uint32_t maxsiq, maxlinks;
 
 	DEV void setOverflow(uint32_t bit) { flags |= bit; }
+#if defined(DACC_STATS)
+	uint32_t st[16];
+	DEV void stat(int i, uint32_t v) { if ( v > st[i] ) st[i] = v; }
+#else
+	DEV void stat(int, uint32_t) {}
+#endif
 
 	// ---- k-mer -> node id by binary search over the ascending node keys ----
 	DEV int32_t findNode(uint32_t const v) const
@@ -499,6 +516,7 @@ struct WindowEngine
 			base += tot;
 		}
 		if ( 3*base+16 > C.linkcap ) { setOverflow(64); nstretch = 0; return; }
+		maxlinks = base;
 		uint32_t rawlinks = base;
 		wv_sync();
 		// pass 2: write node id chains
@@ -597,6 +615,7 @@ struct WindowEngine
 			if ( s < nstretch ) A.scfo[s] = cbase+pre;
 			cbase += tot;
 		}
+		nsf = base; ncsf = cbase;
 		if ( base > C.sfcap || cbase > C.sfcap ) { setOverflow(128); for ( uint32_t s = lane; s < nstretch; s += WSZ ) { A.sfl[s] = 0; A.scfl[s] = 0; } wv_sync(); return; }
 		for ( uint32_t s = lane; s < nstretch; s += WSZ )
 		{
@@ -994,7 +1013,7 @@ struct WindowEngine
 	DEV void forwardAndPairs(int32_t const firstnode, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
 	{
 		// lane 0 only
-		np = 0; nsiq = 0;
+		np = 0; nsiq = 0; maxsiq = 0;
 		for ( uint32_t s = 0; s < nstretch; ++s )
 			if ( A.sfirst[s] == firstnode )
 			{
@@ -1031,6 +1050,7 @@ struct WindowEngine
 					if ( nsiq >= C.poolcap ) { setOverflow(512); return; }
 					HeapSI si; si.left = sub; si.right = sup; si.current = mi; si.path = path; si.w = getPairScore(path,A.arp[mi]);
 					heap_push<HeapSI,CmpWGreater>(A.siq,nsiq,si);
+					if ( nsiq > maxsiq ) maxsiq = nsiq;
 				}
 				uint32_t const pbl = A.p_baselen[path];
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
@@ -1184,21 +1204,29 @@ struct WindowEngine
 				int32_t const firstnode = findNode(firstk);
 				int32_t const lastnode = findNode(lastk);
 				// prepareTraverse (:3541-3787)
+				PROF_T0
 				computeStretches(firstnode,lastnode);
+				PROF(*this,8)
 				computeStretchFeas();
+				PROF(*this,9)
 				computeStretchLinks();
+				PROF(*this,10)
 				if ( wv_any(flags != 0) ) return false;
 				if ( lane == 0 )
 				{
 					reverseEnumerate(lastk,lastnode,lmax);
+					PROF(*this,11)
 					if ( ! flags ) forwardAndPairs(firstnode,lmin,lmax,16);
+					PROF(*this,12)
 				}
 				wv_sync();
 				flags = wv_bcast(flags,0);
+				stat(0,nn); stat(1,npre); stat(2,nstretch); stat(3,nsf); stat(4,ncsf); stat(5,nrl); stat(6,nrp); stat(7,narp); stat(8,np); stat(9,maxsiq); stat(10,conso); stat(11,maxlinks);
 				if ( flags ) return false;
 			}
 		}
 		// CDH -> CH -> ACC in descending weight (:5099-5136), lane 0
+		PROF_T0
 		if ( lane == 0 )
 		{
 			uint32_t nch = 0;
@@ -1241,6 +1269,7 @@ struct WindowEngine
 			}
 		}
 		wv_sync();
+		PROF(*this,13)
 		return nc != 0;
 	}
 

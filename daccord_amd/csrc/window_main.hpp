@@ -27,6 +27,7 @@ struct WindowBatch
 	uint8_t * wrec;            // [nwindows][WREC]
 	WindowOut * wout;          // [nwindows]
 	uint8_t * arena;           // [gridDim][C.bytes]
+	uint64_t * prof;           // optional per-phase cycle counters (profiling builds)
 };
 
 // base i of read r in the orientation the overlap uses (HandleContext.hpp:1910, 1952)
@@ -50,6 +51,11 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 	E.C = B.C; E.T = B.T; E.P = B.P;
 	E.lane = wv_lane();
 	E.flags = 0;
+	E.prof = B.prof;
+#if defined(DACC_STATS)
+	for ( int i = 0; i < 16; ++i ) E.st[i] = 0;
+#endif
+	PROF_T0
 	arena_carve(E.A,arenabase,B.C);
 	Arena & A = E.A;
 	int const lane = E.lane;
@@ -118,6 +124,7 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 	}
 	wv_sync();
 	E.flags = wv_or(E.flags);
+	PROF(E,0)
 
 	int32_t elength = 0;
 	if ( mao && !E.flags )
@@ -126,6 +133,7 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 		elength = E.estimateLength() + 1;
 	}
 	out.elength = elength;
+	PROF(E,1)
 
 	if ( mao >= B.P.minwindowcov && !E.flags )
 	{
@@ -141,10 +149,15 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 			for ( int32_t ff = B.P.maxff; ff >= B.P.minff && !E.flags; --ff )
 			{
 				// setup + filterFreq + computeFeasibleKmerPositions (:2211-2228)
+				PROF_T0
 				E.buildInstances();
+				PROF(E,2)
 				E.buildNodes(ff > 1 ? ff : 1);
+				PROF(E,3)
 				E.buildSuccessors(mao);
+				PROF(E,4)
 				E.computeFeasible();
+				PROF(E,5)
 				if ( ff == 0 )
 				{
 					// gap filling (:2233-2268)
@@ -153,7 +166,9 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 					E.buildSuccessors(mao);
 					E.computeFeasible();
 				}
+				PROF(E,6)
 				E.buildFirstLast();
+				PROF(E,7)
 				E.flags = wv_or(E.flags);
 				if ( E.flags ) break;
 				uint32_t mintry = 0; bool lconsok = false;
@@ -193,7 +208,7 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 			if ( !pathfailed )
 			{
 				out.status = WS_OK; out.conslen = bestlen; out.minrate = minrate;
-				if ( lane == 0 ) E.alignAndEmit(best,bestlen,rec);
+				{ PROF_T0 if ( lane == 0 ) E.alignAndEmit(best,bestlen,rec); PROF(E,14) }
 			}
 			else out.status = WS_FAILED;
 		}
@@ -201,6 +216,9 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 	E.flags = wv_or(E.flags);
 	if ( E.flags ) { out.status = WS_OVERFLOW; out.flags = E.flags; if ( lane == 0 ) rec[0] = 0; }
 	if ( lane == 0 ) B.wout[widx] = out;
+#if defined(DACC_STATS)
+	for ( int i = 0; i < 16; ++i ) dacc_stats_sink(widx,i,E.st[i]);
+#endif
 	wv_sync();
 }
 

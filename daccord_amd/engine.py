@@ -12,7 +12,7 @@ import numpy as np
 from ._structs import (DaccParams, DaccOverlap, DaccPile, DaccFragment, DaccTiming, DaccWindowResult, default_params)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libdaccord_hip.so")
+_SO = os.environ.get("DACC_LIB") or os.path.join(_HERE, "libdaccord_hip.so")
 
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP", -6: "ENOTSUP"}
 
@@ -51,13 +51,14 @@ def lib():
         L.dacc_rerun_resident.argtypes = [vp]
         L.dacc_debug_windows.argtypes = [vp, vp, C.c_uint64, vp]
         L.dacc_debug_tables.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+        L.dacc_debug_profile.argtypes = [vp, vp]
         _lib = L
     return _lib
 
 
 EXPORTS = ["dacc_create", "dacc_destroy", "dacc_set_error_profile", "dacc_load_db", "dacc_submit_piles", "dacc_collect",
            "dacc_release", "dacc_last_error", "dacc_pile_select", "dacc_last_timing", "dacc_rerun_resident",
-           "dacc_debug_windows", "dacc_debug_tables"]
+           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile"]
 
 
 def _ptr(a):
@@ -145,6 +146,11 @@ class Engine:
         out = np.zeros(n.value, dtype=np.dtype(DaccWindowResult))
         if n.value:
             self._chk(self.L.dacc_debug_windows(self.h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def profile(self):
+        out = np.zeros(32, dtype=np.uint64)
+        self._chk(self.L.dacc_debug_profile(self.h, _ptr(out)))
         return out
 
     def tables(self, klimit_n=128):

@@ -166,6 +166,10 @@ int  dacc_debug_windows(dacc_ctx *ctx, dacc_window_result *out, uint64_t cap, ui
  * dacc_set_error_profile (compared bit for bit with the oracle's). */
 int  dacc_debug_tables(dacc_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *n, uint64_t klimit_n);
 
+/* Profiling hook: 32 per-phase shader-cycle counters of the window kernel (zero unless the library was
+ * built with -DDACC_PROFILE). */
+int  dacc_debug_profile(dacc_ctx *ctx, uint64_t *out32);
+
 #ifdef __cplusplus
 }
 #endif
