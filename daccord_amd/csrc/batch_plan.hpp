@@ -14,6 +14,7 @@
 #include <cstdint>
 #include "../../include/daccord_hip.h"
 #include "dev_types.hpp"
+#include "fast_window.hpp"
 
 namespace dacc {
 
@@ -40,9 +41,11 @@ struct BatchPlan
 	uint64_t nwindows, nblocks, nwt, npos, nfragslots, algo_bytes;
 	uint32_t maxdepth, maxcols;
 	ArenaCaps caps;
+	FastCaps fcaps;
 
 	int plan(dacc_params const & par, dacc_pile const * P, uint64_t const np, dacc_overlap const * O, uint64_t const no,
-		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err)
+		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err,
+		uint32_t const tab_nrows = 0, uint32_t const tab_nsup = 0)
 	{
 		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear();
 		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0;
@@ -140,6 +143,12 @@ struct BatchPlan
 		caps.blcap = 256;
 		caps.conscap = 32768 + MAXCONS;
 		caps.pad = 0; caps.bytes = 0;
+		// LDS fast path capacities (windows beyond them are re-run by the generic engine)
+		fcaps.maxs = std::min<uint32_t>(std::max<uint32_t>(caps.maxs,8),64);
+		fcaps.precap = 1024; fcaps.ncap = 896; fcaps.scap = 160; fcaps.lcap = 1024; fcaps.pcapr = 96; fcaps.pcapf = 192;
+		fcaps.siqcap = 128; fcaps.blcap = 96; fcaps.sfcap = 4096; fcaps.conscap = 16384 + MAXCONS; fcaps.pad = 0; fcaps.pad2 = 0;
+		fcaps.nrows = tab_nrows; fcaps.nsup = tab_nsup;
+		{ FastLds L; fcaps.ldsbytes = fast_lds_carve(L,0,fcaps); FastGlobal G; fcaps.gbytes = (fast_global_carve(G,0,fcaps)+255)&~255ull; }
 		return DACC_OK;
 	}
 };

@@ -8,11 +8,13 @@
 #include <string>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <new>
 #include "../../include/daccord_hip.h"
 #include "batch_plan.hpp"
 #include "host_tables.hpp"
 #include "window_main.hpp"
+#include "fast_window.hpp"
 #include "trace_kernel.hpp"
 #include "vote_kernel.hpp"
 
@@ -50,20 +52,45 @@ __global__ void __launch_bounds__(256) k_trace(TraceBatch B)
 // one wavefront per workgroup, grid-stride over windows.  Workgroup b lands on XCD b%8 (observed
 // placement, used for L2 affinity only): give every XCD a contiguous run of windows so that the
 // windows of one pile (which share the pile's overlaps and reads) hit one L2.
-__global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag)
+// generic engine: all windows (list == 0) or the windows the LDS fast path handed back (list[0] = count)
+__global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag, uint32_t const * list)
 {
 	uint32_t const G = gridDim.x;
 	uint32_t const b = blockIdx.x;
 	uint32_t const perx = G >> 3;
 	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
 	uint8_t * arena = B.arena + static_cast<uint64_t>(b)*B.C.bytes;
-	for ( uint64_t base = 0; base < B.nwindows; base += G )
+	uint64_t const n = list ? list[0] : B.nwindows;
+	for ( uint64_t base = 0; base < n; base += G )
 	{
-		uint64_t const w = base + slot;
-		if ( w < B.nwindows )
+		uint64_t const i = base + (list ? b : slot);
+		if ( i < n )
 		{
+			uint64_t const w = list ? list[1+i] : i;
 			processWindow(B,w,arena);
 			if ( threadIdx.x == 0 && B.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
+		}
+	}
+}
+
+// LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice
+__global__ void __launch_bounds__(64) k_window_fast(FastBatch FB)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint32_t const G = gridDim.x;
+	uint32_t const b = blockIdx.x;
+	uint32_t const perx = G >> 3;
+	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
+	uint8_t * garena = FB.garena + static_cast<uint64_t>(b)*FB.F.gbytes;
+	{ FastLds L; fast_lds_carve(L,lds,FB.F); fast_load_tables(L,FB.F,FB.W.T,FB.dpsq_vst); }
+	for ( uint64_t base = 0; base < FB.W.nwindows; base += G )
+	{
+		uint64_t const w = base + slot;
+		if ( w < FB.W.nwindows )
+		{
+			bool const done = processWindowFast(FB,w,lds,garena);
+			if ( !done && threadIdx.x == 0 ) { uint32_t const i = atomicAdd(FB.retry,1u); FB.retry[1+i] = static_cast<uint32_t>(w); }
+			__syncthreads();
 		}
 	}
 }
@@ -143,6 +170,8 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
+	DevBuf<uint64_t> d_vst; DevBuf<uint8_t> d_garena; DevBuf<uint32_t> d_retry;
+	uint32_t fast_grid, retry_grid; int usefast; uint32_t nretry_last;
 	uint32_t tr_threads, win_grid;
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
@@ -191,7 +220,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_garena.release(); c->d_retry.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -210,6 +239,7 @@ int dacc_set_error_profile(dacc_ctx * c, double p_i, double p_d, double est_cor)
 	if ( (rc = upload(c,c->d_dpnorm,c->H.dpnorm.data(),c->H.dpnorm.size())) ) return rc;
 	if ( (rc = upload(c,c->d_dpsq,c->H.dpsq.data(),c->H.dpsq.size())) ) return rc;
 	if ( (rc = upload(c,c->d_vs,c->H.dpsq_vs.data(),c->H.dpsq_vs.size())) ) return rc;
+	if ( (rc = upload(c,c->d_vst,c->H.dpsq_vst.data(),c->H.dpsq_vst.size())) ) return rc;
 	if ( (rc = upload(c,c->d_first,c->H.dpsq_first.data(),c->H.dpsq_first.size())) ) return rc;
 	if ( (rc = upload(c,c->d_size,c->H.dpsq_size.data(),c->H.dpsq_size.size())) ) return rc;
 	if ( (rc = upload(c,c->d_suplo,c->H.suplo.data(),c->H.suplo.size())) ) return rc;
@@ -284,7 +314,15 @@ static int runDevice(dacc_ctx * c)
 		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
 		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
 		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = c->d_prof.p;
-		hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p);
+		if ( c->usefast )
+		{
+			HIPCHK(hipMemsetAsync(c->d_retry.p,0,sizeof(uint32_t),s));
+			FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->d_vst.p; FB.garena = c->d_garena.p; FB.retry = c->d_retry.p;
+			hipLaunchKernelGGL(k_window_fast,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB);
+			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,c->d_retry.p);
+		}
+		else
+			hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0));
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
 	if ( BP.piles.size() )
@@ -302,6 +340,8 @@ static int runDevice(dacc_ctx * c)
 	size_t const symbytes = 2*BP.npos + 64*BP.piles.size() + 64;
 	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
 	HIPCHK(hipMemcpyAsync(herr,c->d_err.p,sizeof(herr),hipMemcpyDeviceToHost,s));
+	c->nretry_last = 0;
+	if ( c->usefast && BP.nwindows ) HIPCHK(hipMemcpyAsync(&c->nretry_last,c->d_retry.p,sizeof(uint32_t),hipMemcpyDeviceToHost,s));
 	if ( BP.piles.size() )
 	{
 		HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
@@ -332,6 +372,7 @@ static int runDevice(dacc_ctx * c)
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
+	c->timing.nretry = c->nretry_last;
 	c->timing.nwindows = BP.nwindows; c->timing.nblocks = BP.nblocks; c->timing.algo_bytes = BP.algo_bytes + nbases;
 	return DACC_OK;
 }
@@ -345,7 +386,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	hipSetDevice(c->device);
 	c->havebatch = false;
 	BatchPlan & BP = c->BP;
-	int rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->h_rlen.data(),c->h_rlen.size(),c->err);
+	int rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->h_rlen.data(),c->h_rlen.size(),c->err,c->H.nrows,c->H.nsup);
 	if ( rc ) return rc;
 	hipStream_t const s = c->stream;
 	HIPCHK(c->d_err.ensure(4));
@@ -368,11 +409,36 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	// window kernel geometry + arenas
 	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
 	uint64_t wg = ((BP.nwindows+7)/8)*8;
-	uint64_t const maxwg = 256*12;
+	uint64_t const maxwg = 256*8;
 	if ( wg > maxwg ) wg = maxwg;
 	if ( wg < 8 ) wg = 8;
-	c->win_grid = wg;
-	HIPCHK(c->d_arena.ensure(wg*BP.caps.bytes));
+	{
+		char const * e = getenv("DACC_NOFAST");
+		c->usefast = !(e && e[0] == '1');
+		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
+		if ( c->H.nrows > 64 ) c->usefast = 0;
+	}
+	if ( c->usefast )
+	{
+		// fast path: LDS bound, floor(160 KiB / ldsbytes) wavefronts per CU
+		uint64_t percu = (160*1024) / (BP.fcaps.ldsbytes ? BP.fcaps.ldsbytes : 1);
+		if ( percu > 8 ) percu = 8;
+		if ( percu < 1 ) percu = 1;
+		uint64_t fg = ((BP.nwindows+7)/8)*8;
+		if ( fg > 256*percu ) fg = 256*percu;
+		if ( fg < 8 ) fg = 8;
+		c->fast_grid = fg;
+		c->retry_grid = wg < 512 ? wg : 512;
+		c->win_grid = c->retry_grid;
+		HIPCHK(c->d_garena.ensure(fg*BP.fcaps.gbytes));
+		HIPCHK(c->d_retry.ensure(BP.nwindows+2));
+		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));
+	}
+	else
+	{
+		c->win_grid = wg;
+		HIPCHK(c->d_arena.ensure(wg*BP.caps.bytes));
+	}
 	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
 	HIPCHK(c->d_has.ensure(BP.npos+1)); HIPCHK(c->d_oc.ensure(BP.npos+1)); HIPCHK(c->d_ld0.ensure(BP.npos+1)); HIPCHK(c->d_ocs.ensure(BP.npos+1));
 	HIPCHK(c->d_outsym.ensure(2*BP.npos + 64*BP.piles.size() + 64));

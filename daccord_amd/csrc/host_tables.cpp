@@ -125,6 +125,11 @@ void buildHostTables(HostTables & H, uint32_t const w, double const p_i, double 
 		}
 		H.dpsq_first[i] = first[i]; H.dpsq_size[i] = V[i].size();
 	}
+	// transposed copy [pos][row]: lanes = consecutive rows read consecutive words (fast_window.hpp)
+	H.dpsq_vst.assign(static_cast<size_t>(nrows)*nsup,0);
+	for ( uint32_t i = 0; i < nrows; ++i )
+		for ( uint32_t pos = 0; pos < nsup; ++pos )
+			H.dpsq_vst[static_cast<size_t>(pos)*nrows+i] = H.dpsq_vs[static_cast<size_t>(i)*nsup+pos];
 	// Vsupport: rows whose support covers read position pos (two monotone pointers, OffsetLikely.hpp:83-92)
 	H.suplo.resize(nsup); H.suphi.resize(nsup);
 	uint32_t j = 0, k = 0;

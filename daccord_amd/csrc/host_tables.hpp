@@ -7,7 +7,7 @@ struct HostTables
 {
 	uint32_t nrows, nsup, kln, nk;
 	std::vector<double> dpnorm, dpsq;
-	std::vector<uint64_t> dpsq_vs;
+	std::vector<uint64_t> dpsq_vs, dpsq_vst;
 	std::vector<uint16_t> dpsq_first, dpsq_size, suplo, suphi;
 	std::vector<uint32_t> klim;
 	std::vector<uint32_t> firsts, rowsizes;

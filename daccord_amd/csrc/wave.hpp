@@ -27,6 +27,7 @@
   static inline uint64_t wv_min64(uint64_t v) { return v; }
   static inline int wv_any(int p) { return p; }
   static inline uint32_t wv_or(uint32_t v) { return v; }
+  static inline uint64_t wv_or64(uint64_t v) { return v; }
   static inline uint32_t wv_bcast(uint32_t v, int) { return v; }
   static inline uint64_t wv_bcast64(uint64_t v, int) { return v; }
   static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
@@ -86,6 +87,12 @@
   }
   DEV int wv_any(int p) { return __any(p); }
   DEV uint32_t wv_or(uint32_t v)
+  {
+	#pragma unroll
+	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
+	return v;
+  }
+  DEV uint64_t wv_or64(uint64_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);

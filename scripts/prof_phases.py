@@ -7,7 +7,8 @@ from daccord_amd import engine
 from daccord_amd._structs import default_params
 from daccord_amd.synth import SynthData
 NAMES = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors", "feasible", "gapfill", "firstlast",
-         "stretches", "stretchfeas", "stretchlinks", "reverse-enum", "forward+pairs", "cand-errors", "align+emit"]
+         "stretches", "stretchfeas", "stretchlinks", "reverse-enum", "forward+pairs", "cand-errors", "align+emit", "-",
+         " s:predcounts", " s:walk1", " s:walk2", " s:splits", " s:sort+uniq"]
 npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 d = SynthData(250000, 1000, 5000, seed=3)
 ovl, piles = engine.pile_select(d.ovl, d.piles)
@@ -16,10 +17,10 @@ for k in (8, 14):
     t0 = time.time(); fr, ba = E(piles[:npiles], ovl, d.trace); t1 = time.time() - t0
     t = E.timing(); pr = E.profile().astype(np.float64)
     w = E.debug_windows()
-    print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms" % (
-        k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms))
+    print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms retry=%d" % (
+        k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms, t.nretry))
     print("  status", dict(zip(*np.unique(w["status"], return_counts=True))), "ff", dict(zip(*np.unique(w["filterfreq"][w["status"] == 1], return_counts=True))), "mean mao %.1f" % w["mao"].mean())
-    tot = pr.sum()
+    tot = pr[:15].sum()
     if tot > 0:
         for i, n in enumerate(NAMES):
             print("  %-16s %6.2f%%  %10.0f cyc/window" % (n, 100 * pr[i] / tot, pr[i] / max(1, t.nwindows)))

@@ -12,6 +12,7 @@
 #include "../../daccord_amd/csrc/batch_plan.hpp"
 #include "../../daccord_amd/csrc/host_tables.hpp"
 #include "../../daccord_amd/csrc/window_main.hpp"
+#include "../../daccord_amd/csrc/fast_window.hpp"
 #include "../../daccord_amd/csrc/trace_kernel.hpp"
 #include "../../daccord_amd/csrc/vote_kernel.hpp"
 
@@ -27,6 +28,7 @@ struct EmulCtx
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<dacc_window_result> windows;
 	std::string err;
+	bool usefast; uint64_t nfast, nretry;
 };
 
 static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
@@ -43,7 +45,9 @@ static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 
 extern "C" {
 
-void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; return c; }
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->nfast = c->nretry = 0; return c; }
+void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
+void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { *nf = static_cast<EmulCtx *>(v)->nfast; *nr = static_cast<EmulCtx *>(v)->nretry; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
 
@@ -74,7 +78,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 	EmulCtx * c = static_cast<EmulCtx *>(v);
 	if ( !c->haveprofile ) return DACC_ESTATE;
 	BatchPlan BP;
-	int rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->rlen.data(),c->rlen.size(),c->err);
+	int rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->rlen.data(),c->rlen.size(),c->err,c->H.nrows,c->H.nsup);
 	if ( rc ) return rc;
 	DevParams P; DevTables T; fillDev(*c,P,T);
 
@@ -116,7 +120,17 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
 		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data(); WB.prof = 0;
-		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) processWindow(WB,wdx,arena.data());
+		FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->H.dpsq_vst.data(); FB.garena = 0; FB.retry = 0;
+		std::vector<uint8_t> lds(BP.fcaps.ldsbytes+64), garena(BP.fcaps.gbytes+64);
+		c->nfast = 0; c->nretry = 0;
+		{ FastLds L; fast_lds_carve(L,lds.data(),BP.fcaps); fast_load_tables(L,BP.fcaps,T,c->H.dpsq_vst.data()); }
+		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
+		bool const usefast = c->usefast && !big && c->H.nrows <= 64;
+		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
+		{
+			bool const fast = usefast && processWindowFast(FB,wdx,lds.data(),garena.data());
+			if ( fast ) ++c->nfast; else { ++c->nretry; processWindow(WB,wdx,arena.data()); }
+		}
 	}
 	c->windows.clear();
 	bool overflow = false;

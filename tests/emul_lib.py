@@ -43,6 +43,8 @@ def lib():
         L.emul_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int]
         L.emul_collect.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.emul_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.emul_set_fast.argtypes = [C.c_void_p, C.c_int]
+        L.emul_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -60,6 +62,14 @@ class Emul:
         if getattr(self, "h", None):
             self.L.emul_destroy(self.h)
             self.h = None
+
+    def set_fast(self, on):
+        self.L.emul_set_fast(self.h, 1 if on else 0)
+
+    def counts(self):
+        a = C.c_uint64(); b = C.c_uint64()
+        self.L.emul_counts(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def set_error_profile(self, p_i, p_d, est_cor):
         self.L.emul_set_error_profile(self.h, p_i, p_d, est_cor)
