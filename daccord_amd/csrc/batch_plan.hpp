@@ -145,8 +145,8 @@ struct BatchPlan
 		caps.pad = 0; caps.bytes = 0;
 		// LDS fast path capacities (windows beyond them are re-run by the generic engine)
 		fcaps.maxs = std::min<uint32_t>(std::max<uint32_t>(caps.maxs,8),64);
-		fcaps.precap = 1024; fcaps.ncap = 896; fcaps.scap = 160; fcaps.lcap = 1024; fcaps.pcapr = 96; fcaps.pcapf = 192;
-		fcaps.siqcap = 128; fcaps.blcap = 96; fcaps.sfcap = 4096; fcaps.conscap = 16384 + MAXCONS; fcaps.pad = 0; fcaps.pad2 = 0;
+		fcaps.precap = 1024; fcaps.ncap = 896; fcaps.scap = 232; fcaps.lcap = 1024; fcaps.wcap = 1408; fcaps.rccap = 256; fcaps.fcap = 224;
+		fcaps.siqcap = 128; fcaps.blcap = 96; fcaps.conscap = 16384 + MAXCONS; fcaps.pad = 0; fcaps.pad2 = 0;
 		fcaps.nrows = tab_nrows; fcaps.nsup = tab_nsup;
 		{ FastLds L; fcaps.ldsbytes = fast_lds_carve(L,0,fcaps); FastGlobal G; fcaps.gbytes = (fast_global_carve(G,0,fcaps)+255)&~255ull; }
 		return DACC_OK;

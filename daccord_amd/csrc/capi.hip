@@ -83,6 +83,9 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB)
 	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
 	uint8_t * garena = FB.garena + static_cast<uint64_t>(b)*FB.F.gbytes;
 	{ FastLds L; fast_lds_carve(L,lds,FB.F); fast_load_tables(L,FB.F,FB.W.T,FB.dpsq_vst); }
+#if defined(DACC_PROFILE)
+	uint64_t const t0c = clock64(), t0w = wall_clock64();
+#endif
 	for ( uint64_t base = 0; base < FB.W.nwindows; base += G )
 	{
 		uint64_t const w = base + slot;
@@ -93,6 +96,9 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB)
 			__syncthreads();
 		}
 	}
+#if defined(DACC_PROFILE)
+	if ( threadIdx.x == 0 && FB.W.prof ) { atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+30),static_cast<unsigned long long>(clock64()-t0c)); atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+31),static_cast<unsigned long long>(wall_clock64()-t0w)); atomicMax(reinterpret_cast<unsigned long long *>(FB.W.prof+29),static_cast<unsigned long long>(wall_clock64()-t0w)); }
+#endif
 }
 
 // one workgroup per pile
@@ -154,7 +160,7 @@ struct dacc_ctx
 	dacc_params par;
 	int device;
 	hipStream_t stream;
-	hipEvent_t ev[6];
+	hipEvent_t ev[6]; hipEvent_t evfast; float fast_ms;
 	std::string err;
 	bool haveprofile, havedb, havebatch;
 	double est_cor;
@@ -207,6 +213,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	std::memset(&c->timing,0,sizeof(c->timing));
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
+	hipEventCreate(&c->evfast); c->fast_ms = 0;
 	*out = c;
 	return DACC_OK;
 }
@@ -319,6 +326,7 @@ static int runDevice(dacc_ctx * c)
 			HIPCHK(hipMemsetAsync(c->d_retry.p,0,sizeof(uint32_t),s));
 			FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->d_vst.p; FB.garena = c->d_garena.p; FB.retry = c->d_retry.p;
 			hipLaunchKernelGGL(k_window_fast,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB);
+			hipEventRecord(c->evfast,s);
 			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,c->d_retry.p);
 		}
 		else
@@ -369,6 +377,7 @@ static int runDevice(dacc_ctx * c)
 	float ms = 0;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[1]); c->timing.trace_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[1],c->ev[2]); c->timing.window_ms = ms;
+	if ( c->usefast && BP.nwindows ) { hipEventElapsedTime(&ms,c->ev[1],c->evfast); c->timing.fast_ms = ms; } else c->timing.fast_ms = 0;
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
@@ -426,6 +435,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( percu < 1 ) percu = 1;
 		uint64_t fg = ((BP.nwindows+7)/8)*8;
 		if ( fg > 256*percu ) fg = 256*percu;
+		if ( BP.fcaps.ldsbytes > 64*1024 ) hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast),hipFuncAttributeMaxDynamicSharedMemorySize,BP.fcaps.ldsbytes);
 		if ( fg < 8 ) fg = 8;
 		c->fast_grid = fg;
 		c->retry_grid = wg < 512 ? wg : 512;

@@ -1,22 +1,34 @@
 /*
  * LDS-resident fast path of the per-window de Bruijn consensus (one wavefront = one window).
  *
- * Same algorithm and exactly the same results as the generic engine (dbg_window.hpp); what
- * changes is where the state lives and how the heavy phases are laid out for CDNA4:
- *   - all per-window working state (strings, Myers masks, k-mer instances, nodes, stretches,
- *     path pools, bounded heaps) sits in the workgroup's LDS slice with 8/16-bit fields,
- *     ~40 KB per wavefront => 4 resident wavefronts per CU; the sort buffer of the build
- *     phase is overlaid by the traversal structures,
- *   - node successors are found without a table: the <=4 successor k-mers of a node are adjacent in the
- *     sorted node-key array, so one lower bound per node is kept,
- *   - k-mer feasibility is never materialised: stretch feasibility is evaluated with
- *     lanes = candidate start positions (<= 64) straight from the fixed-point table, every lane
- *     walking the same (wave-uniform) node/instance loop, results kept as a 64-bit position
- *     mask per stretch plus a compact weight table,
- *   - stretch links are mask intersections.
+ * Same algorithm and exactly the same results as the generic engine (dbg_window.hpp, a close
+ * restatement of the reference's control flow); what changes is where the state lives and how
+ * the work is organised for CDNA4:
+ *
+ *  - all per-window working state sits in the workgroup's LDS slice with 8/16-bit fields; the
+ *    sort buffer of the build phase is overlaid by the traversal structures;
+ *  - node successors need no table: the <= 4 successor k-mers of a node are adjacent in the sorted
+ *    node-key array, one lower bound per node is kept;
+ *  - weights are exact 64-bit fixed point: every weight the reference forms is an integer multiple of
+ *    2^-32 (w = sum of VS entries / 2^32, DotProduct.hpp:54-60) and all its partial sums stay below
+ *    2^21, so the reference's FP64 sums/differences are exact and equal our integer sums times 2^-32.
+ *    Thresholds become integer compares (>= 1e-3 <=> >= 4294968, > 0.1 / >= 0.1 <=> >= 429496730,
+ *    >= 0.5 <=> >= 2^31), heap orders are unchanged;
+ *  - k-mer feasibility is never materialised: stretch feasibility is evaluated with lanes = candidate
+ *    start positions straight from a 32-bit copy of the fixed-point table held in LDS, results kept as
+ *    a 64-bit position mask per stretch plus a compact weight list; stretch links are mask
+ *    intersections evaluated on demand;
+ *  - the reference recomputes stretches, feasibility and both path enumerations for every
+ *    (first k-mer, last k-mer) candidate pair (traverse, DebruijnGraph.hpp:4774-5097; hundreds of
+ *    pairs per window at k=14).  Here stretches and feasibility are computed once per activation
+ *    state; the split pieces of every candidate first / last k-mer are added to the pool once;
+ *    the reverse enumeration is cached per last k-mer and the forward enumeration per first k-mer,
+ *    and reused for a pair whenever the other k-mer's split provably cannot touch it (no scan
+ *    target of the enumeration equals a node that identifies the split stretch or its pieces);
+ *    otherwise the pair is enumerated on its exact stretch set.
+ *
  * Windows that do not fit the LDS capacities (deep piles, strings > 64, gap filling at filter
- * frequency 0, w > 63) are flagged WS_RETRY and re-run by the generic engine; they are a small
- * minority and the result is identical either way.
+ * frequency 0, w > 63, rare shapes) return false and are re-run by the generic engine.
  */
 #ifndef DACC_FAST_WINDOW_HPP
 #define DACC_FAST_WINDOW_HPP
@@ -28,38 +40,49 @@
 namespace dacc {
 
 enum { WS_RETRY = 4 };
+enum { FNC = 48 };          // max first / last k-mer candidates on the fast path
+enum { FNOPAR = 0xFF };
 
 struct FastCaps
 {
-	uint32_t maxs, precap, ncap, scap, lcap, pcapr, pcapf, siqcap, blcap, sfcap, conscap, pad;
+	uint32_t maxs, precap, ncap, scap, lcap, wcap, rccap, fcap, siqcap, blcap, conscap, pad;
 	uint32_t nrows, nsup;        // dimensions of the fixed-point table copy held in LDS
 	uint32_t ldsbytes, pad2;
 	uint64_t gbytes;
 };
 
+struct FSI { uint64_t w; uint8_t left, right, current, path; uint32_t pad; };   // ScoreInterval
+struct FCC { uint64_t w; uint32_t o, l; };                                       // ConsensusCandidate
+
 struct FastLds
 {
 	uint8_t * str; uint8_t * slen; uint64_t * peq; uint8_t * ipos; uint8_t * irpos;
 	uint32_t * nv; uint16_t * nps; uint8_t * nfreq; uint16_t * succ0; uint16_t * sinfo; uint8_t * npred;
-	uint64_t * mfirst; uint64_t * mlast;
 	uint8_t * pfrom; uint8_t * pto; uint8_t * cpfrom; uint8_t * cpto;
-	uint32_t * tab; uint8_t * suplo8; uint8_t * suphi8;   // per-workgroup copies of the model tables
+	uint64_t * mfirst; uint64_t * mlast;
+	uint32_t * tab; uint8_t * suplo8; uint8_t * suphi8;
 	// overlay, build phase
 	uint64_t * pre; uint64_t * lastk;
 	// overlay, traversal phase
 	uint16_t * sfirst; uint16_t * slast; uint16_t * sslen; uint16_t * slink; uint64_t * maskF; uint64_t * maskR; uint16_t * woffF; uint16_t * woffR;
-	uint16_t * links;
+	uint16_t * links; uint64_t * wuF; uint64_t * wuR; uint8_t * ord;
+	uint32_t * fkmer; uint32_t * lkmer; uint16_t * fnode; uint16_t * lnode; uint8_t * parF; uint8_t * posF; uint8_t * parL; uint8_t * posL;
+	uint8_t * pieF; uint8_t * pieL;          // first piece id of candidate i (second = +1), FNOPAR if none
+	// reverse cache
+	uint64_t * rc_w; uint8_t * rc_parent; uint8_t * rc_stretch; uint8_t * rc_pos; uint8_t * rc_len; uint8_t * rc_baselen; uint8_t * rc_ord; uint8_t * rc_arw;
+	uint16_t * rbase; uint8_t * rn; uint8_t * rnpool; uint8_t * rvalid;
+	// forward pool
+	uint64_t * f_w; uint8_t * f_parent; uint8_t * f_stretch; uint8_t * f_pos; uint8_t * f_baselen; uint8_t * f_len; uint8_t * fpop;
+	// heaps
+	uint8_t * rpst; uint8_t * hbl; uint8_t * hbl_n; FSI * siq;
+	FCC * cdh; FCC * ch; FCC * acc; uint32_t * accerr; uint16_t * canderr; uint8_t * prevstr; uint8_t * curstr;
+	// raw stretches (overlay of the caches)
 	uint16_t * tfirst; uint16_t * tlast; uint16_t * tslen; uint16_t * tlink; uint64_t * skey;
-	uint16_t * rp_parent; uint16_t * rp_stretch; double * rp_weight; uint16_t * rp_pos; uint16_t * rp_len; uint16_t * rp_baselen;
-	uint16_t * p_parent; uint16_t * p_stretch; double * p_weight; uint16_t * p_pos; uint16_t * p_len; uint16_t * p_baselen;
-	uint16_t * arp; uint16_t * arw; uint16_t * arwr;
-	double * rpst_w; uint16_t * rpst_i; HeapSI * siq;
-	uint16_t * hbl; uint8_t * hbl_n;
-	HeapCC * cdh; HeapCC * ch; HeapCC * acc; double * accerr; uint16_t * canderr;
+	// final alignment (overlay of the caches)
 	uint64_t * alpv; uint64_t * almv; uint16_t * albot; uint8_t * alops;
 };
 
-struct FastGlobal { double * wF; double * wR; uint8_t * cons; };
+struct FastGlobal { uint8_t * cons; };
 
 #define FCARVE(field,type,count) L.field = reinterpret_cast<type *>(base + o); o = (o + sizeof(type)*static_cast<uint64_t>(count) + 7) & ~static_cast<uint64_t>(7);
 
@@ -78,21 +101,19 @@ HDEV uint32_t fast_lds_carve(FastLds & L, uint8_t * base, FastCaps const & C)
 	FCARVE(succ0,uint16_t,C.ncap)
 	FCARVE(sinfo,uint16_t,C.ncap)
 	FCARVE(npred,uint8_t,C.ncap)
-	FCARVE(mfirst,uint64_t,keycap)
-	FCARVE(mlast,uint64_t,keycap)
 	FCARVE(pfrom,uint8_t,C.ncap)
 	FCARVE(pto,uint8_t,C.ncap)
 	FCARVE(cpfrom,uint8_t,C.ncap)
 	FCARVE(cpto,uint8_t,C.ncap)
+	FCARVE(mfirst,uint64_t,keycap)
+	FCARVE(mlast,uint64_t,keycap)
 	FCARVE(tab,uint32_t,C.nrows*C.nsup)
 	FCARVE(suplo8,uint8_t,C.nsup)
 	FCARVE(suphi8,uint8_t,C.nsup)
 	uint64_t const ubase = o;
-	// build phase
 	FCARVE(pre,uint64_t,C.precap)
 	FCARVE(lastk,uint64_t,keycap)
 	uint64_t const uA = o;
-	// traversal phase (overlays the build phase)
 	o = ubase;
 	FCARVE(sfirst,uint16_t,C.scap)
 	FCARVE(slast,uint16_t,C.scap)
@@ -103,13 +124,52 @@ HDEV uint32_t fast_lds_carve(FastLds & L, uint8_t * base, FastCaps const & C)
 	FCARVE(woffF,uint16_t,C.scap)
 	FCARVE(woffR,uint16_t,C.scap)
 	FCARVE(links,uint16_t,C.lcap)
-	FCARVE(cdh,HeapCC,16)
-	FCARVE(ch,HeapCC,16)
-	FCARVE(acc,HeapCC,16)
-	FCARVE(accerr,double,16)
+	FCARVE(wuF,uint64_t,C.wcap)
+	FCARVE(wuR,uint64_t,C.wcap)
+	FCARVE(ord,uint8_t,C.scap)
+	FCARVE(fkmer,uint32_t,FNC)
+	FCARVE(lkmer,uint32_t,FNC)
+	FCARVE(fnode,uint16_t,FNC)
+	FCARVE(lnode,uint16_t,FNC)
+	FCARVE(parF,uint8_t,FNC)
+	FCARVE(posF,uint8_t,FNC)
+	FCARVE(parL,uint8_t,FNC)
+	FCARVE(posL,uint8_t,FNC)
+	FCARVE(pieF,uint8_t,FNC)
+	FCARVE(pieL,uint8_t,FNC)
+	FCARVE(cdh,FCC,16)
+	FCARVE(ch,FCC,16)
+	FCARVE(acc,FCC,16)
+	FCARVE(accerr,uint32_t,16)
 	FCARVE(canderr,uint16_t,16*C.maxs)
+	FCARVE(prevstr,uint8_t,MAXCONS)
+	FCARVE(curstr,uint8_t,MAXCONS)
 	uint64_t const pbase = o;
-	// raw stretches (until the final stretch arrays exist), then pools / heaps, then the final alignment
+	FCARVE(rc_w,uint64_t,C.rccap)
+	FCARVE(rc_parent,uint8_t,C.rccap)
+	FCARVE(rc_stretch,uint8_t,C.rccap)
+	FCARVE(rc_pos,uint8_t,C.rccap)
+	FCARVE(rc_len,uint8_t,C.rccap)
+	FCARVE(rc_baselen,uint8_t,C.rccap)
+	FCARVE(rc_ord,uint8_t,C.rccap)
+	FCARVE(rc_arw,uint8_t,C.rccap)
+	FCARVE(rbase,uint16_t,FNC+1)
+	FCARVE(rn,uint8_t,FNC+1)
+	FCARVE(rnpool,uint8_t,FNC+1)
+	FCARVE(rvalid,uint8_t,FNC+1)
+	FCARVE(f_w,uint64_t,C.fcap)
+	FCARVE(f_parent,uint8_t,C.fcap)
+	FCARVE(f_stretch,uint8_t,C.fcap)
+	FCARVE(f_pos,uint8_t,C.fcap)
+	FCARVE(f_baselen,uint8_t,C.fcap)
+	FCARVE(f_len,uint8_t,C.fcap)
+	FCARVE(fpop,uint8_t,C.fcap)
+	FCARVE(rpst,uint8_t,256)
+	FCARVE(hbl,uint8_t,C.blcap*12)
+	FCARVE(hbl_n,uint8_t,C.blcap)
+	FCARVE(siq,FSI,C.siqcap)
+	uint64_t const upool = o;
+	o = pbase;
 	FCARVE(tfirst,uint16_t,C.scap)
 	FCARVE(tlast,uint16_t,C.scap)
 	FCARVE(tslen,uint16_t,C.scap)
@@ -117,37 +177,11 @@ HDEV uint32_t fast_lds_carve(FastLds & L, uint8_t * base, FastCaps const & C)
 	FCARVE(skey,uint64_t,next_pow2(C.scap))
 	uint64_t const uraw = o;
 	o = pbase;
-	FCARVE(rp_parent,uint16_t,C.pcapr)
-	FCARVE(rp_stretch,uint16_t,C.pcapr)
-	FCARVE(rp_weight,double,C.pcapr)
-	FCARVE(rp_pos,uint16_t,C.pcapr)
-	FCARVE(rp_len,uint16_t,C.pcapr)
-	FCARVE(rp_baselen,uint16_t,C.pcapr)
-	FCARVE(p_parent,uint16_t,C.pcapf)
-	FCARVE(p_stretch,uint16_t,C.pcapf)
-	FCARVE(p_weight,double,C.pcapf)
-	FCARVE(p_pos,uint16_t,C.pcapf)
-	FCARVE(p_len,uint16_t,C.pcapf)
-	FCARVE(p_baselen,uint16_t,C.pcapf)
-	FCARVE(arp,uint16_t,C.pcapr)
-	FCARVE(arw,uint16_t,C.pcapr)
-	FCARVE(arwr,uint16_t,C.pcapr)
-	uint64_t const hbase = o;
-	FCARVE(rpst_w,double,C.pcapr)
-	FCARVE(rpst_i,uint16_t,C.pcapr)
-	uint64_t const h1 = o;
-	o = hbase;
-	FCARVE(siq,HeapSI,C.siqcap)
-	if ( h1 > o ) o = h1;
-	FCARVE(hbl,uint16_t,C.blcap*12)
-	FCARVE(hbl_n,uint8_t,C.blcap)
-	uint64_t const upool = o;
-	o = pbase;
 	FCARVE(alpv,uint64_t,MAXCONS+1)
 	FCARVE(almv,uint64_t,MAXCONS+1)
 	FCARVE(albot,uint16_t,MAXCONS+1)
 	FCARVE(alops,uint8_t,2*MAXCONS+2*64+8)
-	uint64_t ualn = o;
+	uint64_t const ualn = o;
 	uint64_t m = uA;
 	if ( uraw > m ) m = uraw;
 	if ( upool > m ) m = upool;
@@ -157,23 +191,19 @@ HDEV uint32_t fast_lds_carve(FastLds & L, uint8_t * base, FastCaps const & C)
 
 HDEV uint64_t fast_global_carve(FastGlobal & G, uint8_t * base, FastCaps const & C)
 {
-	uint64_t o = 0;
-	G.wF = reinterpret_cast<double *>(base+o); o += 3ull*8*C.sfcap;
-	G.wR = reinterpret_cast<double *>(base+o); o += 3ull*8*C.sfcap;
-	G.cons = base+o; o += (C.conscap+15)&~15u;
-	return o;
+	G.cons = base;
+	return (C.conscap+255)&~255ull;
 }
 
 struct FastBatch
 {
-	WindowBatch W;              // shared inputs / outputs (arena unused here)
+	WindowBatch W;
 	FastCaps F;
-	uint64_t const * dpsq_vst;  // [nsup][nrows] transposed fixed-point table
+	uint64_t const * dpsq_vst;  // [nsup][nrows] transposed fixed-point table (HBM); copied to LDS as 32-bit
 	uint8_t * garena;           // [gridDim][F.gbytes]
 	uint32_t * retry;           // [0] = count, [1..] = window indices to re-run generically
 };
 
-// copy the model tables into the workgroup's LDS (once per workgroup)
 DEV void fast_load_tables(FastLds & L, FastCaps const & C, DevTables const & T, uint64_t const * vst)
 {
 	int const lane = wv_lane();
@@ -182,17 +212,28 @@ DEV void fast_load_tables(FastLds & L, FastCaps const & C, DevTables const & T, 
 	wv_sync();
 }
 
+#define FW_THRES_FEAS 4294968ull        /* weight >= 1e-3 */
+#define FW_THRES_01   429496730ull      /* weight > 0.1 and weight >= 0.1 (no integer lies between) */
+#define FW_THRES_05   2147483648ull     /* weight >= 0.5 */
+
 struct FastEngine
 {
 	FastLds L; FastGlobal G; FastCaps C; DevTables T; DevParams P;
-	uint64_t const * vst;
 	int lane; uint32_t flags;
 	uint64_t * prof;
 	uint32_t mao, k; uint64_t kmask;
-	uint32_t npre, nlast, nn, nmfirst, nmlast, nstretch, nlinks, nwF, nwR;
-	uint32_t nrp, narp, np, nsiq, ncdh, nacc, conso;
+	uint32_t npre, nlast, nn, nmfirst, nmlast;
+	uint32_t n0, npool, nlinks, nwF, nwR, nview;
+	uint32_t nF, nL;
+	uint32_t rctop;                      // used entries of the reverse cache
+	uint32_t np, nfpop, nsiq, ncdh, nacc, conso;
+	int32_t fcur_fi; int32_t fcur_li;    // what the forward pool holds: F(fi) on view(fi) (li = -1) or an exact pair view
+	uint32_t prevlen;
 
 	DEV void over(uint32_t b) { flags |= b; }
+#if defined(DACC_EMUL) && defined(DACC_FSTATS)
+	void fstat(int i, uint32_t v) { extern uint32_t g_fstat[16]; if ( v > g_fstat[i] ) g_fstat[i] = v; }
+#endif
 
 	DEV int32_t findNode(uint32_t const v) const
 	{
@@ -212,7 +253,6 @@ struct FastEngine
 		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.nv[mid] < v ) lo = mid+1; else hi = mid; }
 		return lo;
 	}
-	// i-th successor (descending (freq,sym) order) of node z
 	DEV int32_t succNode(uint32_t const z, uint32_t const i) const
 	{
 		uint32_t const sym = (L.sinfo[z]>>(2*i))&3;
@@ -228,11 +268,10 @@ struct FastEngine
 	DEV uint32_t nsucc(uint32_t z) const { return (L.sinfo[z]>>8)&7; }
 	DEV uint32_t nsuccact(uint32_t z) const { return (L.sinfo[z]>>11)&7; }
 
-	// ---- instances + sort (setupPreNodes) ----
+	// ================= build: instances, nodes, successors =================
 	DEV void buildInstances()
 	{
 		uint32_t base = 0;
-		// offsets: per string exclusive scan (maxs <= 64 on the fast path => one chunk on the device)
 		for ( uint32_t j = 0; j < mao; ++j ) { uint32_t const len = L.slen[j]; base += (len >= k) ? (len-k+1) : 0; }
 		npre = base;
 		if ( npre > C.precap ) { over(1); npre = 0; return; }
@@ -263,10 +302,8 @@ struct FastEngine
 		wv_bitonic_sort(L.pre,p2);
 	}
 
-	// ---- nodes (setupNodes + filterFreq) + first/last lists ----
 	DEV void buildNodes(uint32_t const f)
 	{
-		// run heads of the sorted instance array -> kept runs (freq >= f)
 		uint32_t base = 0;
 		for ( uint32_t c = 0; c < npre; c += WSZ )
 		{
@@ -289,7 +326,6 @@ struct FastEngine
 		}
 		nn = base;
 		if ( nn > C.ncap ) { over(2); nn = 0; }
-		// compressed instance arrays (pos, reverse pos)
 		for ( uint32_t i = lane; i < npre; i += WSZ )
 		{
 			uint32_t const pos = (L.pre[i]>>16)&0xFFFF, seq = L.pre[i]&0xFFFF;
@@ -297,19 +333,17 @@ struct FastEngine
 		}
 		wv_sync();
 		if ( lane == 0 ) L.nps[nn] = npre;
-		// per node: rows in which it can be feasible at all (getSupportLow/High of the extreme instance positions)
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
-			uint32_t const s0 = L.nps[z], f = L.nfreq[z];
-			uint32_t lo = L.ipos[s0], hi = L.ipos[s0+f-1];       // instances are position sorted
+			uint32_t const s0 = L.nps[z], f2 = L.nfreq[z];
+			uint32_t const lo = L.ipos[s0], hi = L.ipos[s0+f2-1];
 			uint32_t rlo = 255, rhi = 0;
-			for ( uint32_t q = 0; q < f; ++q ) { uint32_t const r = L.irpos[s0+q]; rlo = r < rlo ? r : rlo; rhi = r > rhi ? r : rhi; }
+			for ( uint32_t q = 0; q < f2; ++q ) { uint32_t const r = L.irpos[s0+q]; rlo = r < rlo ? r : rlo; rhi = r > rhi ? r : rhi; }
 			L.pfrom[z] = lo < C.nsup ? L.suplo8[lo] : C.nrows;
 			L.pto[z] = hi < C.nsup ? L.suphi8[hi] : C.nrows;
 			L.cpfrom[z] = rlo < C.nsup ? L.suplo8[rlo] : C.nrows;
 			L.cpto[z] = rhi < C.nsup ? L.suphi8[rhi] : C.nrows;
 		}
-		// maxFirst: (count at read position 0, kmer) descending (maxForPosList(0))
 		uint32_t const kp2 = next_pow2(C.maxs < 2 ? 2 : C.maxs);
 		base = 0;
 		for ( uint32_t c = 0; c < nn; c += WSZ )
@@ -323,9 +357,8 @@ struct FastEngine
 		}
 		nmfirst = base;
 		if ( nmfirst > kp2 ) { over(8); nmfirst = 0; }
-		uint32_t p2 = next_pow2(nmfirst < 2 ? 2 : nmfirst);
+		uint32_t const p2 = next_pow2(nmfirst < 2 ? 2 : nmfirst);
 		for ( uint32_t i = nmfirst + lane; i < p2; i += WSZ ) L.mfirst[i] = ~0ull;
-		// maxLast: runs of the sorted last k-mers (maxLastList)
 		base = 0;
 		for ( uint32_t c = 0; c < nlast; c += WSZ )
 		{
@@ -348,7 +381,6 @@ struct FastEngine
 		wv_bitonic_sort(L.mlast,q2);
 	}
 
-	// ---- successors + activation (setupAddHeap / setNodesActive) ----
 	DEV void buildSuccessors(uint32_t const no)
 	{
 		uint32_t const lim = T.klim[(k-P.klow)*T.kln + (no < static_cast<uint32_t>(T.kln) ? no : T.kln-1)];
@@ -384,8 +416,7 @@ struct FastEngine
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 			if ( nsuccact(z) < nsucc(z) )
 			{
-				int32_t const t = succNode(z,nsuccact(z));
-				uint32_t const fq = L.nfreq[t];
+				uint32_t const fq = L.nfreq[succNode(z,nsuccact(z))];
 				best = fq > best ? fq : best;
 			}
 		best = wv_max(best);
@@ -400,6 +431,7 @@ struct FastEngine
 		return true;
 	}
 
+	// ================= stretches, once per activation state =================
 	DEV void computePredCounts()
 	{
 		uint32_t const shift = 2*(k-1);
@@ -421,7 +453,6 @@ struct FastEngine
 		}
 		wv_sync();
 	}
-
 	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, uint16_t * out, uint32_t & lastnode)
 	{
 		int32_t cur = succNode(z,i);
@@ -439,13 +470,17 @@ struct FastEngine
 		lastnode = cur;
 		return len;
 	}
-
-	// ---- stretches (computeStretches + splitStretches x2 + stretchesUnique) ----
-	DEV void computeStretches(int32_t const firstnode, int32_t const lastsplit)
+	// (first, ext, len desc, last) packed into 56 bits: Stretch::operator< (node ids ascend with k-mer value)
+	DEV static uint64_t sortKey(uint32_t first, uint32_t ext, uint32_t len, uint32_t last)
 	{
-		PROF_T0
+		return (static_cast<uint64_t>(first)<<42) | (static_cast<uint64_t>(ext)<<28) | (static_cast<uint64_t>(0x3FFF-len)<<14) | last;
+	}
+	DEV uint64_t poolKey(uint32_t const s) const { return sortKey(L.sfirst[s],L.links[L.slink[s]+1],L.sslen[s],L.slast[s]); }
+
+	// raw stretches of the current activation state, sorted by Stretch::operator< (pool ids 0..n0-1)
+	DEV void computeBaseStretches()
+	{
 		computePredCounts();
-		PROF(*this,16)
 		uint32_t base = 0;
 		for ( uint32_t c = 0; c < nn; c += WSZ )
 		{
@@ -457,12 +492,11 @@ struct FastEngine
 				for ( uint32_t i = 0; i < cnt; ++i ) { L.tfirst[base+pre+i] = z; L.tlast[base+pre+i] = i; }
 			base += tot;
 		}
-		uint32_t ns = base;
-		if ( ns + 2 > C.scap ) { over(32); nstretch = 0; return; }
+		uint32_t const ns = base;
+		if ( ns + 2 > C.scap || ns > 250 || nn >= 0x3FFF ) { over(32); n0 = 0; return; }
 		wv_sync();
 		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; L.tslen[q] = walkStretch(L.tfirst[q],L.tlast[q],0,ln); }
 		wv_sync();
-		PROF(*this,17)
 		base = 0;
 		for ( uint32_t c = 0; c < ns; c += WSZ )
 		{
@@ -473,86 +507,84 @@ struct FastEngine
 			base += tot;
 		}
 		nlinks = base;
-		if ( nlinks > C.lcap ) { over(64); nstretch = 0; return; }
+		if ( nlinks > C.lcap ) { over(64); n0 = 0; return; }
 		wv_sync();
 		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; walkStretch(L.tfirst[q],L.tlast[q],L.links+L.tlink[q],ln); L.tlast[q] = ln; }
 		wv_sync();
-		PROF(*this,18)
-		// splits at `first` and `last`: an interior node belongs to exactly one stretch, so at most one split per round
-		for ( int round = 0; round < 2; ++round )
-		{
-			int32_t const v = round ? lastsplit : firstnode;
-			if ( v < 0 ) continue;
-			// stretches containing v strictly inside, in index order (an interior node has a unique active
-			// predecessor and successor, so normally there is at most one)
-			uint32_t const ns0 = ns;
-			uint32_t lastdone = 0; bool first = true;
-			while ( true )
-			{
-				uint32_t found = 0xFFFFFFFFu;
-				for ( uint32_t q = lane; q < ns0; q += WSZ )
-				{
-					uint32_t const len = L.tslen[q]; uint16_t const * Lk = L.links + L.tlink[q];
-					for ( uint32_t i = 1; i+1 < len; ++i )
-						if ( Lk[i] == v )
-						{
-							uint32_t const key = (q<<16)|i;
-							if ( (first || (key>>16) > (lastdone>>16)) && key < found ) found = key;
-							break;
-						}
-				}
-				uint32_t const mn = ~wv_max(~found);
-				if ( mn == 0xFFFFFFFFu ) break;
-				uint32_t const q = mn>>16, split = mn&0xFFFF;
-				if ( ns >= C.scap ) { over(32); nstretch = 0; return; }
-				if ( lane == 0 )
-				{
-					uint32_t const len = L.tslen[q]; uint32_t const lo = L.tlink[q];
-					L.tfirst[ns] = v; L.tlast[ns] = L.tlast[q]; L.tslen[ns] = len-split; L.tlink[ns] = lo+split;
-					L.tlast[q] = v; L.tslen[q] = split+1;
-				}
-				++ns; lastdone = mn; first = false;
-				wv_sync();
-			}
-			wv_sync();
-		}
-		PROF(*this,19)
 		uint32_t const p2 = next_pow2(ns < 2 ? 2 : ns);
 		for ( uint32_t q = lane; q < p2; q += WSZ )
-			L.skey[q] = q < ns ?
-				((static_cast<uint64_t>(L.tfirst[q])<<50) | (static_cast<uint64_t>(L.links[L.tlink[q]+1])<<36) | (static_cast<uint64_t>(0x3FFF-L.tslen[q])<<22) | (static_cast<uint64_t>(L.tlast[q])<<8) | q)
-				: ~0ull;
+			L.skey[q] = q < ns ? ((sortKey(L.tfirst[q],L.links[L.tlink[q]+1],L.tslen[q],L.tlast[q])<<8) | q) : ~0ull;
 		wv_sync();
-		if ( nn >= 0x3FFF || ns > 255 ) { over(32); nstretch = 0; return; }
 		wv_bitonic_sort(L.skey,p2);
-		base = 0;
-		for ( uint32_t c = 0; c < ns; c += WSZ )
+		// distinct (first,ext) by construction; a duplicate would need stretchesUnique's tie handling -> generic engine
+		uint32_t dup = 0;
+		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
-			uint32_t const q = c + lane;
-			uint32_t const keep = (q < ns) && (q == 0 || (L.skey[q]>>36) != (L.skey[q-1]>>36));
-			uint32_t tot; uint32_t const pre = wv_scan_excl(keep,tot);
-			if ( keep )
-			{
-				uint32_t const raw = L.skey[q]&0xFF; uint32_t const s = base+pre;
-				// final arrays alias nothing of the raw arrays (separate LDS regions)
-				L.sfirst[s] = L.tfirst[raw]; L.slast[s] = L.tlast[raw]; L.sslen[s] = L.tslen[raw]; L.slink[s] = L.tlink[raw];
-			}
-			base += tot;
+			if ( q && (L.skey[q]>>36) == (L.skey[q-1]>>36) ) dup = 1;
+			uint32_t const raw = L.skey[q]&0xFF;
+			L.sfirst[q] = L.tfirst[raw]; L.slast[q] = L.tlast[raw]; L.sslen[q] = L.tslen[raw]; L.slink[q] = L.tlink[raw];
 		}
-		nstretch = base;
+		if ( wv_any(dup) ) { over(32); n0 = 0; return; }
+		n0 = ns;
 		wv_sync();
-		PROF(*this,20)
 	}
 
-	// ---- stretch feasibility, lanes = candidate positions (computeFeasibleStretchPositions) ----
-	// weight(node,p) = (sum over instances of VS[p][pos]) / 2^32 is an exact multiple of 2^-32, and so is every
-	// partial sum the reference forms (< 2^21), hence the FP64 sums of the reference are exact and equal the
-	// integer sums below times 2^-32, in any order.  weight >= 1e-3  <=>  integer sum >= 4294968.
-	DEV void computeStretchFeas()
+	// pool stretch id = nodes [a,b] of parent stretch par
+	DEV void makePiece(uint32_t const id, uint32_t const par, uint32_t const a, uint32_t const b)
 	{
-		nwF = 0; nwR = 0;
+		uint16_t const * Lk = L.links + L.slink[par];
+		L.sfirst[id] = Lk[a]; L.slast[id] = Lk[b]; L.sslen[id] = b-a+1; L.slink[id] = L.slink[par]+a;
+	}
+	// candidates + the pool stretch each one splits (splitStretches :2772-2841: first occurrence strictly inside)
+	DEV void findCandidatesAndPieces()
+	{
+		uint32_t const firstthres = nmfirst ? ((static_cast<uint32_t>((~L.mfirst[0])>>32))*3)/4 : 0;
+		uint32_t const lastthres = nmlast ? ((static_cast<uint32_t>((~L.mlast[0])>>32))*3)/4 : 0;
+		uint32_t cf = 0, cl = 0;
+		while ( cf < nmfirst && static_cast<uint32_t>((~L.mfirst[cf])>>32) >= firstthres ) ++cf;
+		while ( cl < nmlast && static_cast<uint32_t>((~L.mlast[cl])>>32) >= lastthres ) ++cl;
+		nF = cf; nL = cl; npool = n0;
+		if ( nF > FNC || nL > FNC ) { over(8); return; }
+		for ( uint32_t i = lane; i < nF; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mfirst[i]); L.fkmer[i] = km; int32_t const z = findNode(km); L.fnode[i] = z < 0 ? 0xFFFF : z; L.parF[i] = FNOPAR; L.pieF[i] = FNOPAR; }
+		for ( uint32_t i = lane; i < nL; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mlast[i]); L.lkmer[i] = km; int32_t const z = findNode(km); L.lnode[i] = z < 0 ? 0xFFFF : z; L.parL[i] = FNOPAR; L.pieL[i] = FNOPAR; }
+		wv_sync();
+		// parents: lanes over base stretches.  An interior node has a unique active predecessor and successor, so it
+		// lies strictly inside at most one stretch; anything else goes to the generic engine
+		uint32_t multi = 0;
+		for ( uint32_t s = lane; s < n0; s += WSZ )
+		{
+			uint32_t const len = L.sslen[s]; uint16_t const * Lk = L.links + L.slink[s];
+			for ( uint32_t i = 1; i+1 < len; ++i )
+			{
+				uint32_t const z = Lk[i];
+				for ( uint32_t c = 0; c < nF; ++c ) if ( L.fnode[c] == z ) { if ( L.parF[c] == FNOPAR ) { L.parF[c] = s; L.posF[c] = i; } else if ( L.parF[c] != s ) multi = 1; }
+				for ( uint32_t c = 0; c < nL; ++c ) if ( L.lnode[c] == z ) { if ( L.parL[c] == FNOPAR ) { L.parL[c] = s; L.posL[c] = i; } else if ( L.parL[c] != s ) multi = 1; }
+			}
+		}
+		if ( wv_any(multi) ) { over(32); return; }
+		wv_sync();
+		{
+			uint32_t cnt = 0;
+			for ( uint32_t c = 0; c < nF; ++c ) cnt += (L.parF[c] != FNOPAR);
+			for ( uint32_t c = 0; c < nL; ++c ) cnt += (L.parL[c] != FNOPAR);
+			if ( n0 + 2*cnt + 1 > C.scap || n0 + 2*cnt + 1 > 250 ) { over(32); return; }
+		}
+		if ( lane == 0 )
+		{
+			uint32_t id = n0;
+			for ( uint32_t c = 0; c < nF; ++c ) if ( L.parF[c] != FNOPAR ) { L.pieF[c] = id; makePiece(id,L.parF[c],0,L.posF[c]); makePiece(id+1,L.parF[c],L.posF[c],L.sslen[L.parF[c]]-1); id += 2; }
+			for ( uint32_t c = 0; c < nL; ++c ) if ( L.parL[c] != FNOPAR ) { L.pieL[c] = id; makePiece(id,L.parL[c],0,L.posL[c]); makePiece(id+1,L.parL[c],L.posL[c],L.sslen[L.parL[c]]-1); id += 2; }
+			npool = id;
+		}
+		wv_sync();
+		npool = wv_bcast(npool,0);
+	}
+
+	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions ----
+	DEV void computeStretchFeas(uint32_t const sfrom, uint32_t const sto)
+	{
 		uint32_t const nrows = C.nrows;
-		for ( uint32_t s = 0; s < nstretch; ++s )
+		for ( uint32_t s = sfrom; s < sto; ++s )
 		{
 			uint32_t const len = L.sslen[s];
 			uint16_t const * Lk = L.links + L.slink[s];
@@ -562,45 +594,50 @@ struct FastEngine
 			{
 				uint32_t const Pp = c + lane;
 				bool ok = Pp < nrows, okr = ok;
-				uint64_t sum = 0, rsum = 0, wf = 0, wl = 0, rwf = 0, rwl = 0;
+				uint64_t sum = 0, rsum = 0;
 				for ( uint32_t j = 0; j < len; ++j )
 				{
-					// forward: node j at position Pp+j
+					uint32_t const p = Pp+j;
+					bool const in = p < nrows;
 					{
-						uint32_t const z = Lk[j]; uint32_t const s0 = L.nps[z], f = L.nfreq[z];
-						uint32_t const p = Pp+j;
-						bool const in = p < nrows;
+						uint32_t const z = Lk[j]; uint32_t const i0 = L.nps[z], f = L.nfreq[z];
 						uint64_t u = 0;
-						for ( uint32_t q = 0; q < f; ++q ) u += in ? L.tab[static_cast<uint32_t>(L.ipos[s0+q])*nrows + p] : 0u;
-						ok = ok && in && p >= L.pfrom[z] && p < L.pto[z] && u >= 4294968ull;
-						sum += u; if ( j == 0 ) wf = u; wl = u;
+						for ( uint32_t q = 0; q < f; ++q ) u += in ? L.tab[static_cast<uint32_t>(L.ipos[i0+q])*nrows + p] : 0u;
+						ok = ok && in && p >= L.pfrom[z] && p < L.pto[z] && u >= FW_THRES_FEAS;
+						sum += u;
 					}
-					// reverse: node len-1-j at reverse position Pp+j
 					{
-						uint32_t const z = Lk[len-1-j]; uint32_t const s0 = L.nps[z], f = L.nfreq[z];
-						uint32_t const p = Pp+j;
-						bool const in = p < nrows;
+						uint32_t const z = Lk[len-1-j]; uint32_t const i0 = L.nps[z], f = L.nfreq[z];
 						uint64_t u = 0;
-						for ( uint32_t q = 0; q < f; ++q ) u += in ? L.tab[static_cast<uint32_t>(L.irpos[s0+q])*nrows + p] : 0u;
-						okr = okr && in && p >= L.cpfrom[z] && p < L.cpto[z] && u >= 4294968ull;
-						rsum += u; if ( j == 0 ) rwf = u; rwl = u;
+						for ( uint32_t q = 0; q < f; ++q ) u += in ? L.tab[static_cast<uint32_t>(L.irpos[i0+q])*nrows + p] : 0u;
+						okr = okr && in && p >= L.cpfrom[z] && p < L.cpto[z] && u >= FW_THRES_FEAS;
+						rsum += u;
 					}
 				}
-				double const sc = 2.3283064365386962890625e-10; // 2^-32
 				uint32_t tot; uint32_t const pre = wv_scan_excl(ok ? 1 : 0,tot);
-				if ( ok && bF+pre < C.sfcap ) { G.wF[3*(bF+pre)] = static_cast<double>(sum)*sc; G.wF[3*(bF+pre)+1] = static_cast<double>(wf)*sc; G.wF[3*(bF+pre)+2] = static_cast<double>(wl)*sc; }
+				if ( ok && bF+pre < C.wcap ) L.wuF[bF+pre] = sum;
 				mF |= wv_or64(ok ? (1ull<<Pp) : 0ull);
 				bF += tot;
 				uint32_t const prer = wv_scan_excl(okr ? 1 : 0,tot);
-				if ( okr && bR+prer < C.sfcap ) { G.wR[3*(bR+prer)] = static_cast<double>(rsum)*sc; G.wR[3*(bR+prer)+1] = static_cast<double>(rwf)*sc; G.wR[3*(bR+prer)+2] = static_cast<double>(rwl)*sc; }
+				if ( okr && bR+prer < C.wcap ) L.wuR[bR+prer] = rsum;
 				mR |= wv_or64(okr ? (1ull<<Pp) : 0ull);
 				bR += tot;
 			}
-			if ( bF > C.sfcap || bR > C.sfcap || bF > 0xFFFF || bR > 0xFFFF ) { over(128); return; }
+			if ( bF > C.wcap || bR > C.wcap ) { over(128); return; }
 			if ( lane == 0 ) { L.maskF[s] = mF; L.maskR[s] = mR; L.woffF[s] = nwF; L.woffR[s] = nwR; }
 			nwF = bF; nwR = bR;
 		}
 		wv_sync();
+	}
+	// fixed-point weight of a single node at (reverse) position p
+	DEV uint64_t nodeU(uint32_t const z, uint32_t const p, bool const rev) const
+	{
+		if ( p >= C.nrows ) return 0;
+		uint32_t const i0 = L.nps[z], f = L.nfreq[z];
+		uint8_t const * IP = rev ? L.irpos : L.ipos;
+		uint64_t u = 0;
+		for ( uint32_t q = 0; q < f; ++q ) u += L.tab[static_cast<uint32_t>(IP[i0+q])*C.nrows + p];
+		return u;
 	}
 	DEV int32_t sfFind(uint32_t const s, uint32_t const p) const
 	{
@@ -616,48 +653,80 @@ struct FastEngine
 		if ( !((m>>p)&1) ) return -1;
 		return L.woffR[s] + dacc_popc64(m & ((1ull<<p)-1));
 	}
-	DEV uint32_t stretchLowerBound(uint32_t const node) const
-	{
-		uint32_t lo = 0, hi = nstretch;
-		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.sfirst[mid] < node ) lo = mid+1; else hi = mid; }
-		return lo;
-	}
-	// getReverseStretchLinkWeight(A=i,B=b) >= 0.1 ?  (computeStretchLinks); links are evaluated on demand
+	// getReverseStretchLinkWeight(A=i,B=b) >= 0.1 (computeStretchLinks :3388-3480), evaluated on demand
 	DEV bool linkOk(uint32_t const i, uint32_t const b) const
 	{
 		uint32_t const shift = L.sslen[b]-1;
 		if ( shift >= 64 ) return false;
 		uint64_t const mA = L.maskR[i], mB = L.maskR[b];
 		uint64_t common = mA & (mB<<shift);
-		double weight = 0.0;
+		uint64_t weight = 0;
+		uint32_t const alast = L.slast[i];
 		while ( common )
 		{
 			uint32_t const pa = __builtin_ctzll(common); common &= common-1;
 			uint32_t const ia = L.woffR[i] + dacc_popc64(mA & ((1ull<<pa)-1));
 			uint32_t const pb = pa-shift;
 			uint32_t const ib = L.woffR[b] + dacc_popc64(mB & ((1ull<<pb)-1));
-			double const lweight = G.wR[3*ib] + (G.wR[3*ia] - G.wR[3*ia+1]);
+			uint64_t const lweight = L.wuR[ib] + (L.wuR[ia] - nodeU(alast,pa,true));
 			weight = lweight > weight ? lweight : weight;
 		}
-		return weight >= 1e-1;
+		return weight >= FW_THRES_01;
 	}
 
-	// ---- index heaps over pool weights (same sift algorithm as oracle/o_heap.hpp) ----
+	// ================= views: the stretch set of a pair in sorted order =================
+	// view = base stretches minus the split parents plus the pieces; ord[] lists pool ids in Stretch::operator< order
+	DEV void buildView(uint32_t const * rem, uint32_t const nrem, uint32_t const * add, uint32_t const nadd)
+	{
+		uint64_t akey[4];
+		for ( uint32_t a = 0; a < nadd; ++a ) akey[a] = poolKey(add[a]);
+		for ( uint32_t s = lane; s < n0; s += WSZ )
+		{
+			bool removed = false; uint32_t before = 0;
+			for ( uint32_t r = 0; r < nrem; ++r ) { if ( rem[r] == s ) removed = true; else if ( rem[r] < s ) ++before; }
+			if ( !removed )
+			{
+				uint64_t const key = poolKey(s);
+				uint32_t ins = 0;
+				for ( uint32_t a = 0; a < nadd; ++a ) if ( akey[a] < key ) ++ins;
+				L.ord[s-before+ins] = s;
+			}
+		}
+		if ( lane == 0 )
+			for ( uint32_t a = 0; a < nadd; ++a )
+			{
+				uint32_t lo = 0, hi = n0;
+				while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( poolKey(mid) < akey[a] ) lo = mid+1; else hi = mid; }
+				uint32_t pos = lo;
+				for ( uint32_t r = 0; r < nrem; ++r ) if ( rem[r] < lo ) --pos;
+				for ( uint32_t b = 0; b < nadd; ++b ) if ( akey[b] < akey[a] ) ++pos;
+				L.ord[pos] = add[a];
+			}
+		nview = n0 - nrem + nadd;
+		wv_sync();
+	}
+	DEV uint32_t viewLowerBound(uint32_t const node) const
+	{
+		uint32_t lo = 0, hi = nview;
+		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.sfirst[L.ord[mid]] < node ) lo = mid+1; else hi = mid; }
+		return lo;
+	}
+
+	// ---- heaps (same sift algorithm as oracle/o_heap.hpp) ----
+	template<bool MINHEAP> DEV static bool hless(uint64_t a, uint64_t b) { return MINHEAP ? (a < b) : (a > b); }
 	template<bool MINHEAP>
-	DEV static bool hless(double a, double b) { return MINHEAP ? (a < b) : (a > b); }
-	template<bool MINHEAP>
-	DEV void ipush(uint16_t * H, uint32_t & f, uint16_t const id, double const * W)
+	DEV void ipush(uint8_t * H, uint32_t & f, uint8_t const id, uint64_t const * W)
 	{
 		uint32_t i = f++; H[i] = id;
 		while ( i )
 		{
 			uint32_t const p = (i-1)>>1;
-			if ( hless<MINHEAP>(W[H[i]],W[H[p]]) ) { uint16_t const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
+			if ( hless<MINHEAP>(W[H[i]],W[H[p]]) ) { uint8_t const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
 			else break;
 		}
 	}
 	template<bool MINHEAP>
-	DEV void ipop(uint16_t * H, uint32_t & f, double const * W)
+	DEV void ipop(uint8_t * H, uint32_t & f, uint64_t const * W)
 	{
 		H[0] = H[--f];
 		uint32_t i = 0, r;
@@ -665,332 +734,424 @@ struct FastEngine
 		{
 			uint32_t const m = hless<MINHEAP>(W[H[r-1]],W[H[r]]) ? (r-1) : r;
 			if ( hless<MINHEAP>(W[H[i]],W[H[m]]) ) return;
-			uint16_t const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
+			uint8_t const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
 		}
 		uint32_t const l = 2*i+1;
-		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { uint16_t const t = H[i]; H[i] = H[l]; H[l] = t; }
+		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { uint8_t const t = H[i]; H[i] = H[l]; H[l] = t; }
+	}
+	template<typename TT, bool MINHEAP>
+	DEV void spush(TT * H, uint32_t & f, TT const & e)
+	{
+		uint32_t i = f++; H[i] = e;
+		while ( i )
+		{
+			uint32_t const p = (i-1)>>1;
+			if ( hless<MINHEAP>(H[i].w,H[p].w) ) { TT const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
+			else break;
+		}
+	}
+	template<typename TT, bool MINHEAP>
+	DEV void spop(TT * H, uint32_t & f)
+	{
+		H[0] = H[--f];
+		uint32_t i = 0, r;
+		while ( (r = 2*i+2) < f )
+		{
+			uint32_t const m = hless<MINHEAP>(H[r-1].w,H[r].w) ? (r-1) : r;
+			if ( hless<MINHEAP>(H[i].w,H[m].w) ) return;
+			TT const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
+		}
+		uint32_t const l = 2*i+1;
+		if ( l < f && !hless<MINHEAP>(H[i].w,H[l].w) ) { TT const t = H[i]; H[i] = H[l]; H[l] = t; }
 	}
 
+	// ================= reverse enumeration on the current view (lane 0) =================
+	uint32_t rb, nrp, narp, rlastk;
 	DEV int32_t extendReversePath(uint32_t const parent, uint32_t const s)
 	{
-		if ( nrp >= C.pcapr ) { over(512); return -1; }
+		if ( rb+nrp >= C.rccap || nrp >= 250 ) { over(512); return -1; }
 		uint32_t const id = nrp++;
-		uint32_t const ppos = L.rp_pos[parent], plen = L.rp_len[parent];
+		uint32_t const ppos = L.rc_pos[rb+parent], plen = L.rc_len[rb+parent];
 		int32_t const sfo = csfFind(s,ppos);
-		double weight = L.rp_weight[parent]; uint32_t baselen = L.rp_baselen[parent];
-		if ( plen == 0 ) { baselen = L.sslen[s]+k-1; weight = sfo >= 0 ? G.wR[3*sfo] : 0.0; }
-		else { baselen += L.sslen[s]-1; if ( sfo >= 0 ) weight += G.wR[3*sfo] - G.wR[3*sfo+1]; }
-		L.rp_parent[id] = parent; L.rp_stretch[id] = s; L.rp_len[id] = plen+1; L.rp_pos[id] = ppos + L.sslen[s]-1;
-		L.rp_weight[id] = weight; L.rp_baselen[id] = baselen;
+		uint64_t weight = L.rc_w[rb+parent]; uint32_t baselen = L.rc_baselen[rb+parent];
+		if ( plen == 0 ) { baselen = L.sslen[s]+k-1; weight = sfo >= 0 ? L.wuR[sfo] : 0; }
+		else { baselen += L.sslen[s]-1; if ( sfo >= 0 ) weight += L.wuR[sfo] - nodeU(L.slast[s],ppos,true); }
+		uint32_t const npos = ppos + L.sslen[s]-1;
+		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --nrp; return -1; }
+		L.rc_parent[rb+id] = parent; L.rc_stretch[rb+id] = s; L.rc_len[rb+id] = plen+1; L.rc_pos[rb+id] = npos;
+		L.rc_w[rb+id] = weight; L.rc_baselen[rb+id] = baselen;
 		return id;
 	}
 	DEV bool checkReversePathFeasiblePosition(uint32_t const id) const
 	{
-		uint32_t const s = L.rp_stretch[id];
-		uint32_t const checkpos = L.rp_pos[id] - (L.sslen[s]-1);
+		uint32_t const s = L.rc_stretch[rb+id];
+		uint32_t const checkpos = L.rc_pos[rb+id] - (L.sslen[s]-1);
 		int32_t const f = csfFind(s,checkpos);
-		return f >= 0 && G.wR[3*f] >= 0.5;
+		return f >= 0 && L.wuR[f] >= FW_THRES_05;
 	}
-	DEV uint32_t rpFront(uint32_t const id, uint32_t const lastkmer) const { return L.rp_len[id] ? L.nv[L.sfirst[L.rp_stretch[id]]] : lastkmer; }
-
-	// std::sort permutation on ARP (see dbg_window.hpp arpSort); comparator (front, baselen)
-	uint32_t sortlastk;
-	DEV bool arpLess(uint16_t const a, uint16_t const b) const
+	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len[rb+id] ? L.nv[L.sfirst[L.rc_stretch[rb+id]]] : rlastk; }
+	DEV bool arpLess(uint8_t const a, uint8_t const b) const
 	{
-		uint32_t const fa = rpFront(a,sortlastk), fb = rpFront(b,sortlastk);
+		uint32_t const fa = rpFront(a), fb = rpFront(b);
 		if ( fa != fb ) return fa < fb;
-		return L.rp_baselen[a] < L.rp_baselen[b];
+		return L.rc_baselen[rb+a] < L.rc_baselen[rb+b];
 	}
-	DEV void arpULI(uint16_t * last) { uint16_t const val = *last; uint16_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
-	DEV void arpIns(uint16_t * first, uint16_t * last)
+	DEV void arpULI(uint8_t * last) { uint8_t const val = *last; uint8_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
+	DEV void arpIns(uint8_t * first, uint8_t * last)
 	{
 		if ( first == last ) return;
-		for ( uint16_t * i = first+1; i != last; ++i )
+		for ( uint8_t * i = first+1; i != last; ++i )
 		{
-			if ( arpLess(*i,*first) ) { uint16_t const val = *i; for ( uint16_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
+			if ( arpLess(*i,*first) ) { uint8_t const val = *i; for ( uint8_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
 			else arpULI(i);
 		}
 	}
-	DEV void arpSort(uint16_t * first, uint16_t * last)
+	// libstdc++ std::sort permutation (introsort + final insertion sort), see dbg_window.hpp arpSort
+	DEV void arpSort(uint8_t * first, uint8_t * last)
 	{
 		if ( first == last ) return;
-		int64_t const n = last-first;
+		int32_t const n = last-first;
 		if ( n > 16 )
 		{
-			int depth = 0; { int64_t t = n; while ( t > 1 ) { t >>= 1; ++depth; } depth *= 2; }
-			uint16_t * stF[40]; uint16_t * stL[40]; int stD[40]; int sp = 0;
-			stF[0] = first; stL[0] = last; stD[0] = depth; sp = 1;
+			int depth = 0; { int32_t t = n; while ( t > 1 ) { t >>= 1; ++depth; } depth *= 2; }
+			uint8_t stF[24], stL[24], stD[24]; int sp = 0;   // offsets from first
+			stF[0] = 0; stL[0] = n; stD[0] = depth; sp = 1;
 			while ( sp )
 			{
 				--sp;
-				uint16_t * f = stF[sp]; uint16_t * l = stL[sp]; int d = stD[sp];
+				uint8_t * f = first+stF[sp]; uint8_t * l = first+stL[sp]; int d = stD[sp];
 				while ( l-f > 16 )
 				{
 					if ( d == 0 ) { over(1024); return; }
 					--d;
-					uint16_t * mid = f + (l-f)/2; uint16_t * a = f+1; uint16_t * b = mid; uint16_t * c = l-1;
+					uint8_t * mid = f + (l-f)/2; uint8_t * a = f+1; uint8_t * b = mid; uint8_t * c = l-1;
 					if ( arpLess(*a,*b) )
 					{
-						if ( arpLess(*b,*c) ) { uint16_t t = *f; *f = *b; *b = t; }
-						else if ( arpLess(*a,*c) ) { uint16_t t = *f; *f = *c; *c = t; }
-						else { uint16_t t = *f; *f = *a; *a = t; }
+						if ( arpLess(*b,*c) ) { uint8_t t = *f; *f = *b; *b = t; }
+						else if ( arpLess(*a,*c) ) { uint8_t t = *f; *f = *c; *c = t; }
+						else { uint8_t t = *f; *f = *a; *a = t; }
 					}
-					else if ( arpLess(*a,*c) ) { uint16_t t = *f; *f = *a; *a = t; }
-					else if ( arpLess(*b,*c) ) { uint16_t t = *f; *f = *c; *c = t; }
-					else { uint16_t t = *f; *f = *b; *b = t; }
-					uint16_t * lo = f+1; uint16_t * hi = l;
+					else if ( arpLess(*a,*c) ) { uint8_t t = *f; *f = *a; *a = t; }
+					else if ( arpLess(*b,*c) ) { uint8_t t = *f; *f = *c; *c = t; }
+					else { uint8_t t = *f; *f = *b; *b = t; }
+					uint8_t * lo = f+1; uint8_t * hi = l;
 					while ( true )
 					{
 						while ( arpLess(*lo,*f) ) ++lo;
 						--hi;
 						while ( arpLess(*f,*hi) ) --hi;
 						if ( !(lo < hi) ) break;
-						uint16_t t = *lo; *lo = *hi; *hi = t;
+						uint8_t t = *lo; *lo = *hi; *hi = t;
 						++lo;
 					}
-					if ( sp < 40 ) { stF[sp] = lo; stL[sp] = l; stD[sp] = d; ++sp; } else { over(1024); return; }
+					if ( sp < 24 ) { stF[sp] = lo-first; stL[sp] = l-first; stD[sp] = d; ++sp; } else { over(1024); return; }
 					l = lo;
 				}
 			}
 			arpIns(first,first+16);
-			for ( uint16_t * i = first+16; i != last; ++i ) arpULI(i);
+			for ( uint8_t * i = first+16; i != last; ++i ) arpULI(i);
 		}
 		else arpIns(first,last);
 	}
 
+	// prepareTraverse :3582-3765 on the current view; result block at rc_*[rb ..rb+nrp), sorted order rc_ord, ranks rc_arw
 	DEV void reverseEnumerate(uint32_t const lastkmer, int32_t const lastnode, int64_t const lmax)
 	{
-		nrp = 0; narp = 0;
+		nrp = 0; narp = 0; rlastk = lastkmer;
 		for ( uint32_t i = 0; i < C.blcap; ++i ) L.hbl_n[i] = 0;
 		uint32_t nrpst = 0;
 		if ( lastnode >= 0 )
 		{
+			if ( rb >= C.rccap ) { over(512); return; }
 			uint32_t const id = nrp++;
-			L.rp_parent[id] = 0xFFFF; L.rp_stretch[id] = 0xFFFF; L.rp_len[id] = 0; L.rp_pos[id] = 0; L.rp_weight[id] = 0.0; L.rp_baselen[id] = k;
-			L.rpst_i[nrpst] = id; ++nrpst;
+			L.rc_parent[rb+id] = 0xFF; L.rc_stretch[rb+id] = 0xFF; L.rc_len[rb+id] = 0; L.rc_pos[rb+id] = 0; L.rc_w[rb+id] = 0; L.rc_baselen[rb+id] = k;
+			L.rpst[nrpst++] = id;
 		}
+		uint64_t const * W = L.rc_w + rb;
 		while ( nrpst )
 		{
-			uint32_t const rp = L.rpst_i[0];
-			ipop<false>(L.rpst_i,nrpst,L.rp_weight);
-			uint32_t const bl = L.rp_baselen[rp];
+			uint32_t const rp = L.rpst[0];
+			ipop<false>(L.rpst,nrpst,W);
+			uint32_t const bl = L.rc_baselen[rb+rp];
 			if ( bl >= C.blcap ) { over(2048); return; }
-			uint16_t * H = L.hbl + 12*bl; uint32_t hn = L.hbl_n[bl];
+			uint8_t * H = L.hbl + 12*bl; uint32_t hn = L.hbl_n[bl];
 			if ( hn == 12 )
 			{
-				if ( L.rp_weight[rp] <= L.rp_weight[H[0]] ) continue;
-				else ipop<true>(H,hn,L.rp_weight);
+				if ( W[rp] <= W[H[0]] ) continue;
+				else ipop<true>(H,hn,W);
 			}
-			ipush<true>(H,hn,rp,L.rp_weight);
+			ipush<true>(H,hn,rp,W);
 			L.hbl_n[bl] = hn;
-			L.arp[narp++] = rp;
-			if ( L.rp_len[rp] == 0 )
+			if ( narp >= 250 ) { over(512); return; }
+			L.rc_ord[rb+narp++] = rp;
+			if ( L.rc_len[rb+rp] == 0 )
 			{
-				for ( uint32_t s = 0; s < nstretch; ++s )
+				for ( uint32_t t = 0; t < nview; ++t )
+				{
+					uint32_t const s = L.ord[t];
 					if ( L.slast[s] == lastnode )
 					{
 						int32_t const rpe = extendReversePath(rp,s);
 						if ( rpe < 0 ) return;
-						if ( checkReversePathFeasiblePosition(rpe) ) ipush<false>(L.rpst_i,nrpst,rpe,L.rp_weight);
-						else --nrp; // an infeasible extension is never referenced again: recycle its slot
+						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst,nrpst,rpe,W); }
+						else --nrp;
 					}
+				}
 			}
-			else if ( static_cast<int64_t>(L.rp_baselen[rp]) < (lmax+1)/2 )
+			else if ( static_cast<int64_t>(L.rc_baselen[rb+rp]) < (lmax+1)/2 )
 			{
-				uint32_t const b = L.rp_stretch[rp];
-				// candidates A with A.last == B.first, ascending A (the sorted (to,from) pairs of the reference)
+				uint32_t const b = L.rc_stretch[rb+rp];
 				uint32_t const bf = L.sfirst[b];
-				for ( uint32_t a = 0; a < nstretch; ++a )
+				for ( uint32_t t = 0; t < nview; ++t )
+				{
+					uint32_t const a = L.ord[t];
 					if ( L.slast[a] == bf && linkOk(a,b) )
 					{
 						int32_t const rpe = extendReversePath(rp,a);
 						if ( rpe < 0 ) return;
-						if ( checkReversePathFeasiblePosition(rpe) ) ipush<false>(L.rpst_i,nrpst,rpe,L.rp_weight);
+						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst,nrpst,rpe,W); }
 						else --nrp;
 					}
+				}
 			}
 		}
-		sortlastk = lastkmer;
-		arpSort(L.arp,L.arp+narp);
+		arpSort(L.rc_ord+rb,L.rc_ord+rb+narp);
 		for ( uint32_t i = 0; i < narp; ++i )
 		{
-			double const wi = L.rp_weight[L.arp[i]];
+			uint64_t const wi = W[L.rc_ord[rb+i]];
 			uint32_t r = 0;
 			for ( uint32_t j = 0; j < narp; ++j )
 			{
-				double const wj = L.rp_weight[L.arp[j]];
+				uint64_t const wj = W[L.rc_ord[rb+j]];
 				if ( wj < wi || (wj == wi && j < i) ) ++r;
 			}
-			L.arw[i] = r; L.arwr[i] = narp-r-1;
+			L.rc_arw[rb+i] = r;
 		}
+	}
+	// can the cached reverse block (computed on the view of `last` alone) be used when stretch `par` is split at node `fn`?
+	// the scans of the enumeration look for stretches whose last node equals a target; the split changes the answer
+	// only for targets par.last (parent vs second piece) and fn (first piece)
+	DEV bool reverseUnaffected(uint32_t const base, uint32_t const nacc2, int32_t const lastnode, uint32_t const par, uint32_t const fn, int64_t const lmax) const
+	{
+		uint32_t const plast = L.slast[par];
+		if ( lastnode >= 0 && (static_cast<uint32_t>(lastnode) == plast || static_cast<uint32_t>(lastnode) == fn) ) return false;
+		for ( uint32_t i = 0; i < nacc2; ++i )
+		{
+			uint32_t const rp = L.rc_ord[base+i];
+			if ( L.rc_len[base+rp] && static_cast<int64_t>(L.rc_baselen[base+rp]) < (lmax+1)/2 )
+			{
+				uint32_t const target = L.sfirst[L.rc_stretch[base+rp]];
+				if ( target == plast || target == fn ) return false;
+			}
+		}
+		return true;
 	}
 
+	// ================= forward enumeration on the current view (lane 0) =================
+	uint32_t apqlo, apqhi;
 	DEV int32_t extendPath(int32_t const parent, uint32_t const s)
 	{
-		if ( np >= C.pcapf ) { over(512); return -1; }
+		if ( np >= C.fcap || np >= 250 ) { over(512); return -1; }
 		uint32_t const id = np++;
-		uint32_t const ppos = parent >= 0 ? L.p_pos[parent] : 0;
-		uint32_t const plen = parent >= 0 ? L.p_len[parent] : 0;
-		double weight = parent >= 0 ? L.p_weight[parent] : 0.0;
-		uint32_t baselen = parent >= 0 ? L.p_baselen[parent] : 0;
+		uint32_t const ppos = parent >= 0 ? L.f_pos[parent] : 0;
+		uint32_t const plen = parent >= 0 ? L.f_len[parent] : 0;
+		uint64_t weight = parent >= 0 ? L.f_w[parent] : 0;
+		uint32_t baselen = parent >= 0 ? L.f_baselen[parent] : 0;
 		int32_t const sfo = sfFind(s,ppos);
-		if ( plen == 0 ) { baselen = L.sslen[s]+k-1; weight = sfo >= 0 ? G.wF[3*sfo] : 0; }
-		else { baselen += L.sslen[s]-1; if ( sfo >= 0 ) weight += G.wF[3*sfo] - G.wF[3*sfo+1]; }
-		L.p_parent[id] = parent >= 0 ? parent : 0xFFFF; L.p_stretch[id] = s; L.p_len[id] = plen+1; L.p_pos[id] = ppos + (L.sslen[s]-1);
-		L.p_weight[id] = weight; L.p_baselen[id] = baselen;
+		if ( plen == 0 ) { baselen = L.sslen[s]+k-1; weight = sfo >= 0 ? L.wuF[sfo] : 0; }
+		else { baselen += L.sslen[s]-1; if ( sfo >= 0 ) weight += L.wuF[sfo] - nodeU(L.sfirst[s],ppos,false); }
+		uint32_t const npos = ppos + (L.sslen[s]-1);
+		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --np; return -1; }
+		L.f_parent[id] = parent >= 0 ? parent : 0xFF; L.f_stretch[id] = s; L.f_len[id] = plen+1; L.f_pos[id] = npos;
+		L.f_w[id] = weight; L.f_baselen[id] = baselen;
 		return id;
 	}
-	uint32_t apqlo, apqhi;
 	DEV bool apqPush(uint32_t const id)
 	{
-		uint32_t const bl = L.p_baselen[id];
+		uint32_t const bl = L.f_baselen[id];
 		if ( bl >= C.blcap ) { over(2048); return false; }
-		uint16_t * H = L.hbl + 12*bl; uint32_t hn = L.hbl_n[bl];
+		uint8_t * H = L.hbl + 12*bl; uint32_t hn = L.hbl_n[bl];
 		if ( hn == 12 )
 		{
-			if ( L.p_weight[id] > L.p_weight[H[0]] ) { ipop<true>(H,hn,L.p_weight); ipush<true>(H,hn,id,L.p_weight); }
+			if ( L.f_w[id] > L.f_w[H[0]] ) { ipop<true>(H,hn,L.f_w); ipush<true>(H,hn,id,L.f_w); }
 		}
-		else ipush<true>(H,hn,id,L.p_weight);
+		else ipush<true>(H,hn,id,L.f_w);
 		L.hbl_n[bl] = hn;
 		if ( bl < apqlo ) apqlo = bl;
 		if ( bl+1 > apqhi ) apqhi = bl+1;
 		return true;
 	}
-	DEV double getPairScore(uint32_t const path, uint32_t const rp) const
+	// path tree of traverse :4838-5041 without the score-interval part (that one depends on the reverse block)
+	DEV void forwardEnumerate(int32_t const firstnode, int64_t const lmax)
 	{
-		uint32_t const s = L.p_stretch[path];
-		uint32_t const spos = L.p_pos[path] - (L.sslen[s]-1);
-		int32_t const sfo = sfFind(s,spos);
-		if ( sfo >= 0 ) return L.p_weight[path] + L.rp_weight[rp] - G.wF[3*sfo+2];
-		else return L.p_weight[path] + L.rp_weight[rp];
-	}
-	DEV uint32_t decodePathPair(uint32_t const path, uint32_t const rp, uint32_t o)
-	{
-		uint16_t chain[64]; uint32_t cl = 0;
-		for ( uint32_t q = path; q != 0xFFFF; q = L.p_parent[q] ) { if ( cl >= 64 ) { over(4096); return ~0u; } chain[cl++] = L.p_stretch[q]; }
-		uint32_t need = k;
-		for ( uint32_t i = 0; i < cl; ++i ) need += L.sslen[chain[i]]-1;
-		for ( uint32_t q = rp; L.rp_len[q]; q = L.rp_parent[q] ) need += L.sslen[L.rp_stretch[q]]-1;
-		if ( o + need > C.conscap - MAXCONS ) { over(4096); return ~0u; }
-		uint32_t const firstv = L.nv[L.sfirst[chain[cl-1]]];
-		for ( uint32_t i = 0; i < k; ++i ) G.cons[o++] = (firstv >> (2*(k-1-i))) & 3;
-		for ( uint32_t ii = 0; ii < cl; ++ii )
-		{
-			uint32_t const s = chain[cl-1-ii]; uint16_t const * Lk = L.links + L.slink[s];
-			for ( uint32_t j = 1; j < L.sslen[s]; ++j ) G.cons[o++] = L.nv[Lk[j]] & 3;
-		}
-		for ( uint32_t q = rp; L.rp_len[q]; q = L.rp_parent[q] )
-		{
-			uint32_t const s = L.rp_stretch[q]; uint16_t const * Lk = L.links + L.slink[s];
-			for ( uint32_t j = 1; j < L.sslen[s]; ++j ) G.cons[o++] = L.nv[Lk[j]] & 3;
-		}
-		return o;
-	}
-
-	DEV void forwardAndPairs(int32_t const firstnode, uint32_t const lastkmer, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
-	{
-		np = 0; nsiq = 0;
+		np = 0; nfpop = 0;
 		for ( uint32_t i = 0; i < C.blcap; ++i ) L.hbl_n[i] = 0;
 		apqlo = C.blcap; apqhi = 0;
-		for ( uint32_t s = 0; s < nstretch; ++s )
+		for ( uint32_t t = 0; t < nview; ++t )
+		{
+			uint32_t const s = L.ord[t];
 			if ( L.sfirst[s] == firstnode )
 			{
 				int32_t const id = extendPath(-1,s);
 				if ( id < 0 || !apqPush(id) ) return;
 			}
+		}
 		for ( uint32_t zz = apqlo; zz < apqhi; ++zz )
 			while ( L.hbl_n[zz] )
 			{
-				uint16_t * H = L.hbl + 12*zz; uint32_t hn = L.hbl_n[zz];
+				uint8_t * H = L.hbl + 12*zz; uint32_t hn = L.hbl_n[zz];
 				uint32_t const path = H[0];
-				ipop<true>(H,hn,L.p_weight);
+				ipop<true>(H,hn,L.f_w);
 				L.hbl_n[zz] = hn;
-				int64_t const candlen = static_cast<int64_t>(L.p_pos[path]) + k;
-				uint32_t const laststretch = L.p_stretch[path];
-				uint32_t const front = L.nv[L.slast[laststretch]];
-				uint32_t lo = 0, hi = narp;
-				while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( rpFront(L.arp[mid],lastkmer) < front ) lo = mid+1; else hi = mid; }
-				uint32_t e = lo;
-				while ( e < narp && rpFront(L.arp[e],lastkmer) == front ) ++e;
-				int64_t bllo = lmin + static_cast<int64_t>(k) - candlen; if ( bllo < 0 ) bllo = 0;
-				int64_t blhi = lmax + static_cast<int64_t>(k) - candlen; if ( blhi < 0 ) blhi = 0;
-				uint32_t const bllo16 = static_cast<uint16_t>(bllo), blhi16 = static_cast<uint16_t>(blhi);
-				uint32_t sub = lo;
-				while ( sub < e && L.rp_baselen[L.arp[sub]] < bllo16 ) ++sub;
-				uint32_t sup = sub;
-				while ( sup < e && !(blhi16 < L.rp_baselen[L.arp[sup]]) ) ++sup;
-				if ( sub != sup )
-				{
-					uint32_t mi = sub;
-					for ( uint32_t i = sub+1; i < sup; ++i ) if ( L.arwr[i] < L.arwr[mi] ) mi = i;
-					if ( nsiq >= C.siqcap ) { over(512); return; }
-					HeapSI si; si.left = sub; si.right = sup; si.current = mi; si.path = path; si.w = getPairScore(path,L.arp[mi]);
-					heap_push<HeapSI,CmpWGreater>(L.siq,nsiq,si);
-				}
-				uint32_t const pbl = L.p_baselen[path];
+				if ( nfpop >= C.fcap ) { over(512); return; }
+				L.fpop[nfpop++] = path;
+				uint32_t const pbl = L.f_baselen[path];
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 				{
-					uint32_t const lastn = L.slast[laststretch];
-					for ( uint32_t s = stretchLowerBound(lastn); s < nstretch && L.sfirst[s] == lastn; ++s )
+					uint32_t const lastn = L.slast[L.f_stretch[path]];
+					for ( uint32_t t = viewLowerBound(lastn); t < nview && L.sfirst[L.ord[t]] == lastn; ++t )
 					{
-						int32_t const sfo = sfFind(s,L.p_pos[path]);
-						double const eweight = sfo >= 0 ? G.wF[3*sfo] : 0.0;
-						if ( eweight > 0.1 )
+						uint32_t const s = L.ord[t];
+						int32_t const sfo = sfFind(s,L.f_pos[path]);
+						uint64_t const eweight = sfo >= 0 ? L.wuF[sfo] : 0;
+						if ( eweight >= FW_THRES_01 )
 						{
 							int32_t const ep = extendPath(path,s);
 							if ( ep < 0 ) return;
-							if ( L.p_weight[ep] > 0.1 && static_cast<int64_t>(L.p_pos[ep]) + k <= lmax )
+							if ( L.f_w[ep] >= FW_THRES_01 && static_cast<int64_t>(L.f_pos[ep]) + k <= lmax )
 							{
 								if ( !apqPush(ep) ) return;
 							}
-							else --np; // never referenced again
+							else --np;
 						}
 					}
 				}
 			}
-		uint32_t prevo = 0, prevlen = ~0u;
+	}
+	// scans of the forward enumeration look for stretches whose first node equals a target; splitting `par` at `ln`
+	// changes the answer only for targets par.first (parent vs first piece) and ln (second piece)
+	DEV bool forwardUnaffected(int32_t const firstnode, uint32_t const par, uint32_t const ln, int64_t const lmax) const
+	{
+		uint32_t const pfirst = L.sfirst[par];
+		if ( static_cast<uint32_t>(firstnode) == pfirst || static_cast<uint32_t>(firstnode) == ln ) return false;
+		for ( uint32_t i = 0; i < nfpop; ++i )
+		{
+			uint32_t const path = L.fpop[i];
+			uint32_t const pbl = L.f_baselen[path];
+			if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
+			{
+				uint32_t const target = L.slast[L.f_stretch[path]];
+				if ( target == pfirst || target == ln ) return false;
+			}
+		}
+		return true;
+	}
+
+	// ================= combining a forward tree with a reverse block (score intervals + pair loop) =================
+	DEV uint64_t getPairScore(uint32_t const path, uint32_t const base, uint32_t const rp) const
+	{
+		uint32_t const s = L.f_stretch[path];
+		uint32_t const spos = L.f_pos[path] - (L.sslen[s]-1);
+		int32_t const sfo = sfFind(s,spos);
+		if ( sfo >= 0 ) return L.f_w[path] + L.rc_w[base+rp] - nodeU(L.slast[s],L.f_pos[path],false);
+		else return L.f_w[path] + L.rc_w[base+rp];
+	}
+	DEV uint32_t rcFront(uint32_t const base, uint32_t const rp, uint32_t const lastkmer) const { return L.rc_len[base+rp] ? L.nv[L.sfirst[L.rc_stretch[base+rp]]] : lastkmer; }
+	// decodePathPair :4267-4300 into dst (2-bit codes); returns length or ~0
+	DEV uint32_t decodePathPair(uint32_t const path, uint32_t const base, uint32_t const rp, uint8_t * dst)
+	{
+		uint8_t chain[64]; uint32_t cl = 0;
+		for ( uint32_t q = path; q != 0xFF; q = L.f_parent[q] ) { if ( cl >= 64 ) { over(4096); return ~0u; } chain[cl++] = L.f_stretch[q]; }
+		uint32_t need = k;
+		for ( uint32_t i = 0; i < cl; ++i ) need += L.sslen[chain[i]]-1;
+		for ( uint32_t q = rp; L.rc_len[base+q]; q = L.rc_parent[base+q] ) need += L.sslen[L.rc_stretch[base+q]]-1;
+		if ( need > MAXCONS ) { over(4096); return ~0u; }
+		uint32_t o = 0;
+		uint32_t const firstv = L.nv[L.sfirst[chain[cl-1]]];
+		for ( uint32_t i = 0; i < k; ++i ) dst[o++] = (firstv >> (2*(k-1-i))) & 3;
+		for ( uint32_t ii = 0; ii < cl; ++ii )
+		{
+			uint32_t const s = chain[cl-1-ii]; uint16_t const * Lk = L.links + L.slink[s];
+			for ( uint32_t j = 1; j < L.sslen[s]; ++j ) dst[o++] = L.nv[Lk[j]] & 3;
+		}
+		for ( uint32_t q = rp; L.rc_len[base+q]; q = L.rc_parent[base+q] )
+		{
+			uint32_t const s = L.rc_stretch[base+q]; uint16_t const * Lk = L.links + L.slink[s];
+			for ( uint32_t j = 1; j < L.sslen[s]; ++j ) dst[o++] = L.nv[Lk[j]] & 3;
+		}
+		return o;
+	}
+	DEV void combinePair(uint32_t const base, uint32_t const nacc2, uint32_t const lastkmer, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
+	{
+		nsiq = 0;
+		for ( uint32_t pi = 0; pi < nfpop; ++pi )
+		{
+			uint32_t const path = L.fpop[pi];
+			int64_t const candlen = static_cast<int64_t>(L.f_pos[path]) + k;
+			uint32_t const front = L.nv[L.slast[L.f_stretch[path]]];
+			uint32_t lo = 0, hi = nacc2;
+			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( rcFront(base,L.rc_ord[base+mid],lastkmer) < front ) lo = mid+1; else hi = mid; }
+			uint32_t e = lo;
+			while ( e < nacc2 && rcFront(base,L.rc_ord[base+e],lastkmer) == front ) ++e;
+			int64_t bllo = lmin + static_cast<int64_t>(k) - candlen; if ( bllo < 0 ) bllo = 0;
+			int64_t blhi = lmax + static_cast<int64_t>(k) - candlen; if ( blhi < 0 ) blhi = 0;
+			uint32_t const bllo16 = static_cast<uint16_t>(bllo), blhi16 = static_cast<uint16_t>(blhi);
+			uint32_t sub = lo;
+			while ( sub < e && L.rc_baselen[base+L.rc_ord[base+sub]] < bllo16 ) ++sub;
+			uint32_t sup = sub;
+			while ( sup < e && !(blhi16 < L.rc_baselen[base+L.rc_ord[base+sup]]) ) ++sup;
+			if ( sub != sup )
+			{
+				uint32_t mi = sub;
+				for ( uint32_t i = sub+1; i < sup; ++i ) if ( L.rc_arw[base+i] > L.rc_arw[base+mi] ) mi = i;
+				if ( nsiq >= C.siqcap ) { over(512); return; }
+				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = path; si.pad = 0; si.w = getPairScore(path,base,L.rc_ord[base+mi]);
+				spush<FSI,false>(L.siq,nsiq,si);
+			}
+		}
+		prevlen = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
 		{
-			HeapSI const si = L.siq[0];
-			heap_popvoid<HeapSI,CmpWGreater>(L.siq,nsiq);
+			FSI const si = L.siq[0];
+			// the score intervals leave the heap in non increasing weight order and everything still inside is not
+			// heavier, so once the candidate heap is full and its top cannot be beaten, nothing of this pair can enter
+			if ( ncdh == 16 && si.w <= L.cdh[0].w ) break;
+			spop<FSI,false>(L.siq,nsiq);
 			{
-				uint32_t const v = L.arw[si.current];
+				uint32_t const v = L.rc_arw[base+si.current];
 				if ( v )
 				{
 					bool found = false; uint32_t bu = 0, bi = 0;
 					for ( uint32_t i = si.left; i < si.right; ++i )
 					{
-						uint32_t const r = L.arw[i];
+						uint32_t const r = L.rc_arw[base+i];
 						if ( r <= v-1 && (!found || r > bu) ) { found = true; bu = r; bi = i; }
 					}
 					if ( found )
 					{
-						HeapSI sic = si; sic.current = bi; sic.w = getPairScore(si.path,L.arp[bi]);
+						FSI sic = si; sic.current = bi; sic.w = getPairScore(si.path,base,L.rc_ord[base+bi]);
 						if ( nsiq >= C.siqcap ) { over(512); return; }
-						heap_push<HeapSI,CmpWGreater>(L.siq,nsiq,sic);
+						spush<FSI,false>(L.siq,nsiq,sic);
 					}
 				}
 			}
-			double const weight = si.w;
-			if ( ncdh == 16 )
-			{
-				if ( weight <= L.cdh[0].w ) continue;
-				else heap_popvoid<HeapCC,CmpWLess>(L.cdh,ncdh);
-			}
-			uint32_t const consstart = conso;
-			uint32_t const nc = decodePathPair(si.path,L.arp[si.current],conso);
-			if ( nc == ~0u ) return;
-			conso = nc;
-			uint32_t const conslen = conso-consstart;
+			uint64_t const weight = si.w;
+			if ( ncdh == 16 ) spop<FCC,true>(L.cdh,ncdh);   // weight > top here
+			uint32_t const conslen = decodePathPair(si.path,base,L.rc_ord[base+si.current],L.curstr);
+			if ( conslen == ~0u ) return;
 			if ( conslen == prevlen )
 			{
 				bool eq = true;
-				for ( uint32_t i = 0; i < conslen; ++i ) if ( G.cons[prevo+i] != G.cons[consstart+i] ) { eq = false; break; }
+				for ( uint32_t i = 0; i < conslen; ++i ) if ( L.prevstr[i] != L.curstr[i] ) { eq = false; break; }
 				if ( eq ) continue;
 			}
-			prevo = consstart; prevlen = conslen;
-			HeapCC cc; cc.w = weight; cc.o = consstart; cc.l = conslen;
-			heap_push<HeapCC,CmpWLess>(L.cdh,ncdh,cc);
+			for ( uint32_t i = 0; i < conslen; ++i ) L.prevstr[i] = L.curstr[i];
+			prevlen = conslen;
+			if ( conso + conslen > C.conscap - MAXCONS ) { over(4096); return; }
+			for ( uint32_t i = 0; i < conslen; ++i ) G.cons[conso+i] = L.curstr[i];
+			FCC cc; cc.w = weight; cc.o = conso; cc.l = conslen;
+			conso += conslen;
+			spush<FCC,true>(L.cdh,ncdh,cc);
 		}
 	}
 
@@ -1029,49 +1190,143 @@ struct FastEngine
 		wv_sync();
 	}
 
+	// ================= traverse (:4496-5170) for one activation state =================
 	DEV bool traverse(int64_t const lmin, int64_t const lmax)
 	{
-		if ( lane == 0 ) { conso = 0; ncdh = 0; nacc = 0; }
-		uint32_t const firstthres = nmfirst ? ((static_cast<uint32_t>((~L.mfirst[0])>>32))*3)/4 : 0;
-		uint32_t const lastthres = nmlast ? ((static_cast<uint32_t>((~L.mlast[0])>>32))*3)/4 : 0;
-		for ( uint32_t fi = 0; fi < nmfirst; ++fi )
+		PROF_T0
+		conso = 0; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; rctop = 0; fcur_fi = -1; fcur_li = -1;
+		computeBaseStretches();
+		flags = wv_or(flags); if ( flags ) return false;
+		PROF(*this,8)
+		findCandidatesAndPieces();
+		flags = wv_or(flags); if ( flags ) return false;
+		computeStretchFeas(0,npool);
+		flags = wv_or(flags); if ( flags ) return false;
+		for ( uint32_t i = lane; i < FNC+1; i += WSZ ) L.rvalid[i] = 0;
+		wv_sync();
+		PROF(*this,9)
+#if defined(DACC_EMUL) && defined(DACC_FSTATS)
+		fstat(0,nwF); fstat(1,nwR); fstat(2,npool); fstat(3,nF); fstat(4,nL); fstat(5,nlinks); fstat(6,nn); fstat(7,npre);
+#endif
+		for ( uint32_t fi = 0; fi < nF; ++fi )
 		{
-			uint64_t const fkey = ~L.mfirst[fi];
-			if ( static_cast<uint32_t>(fkey>>32) < firstthres ) break;
-			for ( uint32_t li = 0; li < nmlast; ++li )
+			int32_t const firstnode = L.fnode[fi] == 0xFFFF ? -1 : L.fnode[fi];
+			uint32_t const sf = L.parF[fi];
+			for ( uint32_t li = 0; li < nL; ++li )
 			{
-				uint64_t const lkey = ~L.mlast[li];
-				if ( static_cast<uint32_t>(lkey>>32) < lastthres ) break;
-				uint32_t const firstk = static_cast<uint32_t>(fkey), lastk = static_cast<uint32_t>(lkey);
-				int32_t const firstnode = findNode(firstk);
-				int32_t const lastnode = findNode(lastk);
-				PROF_T0
-				computeStretches(firstnode,lastnode);
-				PROF(*this,8)
-				flags = wv_or(flags);
-				if ( flags ) return false;
-				computeStretchFeas();
-				PROF(*this,9)
-				flags = wv_or(flags);
-				if ( flags ) return false;
+				uint32_t const lastk = L.lkmer[li];
+				int32_t const lastnode = L.lnode[li] == 0xFFFF ? -1 : L.lnode[li];
+				uint32_t const sl = L.parL[li];
+				bool const same = (sf != FNOPAR && sf == sl);
+				// ---- the pair's exact stretch set (split at first, then at last)
+				uint32_t remX[2], addX[4]; uint32_t nremX = 0, naddX = 0; bool needMid = false; uint32_t midA = 0, midB = 0;
+				if ( same )
+				{
+					uint32_t const pf = L.posF[fi], pl = L.posL[li];
+					remX[nremX++] = sf;
+					if ( pf == pl ) { addX[naddX++] = L.pieF[fi]; addX[naddX++] = L.pieF[fi]+1; }
+					else if ( pf < pl ) { addX[naddX++] = L.pieF[fi]; addX[naddX++] = L.pieL[li]+1; needMid = true; midA = pf; midB = pl; }
+					else { addX[naddX++] = L.pieL[li]; addX[naddX++] = L.pieF[fi]+1; needMid = true; midA = pl; midB = pf; }
+				}
+				else
+				{
+					if ( sf != FNOPAR ) { remX[nremX++] = sf; addX[naddX++] = L.pieF[fi]; addX[naddX++] = L.pieF[fi]+1; }
+					if ( sl != FNOPAR ) { remX[nremX++] = sl; addX[naddX++] = L.pieL[li]; addX[naddX++] = L.pieL[li]+1; }
+				}
+				// ---- reverse block: cached per last k-mer when the first k-mer's split cannot touch it
+				bool rcached = false;
+				if ( !same )
+				{
+					if ( ! L.rvalid[li] )
+					{
+						uint32_t remL[1], addL[2]; uint32_t nr = 0, na = 0;
+						if ( sl != FNOPAR ) { remL[nr++] = sl; addL[na++] = L.pieL[li]; addL[na++] = L.pieL[li]+1; }
+						buildView(remL,nr,addL,na);
+						if ( lane == 0 )
+						{
+							rb = rctop;
+							reverseEnumerate(lastk,lastnode,lmax);
+							L.rbase[li] = rb; L.rn[li] = narp; L.rnpool[li] = nrp; L.rvalid[li] = 1;
+							rctop = rb + nrp;
+						}
+						wv_sync();
+						flags = wv_bcast(flags,0); if ( flags ) return false;
+						rctop = wv_bcast(rctop,0);
+					}
+					rcached = (sf == FNOPAR);
+					if ( !rcached )
+					{
+						uint32_t ok = 0;
+						if ( lane == 0 ) ok = reverseUnaffected(L.rbase[li],L.rn[li],lastnode,sf,L.fnode[fi],lmax) ? 1 : 0;
+						rcached = wv_bcast(ok,0) != 0;
+					}
+				}
+				// ---- forward tree: cached for the current first k-mer when the last k-mer's split cannot touch it
+				bool fcached = false;
+				if ( !same )
+				{
+					if ( fcur_fi != static_cast<int32_t>(fi) || fcur_li != -1 )
+					{
+						uint32_t remF[1], addF[2]; uint32_t nr = 0, na = 0;
+						if ( sf != FNOPAR ) { remF[nr++] = sf; addF[na++] = L.pieF[fi]; addF[na++] = L.pieF[fi]+1; }
+						buildView(remF,nr,addF,na);
+						if ( lane == 0 ) forwardEnumerate(firstnode,lmax);
+						wv_sync();
+						flags = wv_bcast(flags,0); if ( flags ) return false;
+						fcur_fi = fi; fcur_li = -1;
+					}
+					fcached = (sl == FNOPAR);
+					if ( !fcached )
+					{
+						uint32_t ok = 0;
+						if ( lane == 0 ) ok = forwardUnaffected(firstnode,sl,L.lnode[li],lmax) ? 1 : 0;
+						fcached = wv_bcast(ok,0) != 0;
+					}
+				}
+				// ---- exact enumeration where a cache cannot be used
+				uint32_t swF = nwF, swR = nwR;
+				if ( !rcached || !fcached )
+				{
+					if ( needMid )
+					{
+						// middle piece of a stretch split twice: a temporary pool entry with its own feasibility
+						if ( npool+1 > C.scap ) { over(32); return false; }
+						if ( lane == 0 ) makePiece(npool,sf,midA,midB);
+						wv_sync();
+						computeStretchFeas(npool,npool+1);
+						flags = wv_or(flags); if ( flags ) return false;
+						addX[naddX++] = npool;
+					}
+					buildView(remX,nremX,addX,naddX);
+					if ( lane == 0 )
+					{
+						if ( !rcached ) { rb = rctop; reverseEnumerate(lastk,lastnode,lmax); }
+						if ( !fcached && !flags ) forwardEnumerate(firstnode,lmax);
+					}
+					wv_sync();
+					flags = wv_bcast(flags,0); if ( flags ) return false;
+					if ( !fcached ) { fcur_fi = fi; fcur_li = li; }
+				}
 				if ( lane == 0 )
 				{
-					reverseEnumerate(lastk,lastnode,lmax);
-					PROF(*this,11)
-					if ( ! flags ) forwardAndPairs(firstnode,lastk,lmin,lmax,16);
-					PROF(*this,12)
+					uint32_t base, nacc2;
+					if ( rcached ) { base = L.rbase[li]; nacc2 = L.rn[li]; } else { base = rb; nacc2 = narp; }
+					combinePair(base,nacc2,lastk,lmin,lmax,16);
 				}
 				wv_sync();
-				flags = wv_bcast(flags,0);
-				if ( flags ) return false;
+				flags = wv_bcast(flags,0); if ( flags ) return false;
+				nwF = swF; nwR = swR;   // drop the weights of a temporary middle piece
 			}
 		}
-		PROF_T0
+		PROF(*this,12)
+#if defined(DACC_EMUL) && defined(DACC_FSTATS)
+		fstat(8,rctop); fstat(9,np); fstat(10,conso);
+#endif
 		if ( lane == 0 )
 		{
 			uint32_t nch = 0;
-			while ( ncdh ) { HeapCC const c = L.cdh[0]; heap_popvoid<HeapCC,CmpWLess>(L.cdh,ncdh); heap_push<HeapCC,CmpWGreater>(L.ch,nch,c); }
-			while ( nch ) { L.acc[nacc++] = L.ch[0]; heap_popvoid<HeapCC,CmpWGreater>(L.ch,nch); }
+			while ( ncdh ) { FCC const c = L.cdh[0]; spop<FCC,true>(L.cdh,ncdh); spush<FCC,false>(L.ch,nch,c); }
+			while ( nch ) { L.acc[nacc++] = L.ch[0]; spop<FCC,false>(L.ch,nch); }
 		}
 		wv_sync();
 		uint32_t const nc = wv_bcast(nacc,0);
@@ -1086,13 +1341,13 @@ struct FastEngine
 		{
 			for ( uint32_t c = 0; c < nc; ++c )
 			{
-				uint64_t s = 0;
+				uint32_t s = 0;
 				for ( uint32_t j = 0; j < mao; ++j ) s += L.canderr[c*mao+j];
-				L.accerr[c] = static_cast<double>(s);
+				L.accerr[c] = s;
 			}
 			for ( uint32_t i = 1; i < nc; ++i )
 			{
-				HeapCC const v = L.acc[i]; double const e = L.accerr[i];
+				FCC const v = L.acc[i]; uint32_t const e = L.accerr[i];
 				if ( e < L.accerr[0] )
 				{
 					for ( uint32_t q = i; q > 0; --q ) { L.acc[q] = L.acc[q-1]; L.accerr[q] = L.accerr[q-1]; }
@@ -1215,13 +1470,14 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 {
 	WindowBatch const & B = FB.W;
 	FastEngine E;
-	E.C = FB.F; E.T = B.T; E.P = B.P; E.vst = FB.dpsq_vst;
+	E.C = FB.F; E.T = B.T; E.P = B.P;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 	fast_lds_carve(E.L,lds,FB.F);
 	fast_global_carve(E.G,garena,FB.F);
 	FastLds & L = E.L;
 	int const lane = E.lane;
 	PROF_T0
+	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); } return false; }
 
 	uint32_t lo = 0, hi = B.npiles;
 	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
@@ -1233,9 +1489,8 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 	WindowOut out; out.status = WS_INSUFFICIENT; out.mao = 0; out.elength = 0; out.k = 0; out.filterfreq = -1; out.conslen = 0; out.minrate = 0; out.flags = 0;
 	uint8_t * rec = B.wrec + widx*WREC;
 	if ( lane == 0 ) rec[0] = 0;
-	if ( B.P.w > 63 ) return false;
+	if ( B.P.w > 63 ) { FFAIL(1) }
 
-	// active set -> keys in the (still unused) instance buffer
 	DevOvl const * ov = B.ovl + pile.first_ovl;
 	uint32_t nact = 0;
 	for ( uint32_t c = 0; c < pile.novl; c += WSZ )
@@ -1247,7 +1502,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 		if ( act && nact+pre < FB.F.precap ) L.pre[nact+pre] = (static_cast<uint64_t>(ov[z].ekey)<<32) | z;
 		nact += tot;
 	}
-	if ( nact > FB.F.precap ) return false;
+	if ( nact > FB.F.precap ) { FFAIL(2) }
 	uint32_t const ap2 = next_pow2(nact < 2 ? 2 : nact);
 	for ( uint32_t i = nact + lane; i < ap2; i += WSZ ) L.pre[i] = ~0ull;
 	wv_sync();
@@ -1258,7 +1513,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 		uint64_t const nb = (B.P.maxalign > 0) ? (B.P.maxalign-1) : 0;
 		mao = 1 + static_cast<uint32_t>(nact < nb ? nact : nb);
 	}
-	if ( mao > FB.F.maxs ) return false;
+	if ( mao > FB.F.maxs ) { FFAIL(3) }
 	E.mao = mao; out.mao = mao;
 
 	uint32_t toolong = 0;
@@ -1281,7 +1536,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 		}
 	}
 	wv_sync();
-	if ( toolong ) return false;
+	if ( toolong ) { FFAIL(4) }
 	PROF(E,0)
 
 	int32_t elength = 0;
@@ -1289,7 +1544,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 	{
 		E.buildPeq();
 		int32_t const idx = E.estimateLength();
-		if ( idx < 0 ) return false;
+		if ( idx < 0 ) { FFAIL(5) }
 		elength = idx+1;
 	}
 	out.elength = elength;
@@ -1307,7 +1562,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
 			for ( int32_t ff = B.P.maxff; ff >= B.P.minff; --ff )
 			{
-				if ( ff == 0 ) return false; // gap filling: generic engine
+				if ( ff == 0 ) { FFAIL(6) } // gap filling: generic engine
 				PROF_T0
 				E.buildInstances();
 				PROF(E,2)
@@ -1316,21 +1571,21 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 				E.buildSuccessors(mao);
 				PROF(E,4)
 				E.flags = wv_or(E.flags);
-				if ( E.flags ) return false;
+				if ( E.flags ) { FFAIL(7) }
 				uint32_t mintry = 0; bool lconsok = false;
 				while ( true )
 				{
 					bool const consok = E.traverse(static_cast<int64_t>(elength)-4,static_cast<int64_t>(elength)+4);
 					E.flags = wv_or(E.flags);
-					if ( E.flags ) return false;
+					if ( E.flags ) { FFAIL(8) }
 					if ( consok )
 					{
-						uint64_t const err = static_cast<uint64_t>(L.accerr[0]);
+						uint64_t const err = L.accerr[0];
 						if ( err < minrate )
 						{
 							lconsok = true; minrate = err; haveMin = true;
 							bestlen = L.acc[0].l;
-							if ( bestlen > MAXCONS ) return false;
+							if ( bestlen > MAXCONS ) { FFAIL(9) }
 							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = E.G.cons[L.acc[0].o+i];
 							out.k = k; out.filterfreq = ff;
 							wv_sync();
@@ -1359,6 +1614,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 	if ( lane == 0 ) B.wout[widx] = out;
 	wv_sync();
 	return true;
+	#undef FFAIL
 }
 
 }

@@ -17,12 +17,13 @@ for k in (8, 14):
     t0 = time.time(); fr, ba = E(piles[:npiles], ovl, d.trace); t1 = time.time() - t0
     t = E.timing(); pr = E.profile().astype(np.float64)
     w = E.debug_windows()
-    print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms retry=%d" % (
-        k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms, t.nretry))
+    print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms retry=%d fast=%.1fms" % (
+        k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms, t.nretry, t.fast_ms))
     print("  status", dict(zip(*np.unique(w["status"], return_counts=True))), "ff", dict(zip(*np.unique(w["filterfreq"][w["status"] == 1], return_counts=True))), "mean mao %.1f" % w["mao"].mean())
     tot = pr[:15].sum()
     if tot > 0:
         for i, n in enumerate(NAMES):
             print("  %-16s %6.2f%%  %10.0f cyc/window" % (n, 100 * pr[i] / tot, pr[i] / max(1, t.nwindows)))
         print("  total cyc/window %.0f" % (tot / max(1, t.nwindows)))
+        print("  block lifetime: clock64 sum %.3e wall_clock64 sum %.3e (100MHz) max wall %.3f ms; ratio clock/wall %.2f" % (pr[30], pr[31], pr[29]/1e5, pr[30]/max(pr[31],1)))
     E.close()
