@@ -41,7 +41,7 @@ struct BatchPlan
 	uint64_t nwindows, nblocks, nwt, npos, nfragslots, algo_bytes;
 	uint32_t maxdepth, maxcols;
 	ArenaCaps caps;
-	FastCaps fcaps;
+	FastCaps fcaps, fcaps2;   // LDS fast path: small tier (several wavefronts per CU) and large tier (one per CU)
 
 	int plan(dacc_params const & par, dacc_pile const * P, uint64_t const np, dacc_overlap const * O, uint64_t const no,
 		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err,
@@ -149,6 +149,11 @@ struct BatchPlan
 		fcaps.siqcap = 128; fcaps.blcap = 96; fcaps.conscap = 16384 + MAXCONS; fcaps.pad = 0; fcaps.pad2 = 0;
 		fcaps.nrows = tab_nrows; fcaps.nsup = tab_nsup;
 		{ FastLds L; fcaps.ldsbytes = fast_lds_carve(L,0,fcaps); FastGlobal G; fcaps.gbytes = (fast_global_carve(G,0,fcaps)+255)&~255ull; }
+		fcaps2 = fcaps;
+		fcaps2.maxs = std::min<uint32_t>(std::max<uint32_t>(caps.maxs,8),96);
+		fcaps2.precap = 2048; fcaps2.ncap = 1792; fcaps2.scap = 250; fcaps2.lcap = 2048; fcaps2.wcap = 2560; fcaps2.rccap = 512; fcaps2.fcap = 250;
+		fcaps2.siqcap = 200; fcaps2.blcap = 128; fcaps2.conscap = 32768 + MAXCONS;
+		{ FastLds L; fcaps2.ldsbytes = fast_lds_carve(L,0,fcaps2); FastGlobal G; fcaps2.gbytes = (fast_global_carve(G,0,fcaps2)+255)&~255ull; }
 		return DACC_OK;
 	}
 };

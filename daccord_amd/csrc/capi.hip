@@ -73,8 +73,9 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 	}
 }
 
-// LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice
-__global__ void __launch_bounds__(64) k_window_fast(FastBatch FB)
+// LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice.
+// list == 0: all windows; else the windows a smaller capacity tier handed over.  Windows that do not fit go to FB.retry.
+__global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const * list)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint32_t const G = gridDim.x;
@@ -86,18 +87,20 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB)
 #if defined(DACC_PROFILE)
 	uint64_t const t0c = clock64(), t0w = wall_clock64();
 #endif
-	for ( uint64_t base = 0; base < FB.W.nwindows; base += G )
+	uint64_t const n = list ? list[0] : FB.W.nwindows;
+	for ( uint64_t base = 0; base < n; base += G )
 	{
-		uint64_t const w = base + slot;
-		if ( w < FB.W.nwindows )
+		uint64_t const i = base + (list ? b : slot);
+		if ( i < n )
 		{
+			uint64_t const w = list ? list[1+i] : i;
 			bool const done = processWindowFast(FB,w,lds,garena);
-			if ( !done && threadIdx.x == 0 ) { uint32_t const i = atomicAdd(FB.retry,1u); FB.retry[1+i] = static_cast<uint32_t>(w); }
+			if ( !done && threadIdx.x == 0 ) { uint32_t const q = atomicAdd(FB.retry,1u); FB.retry[1+q] = static_cast<uint32_t>(w); }
 			__syncthreads();
 		}
 	}
 #if defined(DACC_PROFILE)
-	if ( threadIdx.x == 0 && FB.W.prof ) { atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+30),static_cast<unsigned long long>(clock64()-t0c)); atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+31),static_cast<unsigned long long>(wall_clock64()-t0w)); atomicMax(reinterpret_cast<unsigned long long *>(FB.W.prof+29),static_cast<unsigned long long>(wall_clock64()-t0w)); }
+	if ( threadIdx.x == 0 && FB.W.prof && !list ) { atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+30),static_cast<unsigned long long>(clock64()-t0c)); atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+31),static_cast<unsigned long long>(wall_clock64()-t0w)); atomicMax(reinterpret_cast<unsigned long long *>(FB.W.prof+29),static_cast<unsigned long long>(wall_clock64()-t0w)); }
 #endif
 }
 
@@ -176,8 +179,8 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint8_t> d_garena; DevBuf<uint32_t> d_retry;
-	uint32_t fast_grid, retry_grid; int usefast; uint32_t nretry_last;
+	DevBuf<uint64_t> d_vst; DevBuf<uint8_t> d_garena, d_garena2; DevBuf<uint32_t> d_retry, d_retry2;
+	uint32_t fast_grid, fast2_grid, retry_grid; int usefast; uint32_t nretry_last, nretry2_last;
 	uint32_t tr_threads, win_grid;
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
@@ -227,7 +230,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_garena.release(); c->d_retry.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_garena.release(); c->d_retry.release(); c->d_garena2.release(); c->d_retry2.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -324,10 +327,15 @@ static int runDevice(dacc_ctx * c)
 		if ( c->usefast )
 		{
 			HIPCHK(hipMemsetAsync(c->d_retry.p,0,sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_retry2.p,0,sizeof(uint32_t),s));
 			FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->d_vst.p; FB.garena = c->d_garena.p; FB.retry = c->d_retry.p;
-			hipLaunchKernelGGL(k_window_fast,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB);
+			hipLaunchKernelGGL(k_window_fast,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB,static_cast<uint32_t const *>(0));
 			hipEventRecord(c->evfast,s);
-			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,c->d_retry.p);
+			// second tier: the windows that overflowed the small LDS layout, one wavefront per CU with a large layout
+			FastBatch FB2 = FB; FB2.F = BP.fcaps2; FB2.garena = c->d_garena2.p; FB2.retry = c->d_retry2.p;
+			hipLaunchKernelGGL(k_window_fast,dim3(c->fast2_grid),dim3(64),BP.fcaps2.ldsbytes,s,FB2,static_cast<uint32_t const *>(c->d_retry.p));
+			// what is left (rare shapes) goes through the generic engine
+			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_retry2.p));
 		}
 		else
 			hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0));
@@ -349,7 +357,8 @@ static int runDevice(dacc_ctx * c)
 	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
 	HIPCHK(hipMemcpyAsync(herr,c->d_err.p,sizeof(herr),hipMemcpyDeviceToHost,s));
 	c->nretry_last = 0;
-	if ( c->usefast && BP.nwindows ) HIPCHK(hipMemcpyAsync(&c->nretry_last,c->d_retry.p,sizeof(uint32_t),hipMemcpyDeviceToHost,s));
+	c->nretry2_last = 0;
+	if ( c->usefast && BP.nwindows ) { HIPCHK(hipMemcpyAsync(&c->nretry_last,c->d_retry.p,sizeof(uint32_t),hipMemcpyDeviceToHost,s)); HIPCHK(hipMemcpyAsync(&c->nretry2_last,c->d_retry2.p,sizeof(uint32_t),hipMemcpyDeviceToHost,s)); }
 	if ( BP.piles.size() )
 	{
 		HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
@@ -381,7 +390,7 @@ static int runDevice(dacc_ctx * c)
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
-	c->timing.nretry = c->nretry_last;
+	c->timing.nretry = c->nretry_last; c->timing.nretry2 = c->nretry2_last;
 	c->timing.nwindows = BP.nwindows; c->timing.nblocks = BP.nblocks; c->timing.algo_bytes = BP.algo_bytes + nbases;
 	return DACC_OK;
 }
@@ -435,13 +444,15 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( percu < 1 ) percu = 1;
 		uint64_t fg = ((BP.nwindows+7)/8)*8;
 		if ( fg > 256*percu ) fg = 256*percu;
-		if ( BP.fcaps.ldsbytes > 64*1024 ) hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast),hipFuncAttributeMaxDynamicSharedMemorySize,BP.fcaps.ldsbytes);
+		{ uint32_t const mx = BP.fcaps.ldsbytes > BP.fcaps2.ldsbytes ? BP.fcaps.ldsbytes : BP.fcaps2.ldsbytes; if ( mx > 160*1024 ) { c->err = "LDS layout exceeds 160 KiB"; return DACC_ENOTSUP; } if ( mx > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast),hipFuncAttributeMaxDynamicSharedMemorySize,mx)); }
 		if ( fg < 8 ) fg = 8;
 		c->fast_grid = fg;
 		c->retry_grid = wg < 512 ? wg : 512;
 		c->win_grid = c->retry_grid;
 		HIPCHK(c->d_garena.ensure(fg*BP.fcaps.gbytes));
-		HIPCHK(c->d_retry.ensure(BP.nwindows+2));
+		c->fast2_grid = fg < 256 ? fg : 256;
+		HIPCHK(c->d_garena2.ensure(static_cast<size_t>(c->fast2_grid)*BP.fcaps2.gbytes));
+		HIPCHK(c->d_retry.ensure(BP.nwindows+2)); HIPCHK(c->d_retry2.ensure(BP.nwindows+2));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));
 	}
 	else

@@ -62,7 +62,7 @@ struct FastLds
 	uint64_t * mfirst; uint64_t * mlast;
 	uint32_t * tab; uint8_t * suplo8; uint8_t * suphi8;
 	// overlay, build phase
-	uint64_t * pre; uint64_t * lastk;
+	uint64_t * pre; uint64_t * lastk; uint64_t * gfbuf; uint32_t gfcap;   // gfbuf: scratch behind the build overlay (gap filling)
 	// overlay, traversal phase
 	uint16_t * sfirst; uint16_t * slast; uint16_t * sslen; uint16_t * slink; uint64_t * maskF; uint64_t * maskR; uint16_t * woffF; uint16_t * woffR;
 	uint16_t * links; uint64_t * wuF; uint64_t * wuR; uint8_t * ord;
@@ -186,6 +186,7 @@ HDEV uint32_t fast_lds_carve(FastLds & L, uint8_t * base, FastCaps const & C)
 	if ( uraw > m ) m = uraw;
 	if ( upool > m ) m = upool;
 	if ( ualn > m ) m = ualn;
+	L.gfbuf = reinterpret_cast<uint64_t *>(base + uA); L.gfcap = static_cast<uint32_t>((m-uA)/8);
 	return static_cast<uint32_t>(m);
 }
 
@@ -429,6 +430,100 @@ struct FastEngine
 		}
 		wv_sync();
 		return true;
+	}
+
+	// ================= gap filling at filter frequency 0 (getLevelSuccessors(2), :1016-1161) =================
+	// feasible position list of node z is implicit: p in [pfrom,pto) with nodeU(z,p) >= 1e-3
+	DEV void levelSuccessors2()
+	{
+		uint32_t const s = 2;
+		uint64_t * REC = L.gfbuf;          // records (from<<48 | to<<32 | cv)
+		uint32_t const cap = L.gfcap/2;    // second half holds the (cv,pos) candidates
+		uint64_t * ANE = L.gfbuf + cap;
+		// pass 1: missing intermediate k-mers between nodes two steps apart
+		uint32_t base = 0;
+		for ( uint32_t c = 0; c < nn; c += WSZ )
+		{
+			uint32_t const i = c + lane;
+			uint32_t cnt = 0; uint32_t lo = 0; uint32_t low = 0, vhigh = 0;
+			if ( i < nn )
+			{
+				uint32_t const v = L.nv[i];
+				low = static_cast<uint32_t>((static_cast<uint64_t>(v)<<(2*s)) & kmask);
+				vhigh = static_cast<uint32_t>((static_cast<uint64_t>(v)<<2) & kmask);
+				lo = lowerNode(low);
+				for ( uint32_t q = lo; q < nn && L.nv[q] <= (low|0xF); ++q )
+					if ( findNode((L.nv[q]>>2)|vhigh) < 0 ) ++cnt;
+			}
+			uint32_t tot; uint32_t const pre = wv_scan_excl(cnt,tot);
+			if ( i < nn && cnt && base+pre+cnt <= cap )
+			{
+				uint32_t o = base+pre;
+				for ( uint32_t q = lo; q < nn && L.nv[q] <= (low|0xF); ++q )
+				{
+					uint32_t const cv = (L.nv[q]>>2)|vhigh;
+					if ( findNode(cv) < 0 ) REC[o++] = (static_cast<uint64_t>(i)<<48) | (static_cast<uint64_t>(q)<<32) | cv;
+				}
+			}
+			base += tot;
+		}
+		uint32_t const nrec = base;
+		if ( nrec > cap ) { over(8192); return; }
+		wv_sync();
+		// pass 2: best common feasible position of `from` (shifted by s) and `to`
+		base = 0;
+		for ( uint32_t c = 0; c < nrec; c += WSZ )
+		{
+			uint32_t const r = c + lane;
+			uint32_t have = 0; uint64_t cand = 0;
+			if ( r < nrec )
+			{
+				uint32_t const from = REC[r]>>48, to = (REC[r]>>32)&0xFFFF; uint32_t const cv = static_cast<uint32_t>(REC[r]);
+				uint64_t mweight = 0; uint32_t mp = 0;
+				// common position pp: from feasible at pp-s, to feasible at pp; ascending pp, strict > keeps the first maximum
+				for ( uint32_t pp = L.pfrom[to]; pp < L.pto[to]; ++pp )
+				{
+					if ( pp < s ) continue;
+					uint32_t const pf = pp-s;
+					if ( pf < L.pfrom[from] || pf >= L.pto[from] ) continue;
+					uint64_t const ua = nodeU(from,pf,false), ub = nodeU(to,pp,false);
+					if ( ua < FW_THRES_FEAS || ub < FW_THRES_FEAS ) continue;
+					uint64_t const weight = ua+ub;
+					if ( !have || weight > mweight ) { have = 1; mweight = weight; mp = pp - s + 1; }
+				}
+				cand = (static_cast<uint64_t>(cv)<<8) | mp;
+			}
+			uint32_t tot; uint32_t const pre = wv_scan_excl(have,tot);
+			if ( have ) ANE[base+pre] = cand;
+			base += tot;
+		}
+		uint32_t const nane = base;
+		uint32_t const p2 = next_pow2(nane < 2 ? 2 : nane);
+		if ( p2 > cap ) { over(8192); return; }
+		for ( uint32_t i = nane + lane; i < p2; i += WSZ ) ANE[i] = ~0ull;
+		wv_sync();
+		wv_bitonic_sort(ANE,p2);       // (v,pos) ascending, NodeAddElement::operator<
+		// pass 3: attach each candidate to the first string that is long enough and append the instance
+		base = 0;
+		for ( uint32_t c = 0; c < nane; c += WSZ )
+		{
+			uint32_t const i = c + lane;
+			uint32_t ok = 0; uint32_t seqid = 0, pos = 0; uint64_t cv = 0;
+			if ( i < nane )
+			{
+				pos = ANE[i]&0xFF; cv = ANE[i]>>8;
+				for ( uint32_t j = 0; j < mao; ++j ) if ( pos + k <= L.slen[j] ) { seqid = j; ok = 1; break; }
+			}
+			uint32_t tot; uint32_t const pre = wv_scan_excl(ok,tot);
+			if ( ok && npre+base+pre < C.precap ) L.pre[npre+base+pre] = (cv<<32) | (static_cast<uint64_t>(pos)<<16) | seqid;
+			base += tot;
+		}
+		if ( npre + base > C.precap ) { over(1); return; }
+		npre += base;
+		uint32_t const q2 = next_pow2(npre < 2 ? 2 : npre);
+		for ( uint32_t i = npre + lane; i < q2; i += WSZ ) L.pre[i] = ~0ull;
+		wv_sync();
+		wv_bitonic_sort(L.pre,q2);
 	}
 
 	// ================= stretches, once per activation state =================
@@ -1562,7 +1657,6 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
 			for ( int32_t ff = B.P.maxff; ff >= B.P.minff; --ff )
 			{
-				if ( ff == 0 ) { FFAIL(6) } // gap filling: generic engine
 				PROF_T0
 				E.buildInstances();
 				PROF(E,2)
@@ -1570,6 +1664,16 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 				PROF(E,3)
 				E.buildSuccessors(mao);
 				PROF(E,4)
+				if ( ff == 0 )
+				{
+					// gap filling (HandleContext.hpp:2233-2268)
+					E.levelSuccessors2();
+					E.flags = wv_or(E.flags);
+					if ( E.flags ) { FFAIL(6) }
+					E.buildNodes(1);
+					E.buildSuccessors(mao);
+					PROF(E,6)
+				}
 				E.flags = wv_or(E.flags);
 				if ( E.flags ) { FFAIL(7) }
 				uint32_t mintry = 0; bool lconsok = false;

@@ -139,8 +139,8 @@ typedef struct dacc_timing {
 	uint64_t nblocks;        /* trace blocks aligned */
 	uint64_t algo_bytes;     /* algorithmic bytes of the batch */
 	uint64_t nretry;         /* windows the LDS fast path handed to the generic engine */
-	float fast_ms;           /* LDS fast-path kernel alone (window_ms = fast + generic re-runs) */
-	float pad;
+	float fast_ms;           /* first-tier LDS kernel alone (window_ms = all tiers) */
+	uint32_t nretry2;        /* windows that also overflowed the second LDS tier (generic engine) */
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 
