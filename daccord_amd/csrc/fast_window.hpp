@@ -1499,7 +1499,39 @@ struct FastEngine
 		}
 		union { double d; uint64_t u; } dm; dm.d = DACC_DBL_MIN;
 		if ( bestbits > dm.u ) maxvprodindex = besti;
-		return maxvprodindex; // -1: the density fallback is left to the generic engine
+		if ( maxvprodindex == -1 )
+		{
+			// density fallback (HandleContext.hpp:2103-2155): histogram of lengths (count-1) against the DPnormSquare rows
+			int32_t res = -1;
+			if ( lane == 0 )
+			{
+				uint32_t maxlen = 0;
+				for ( uint32_t j = 0; j < mao; ++j ) maxlen = L.slen[j] > maxlen ? L.slen[j] : maxlen;
+				int32_t maxoff = -1; double maxoffv = DACC_DBL_MIN;
+				for ( int32_t i = 0; i < T.nrows; ++i )
+				{
+					uint32_t const fs = T.dpsq_first[i], sz = T.dpsq_size[i];
+					double const * V = T.dpsq + static_cast<uint64_t>(i)*T.nsup;
+					double sdot = 0;
+					for ( uint32_t t = 0; t < sz; ++t )
+					{
+						uint32_t const jj = fs+t;
+						if ( jj < maxlen+1 )
+						{
+							uint32_t cnt = 0;
+							for ( uint32_t j = 0; j < mao; ++j ) cnt += (L.slen[j] == jj);
+							double const o = cnt ? static_cast<double>(cnt-1) : 0.0;
+							sdot += V[jj] * o;
+						}
+						else break;
+					}
+					if ( sdot > maxoffv ) { maxoff = i; maxoffv = sdot; }
+				}
+				if ( maxoff != -1 && maxoffv >= 1e-3 ) res = maxoff;
+			}
+			maxvprodindex = static_cast<int32_t>(wv_bcast(static_cast<uint32_t>(res),0));
+		}
+		return maxvprodindex;
 	}
 
 	DEV void alignAndEmit(uint8_t const * cons, uint32_t const n, uint8_t * rec)
@@ -1638,9 +1670,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 	if ( mao )
 	{
 		E.buildPeq();
-		int32_t const idx = E.estimateLength();
-		if ( idx < 0 ) { FFAIL(5) }
-		elength = idx+1;
+		elength = E.estimateLength()+1;
 	}
 	out.elength = elength;
 	PROF(E,1)

@@ -29,7 +29,7 @@ struct EmulCtx
 	std::vector<dacc_window_result> windows;
 	std::string err;
 	bool usefast; uint64_t nfast, nretry, nfast2;
-	uint64_t reasons[64]; uint64_t flagbits[24];
+	uint64_t reasons[64]; uint64_t flagbits[24]; uint64_t reasons2[64]; uint64_t flagbits2[24];
 };
 
 static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
@@ -48,6 +48,7 @@ extern "C" {
 
 void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->nfast = c->nretry = 0; return c; }
 void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
+void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasons2[i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbits2[i]; }
 void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasons[i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbits[i]; }
 void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { *nf = static_cast<EmulCtx *>(v)->nfast; *nr = static_cast<EmulCtx *>(v)->nretry; }
 void emul_counts3(void * v, uint64_t * nf, uint64_t * nf2, uint64_t * nr) { *nf = static_cast<EmulCtx *>(v)->nfast; *nf2 = static_cast<EmulCtx *>(v)->nfast2; *nr = static_cast<EmulCtx *>(v)->nretry; }
@@ -126,7 +127,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->H.dpsq_vst.data(); FB.garena = 0; FB.retry = 0;
 		FastBatch FB2 = FB; FB2.F = BP.fcaps2;
 		std::vector<uint8_t> lds(BP.fcaps.ldsbytes+64), garena(BP.fcaps.gbytes+64), lds2(BP.fcaps2.ldsbytes+64), garena2(BP.fcaps2.gbytes+64);
-		c->nfast = 0; c->nretry = 0; c->nfast2 = 0; for ( int i = 0; i < 64; ++i ) c->reasons[i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbits[i] = 0;
+		c->nfast = 0; c->nretry = 0; c->nfast2 = 0; for ( int i = 0; i < 64; ++i ) { c->reasons[i] = 0; c->reasons2[i] = 0; } for ( int i = 0; i < 24; ++i ) { c->flagbits[i] = 0; c->flagbits2[i] = 0; }
 		{ FastLds L; fast_lds_carve(L,lds.data(),BP.fcaps); fast_load_tables(L,BP.fcaps,T,c->H.dpsq_vst.data()); }
 		{ FastLds L; fast_lds_carve(L,lds2.data(),BP.fcaps2); fast_load_tables(L,BP.fcaps2,T,c->H.dpsq_vst.data()); }
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
@@ -144,6 +145,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			if ( usefast ) { uint32_t const f = wout[wdx].flags; c->reasons[(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbits[b]++; }
 			fast = usefast && processWindowFast(FB2,wdx,lds2.data(),garena2.data());
 			if ( fast ) { ++c->nfast2; continue; }
+			if ( usefast ) { uint32_t const f = wout[wdx].flags; c->reasons2[(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbits2[b]++; }
 			++c->nretry; processWindow(WB,wdx,arena.data());
 		}
 	}
