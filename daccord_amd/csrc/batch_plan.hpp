@@ -143,17 +143,9 @@ struct BatchPlan
 		caps.blcap = 256;
 		caps.conscap = 32768 + MAXCONS;
 		caps.pad = 0; caps.bytes = 0;
-		// LDS fast path capacities (windows beyond them are re-run by the generic engine)
-		fcaps.maxs = std::min<uint32_t>(std::max<uint32_t>(caps.maxs,8),64);
-		fcaps.precap = 1024; fcaps.ncap = 896; fcaps.scap = 232; fcaps.lcap = 1024; fcaps.wcap = 1408; fcaps.rccap = 256; fcaps.fcap = 224;
-		fcaps.siqcap = 128; fcaps.blcap = 96; fcaps.conscap = 16384 + MAXCONS; fcaps.pad = 0; fcaps.pad2 = 0;
-		fcaps.nrows = tab_nrows; fcaps.nsup = tab_nsup;
-		{ FastLds L; fcaps.ldsbytes = fast_lds_carve(L,0,fcaps); FastGlobal G; fcaps.gbytes = (fast_global_carve(G,0,fcaps)+255)&~255ull; }
-		fcaps2 = fcaps;
-		fcaps2.maxs = std::min<uint32_t>(std::max<uint32_t>(caps.maxs,8),96);
-		fcaps2.precap = 2048; fcaps2.ncap = 1792; fcaps2.scap = 250; fcaps2.lcap = 2048; fcaps2.wcap = 2560; fcaps2.rccap = 512; fcaps2.fcap = 250;
-		fcaps2.siqcap = 200; fcaps2.blcap = 128; fcaps2.conscap = 32768 + MAXCONS;
-		{ FastLds L; fcaps2.ldsbytes = fast_lds_carve(L,0,fcaps2); FastGlobal G; fcaps2.gbytes = (fast_global_carve(G,0,fcaps2)+255)&~255ull; }
+		// LDS fast path capacity tiers (compile time, fast_window.hpp); windows beyond them are re-run by the generic engine
+		fcaps = fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
+		fcaps2 = fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup);
 		return DACC_OK;
 	}
 };

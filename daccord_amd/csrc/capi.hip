@@ -75,15 +75,18 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 
 // LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice.
 // list == 0: all windows; else the windows a smaller capacity tier handed over.  Windows that do not fit go to FB.retry.
+template<int TIER>
 __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const * list)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	typedef FastTier<TIER> CT;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
+	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
 	uint32_t const G = gridDim.x;
 	uint32_t const b = blockIdx.x;
 	uint32_t const perx = G >> 3;
 	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
 	uint8_t * garena = FB.garena + static_cast<uint64_t>(b)*FB.F.gbytes;
-	{ FastLds L; fast_lds_carve(L,lds,FB.F); fast_load_tables(L,FB.F,FB.W.T,FB.dpsq_vst); }
+	{ FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
 #if defined(DACC_PROFILE)
 	uint64_t const t0c = clock64(), t0w = wall_clock64();
 #endif
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 		if ( i < n )
 		{
 			uint64_t const w = list ? list[1+i] : i;
-			bool const done = processWindowFast(FB,w,lds,garena);
+			bool const done = processWindowFast<CT>(FB,w,lds,garena);
 			if ( !done && threadIdx.x == 0 ) { uint32_t const q = atomicAdd(FB.retry,1u); FB.retry[1+q] = static_cast<uint32_t>(w); }
 			__syncthreads();
 		}
@@ -329,11 +332,11 @@ static int runDevice(dacc_ctx * c)
 			HIPCHK(hipMemsetAsync(c->d_retry.p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_retry2.p,0,sizeof(uint32_t),s));
 			FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->d_vst.p; FB.garena = c->d_garena.p; FB.retry = c->d_retry.p;
-			hipLaunchKernelGGL(k_window_fast,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB,static_cast<uint32_t const *>(0));
+			hipLaunchKernelGGL(k_window_fast<1>,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB,static_cast<uint32_t const *>(0));
 			hipEventRecord(c->evfast,s);
 			// second tier: the windows that overflowed the small LDS layout, one wavefront per CU with a large layout
 			FastBatch FB2 = FB; FB2.F = BP.fcaps2; FB2.garena = c->d_garena2.p; FB2.retry = c->d_retry2.p;
-			hipLaunchKernelGGL(k_window_fast,dim3(c->fast2_grid),dim3(64),BP.fcaps2.ldsbytes,s,FB2,static_cast<uint32_t const *>(c->d_retry.p));
+			hipLaunchKernelGGL(k_window_fast<2>,dim3(c->fast2_grid),dim3(64),BP.fcaps2.ldsbytes,s,FB2,static_cast<uint32_t const *>(c->d_retry.p));
 			// what is left (rare shapes) goes through the generic engine
 			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_retry2.p));
 		}
@@ -434,7 +437,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		char const * e = getenv("DACC_NOFAST");
 		c->usefast = !(e && e[0] == '1');
 		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
-		if ( c->H.nrows > 64 ) c->usefast = 0;
+		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP ) c->usefast = 0;
 	}
 	if ( c->usefast )
 	{
@@ -444,7 +447,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( percu < 1 ) percu = 1;
 		uint64_t fg = ((BP.nwindows+7)/8)*8;
 		if ( fg > 256*percu ) fg = 256*percu;
-		{ uint32_t const mx = BP.fcaps.ldsbytes > BP.fcaps2.ldsbytes ? BP.fcaps.ldsbytes : BP.fcaps2.ldsbytes; if ( mx > 160*1024 ) { c->err = "LDS layout exceeds 160 KiB"; return DACC_ENOTSUP; } if ( mx > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast),hipFuncAttributeMaxDynamicSharedMemorySize,mx)); }
+		{ uint32_t const mx = BP.fcaps.ldsbytes > BP.fcaps2.ldsbytes ? BP.fcaps.ldsbytes : BP.fcaps2.ldsbytes; if ( mx > 160*1024 ) { c->err = "LDS layout exceeds 160 KiB"; return DACC_ENOTSUP; } if ( BP.fcaps.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.fcaps.ldsbytes)); if ( BP.fcaps2.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.fcaps2.ldsbytes)); }
 		if ( fg < 8 ) fg = 8;
 		c->fast_grid = fg;
 		c->retry_grid = wg < 512 ? wg : 512;

@@ -42,7 +42,9 @@ namespace dacc {
 enum { WS_RETRY = 4 };
 enum { FNC = 48 };          // max first / last k-mer candidates on the fast path
 enum { FNOPAR = 0xFF };
+enum { FSUPCAP = 128 };     // max width (read offsets) of the model table copy in LDS
 
+// run time description of a capacity tier (host planning, launch parameters)
 struct FastCaps
 {
 	uint32_t maxs, precap, ncap, scap, lcap, wcap, rccap, fcap, siqcap, blcap, conscap, pad;
@@ -54,146 +56,154 @@ struct FastCaps
 struct FSI { uint64_t w; uint8_t left, right, current, path; uint32_t pad; };   // ScoreInterval
 struct FCC { uint64_t w; uint32_t o, l; };                                       // ConsensusCandidate
 
+// compile time capacities of the two tiers: every LDS offset below is an instruction immediate
+template<int TIER> struct FastTier;
+template<> struct FastTier<1> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1408, rccap = 256, fcap = 224, siqcap = 128, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<2> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2560, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
+
+HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
+HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+/*
+ * LDS layout of one wavefront.  FLD(name,type,count,start) declares an array at byte offset `start` (a constant
+ * expression), its end offset e_name (8 byte aligned) and an accessor returning an LDS (address space 3) pointer, so
+ * that every access compiles to ds_read/ds_write with a constant offset.
+ */
+#define FLD(name,type,count,start) \
+	static constexpr uint32_t o_##name = (start); \
+	static constexpr uint32_t e_##name = (o_##name + static_cast<uint32_t>(sizeof(type))*static_cast<uint32_t>(count) + 7u) & ~7u; \
+	HDEV LDSQ type * name() const { return reinterpret_cast<LDSQ type *>(base + o_##name); }
+
+template<typename CT>
 struct FastLds
 {
-	uint8_t * str; uint8_t * slen; uint64_t * peq; uint8_t * ipos; uint8_t * irpos;
-	uint32_t * nv; uint16_t * nps; uint8_t * nfreq; uint16_t * succ0; uint16_t * sinfo; uint8_t * npred;
-	uint8_t * pfrom; uint8_t * pto; uint8_t * cpfrom; uint8_t * cpto;
-	uint64_t * mfirst; uint64_t * mlast;
-	uint32_t * tab; uint8_t * suplo8; uint8_t * suphi8;
-	// overlay, build phase
-	uint64_t * pre; uint64_t * lastk; uint64_t * gfbuf; uint32_t gfcap;   // gfbuf: scratch behind the build overlay (gap filling)
-	// overlay, traversal phase
-	uint16_t * sfirst; uint16_t * slast; uint16_t * sslen; uint16_t * slink; uint64_t * maskF; uint64_t * maskR; uint16_t * woffF; uint16_t * woffR;
-	uint16_t * links; uint64_t * wuF; uint64_t * wuR; uint8_t * ord;
-	uint32_t * fkmer; uint32_t * lkmer; uint16_t * fnode; uint16_t * lnode; uint8_t * parF; uint8_t * posF; uint8_t * parL; uint8_t * posL;
-	uint8_t * pieF; uint8_t * pieL;          // first piece id of candidate i (second = +1), FNOPAR if none
+	LDSQ uint8_t * base;
+	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
+	// ---- live during the whole window ----
+	FLD(str,uint8_t,CT::maxs*64,0)
+	FLD(slen,uint8_t,CT::maxs,e_str)
+	FLD(peq,uint64_t,CT::maxs*4,e_slen)
+	FLD(ipos,uint8_t,CT::precap,e_peq)
+	FLD(irpos,uint8_t,CT::precap,e_ipos)
+	FLD(nv,uint32_t,CT::ncap,e_irpos)
+	FLD(nps,uint16_t,CT::ncap+1,e_nv)
+	FLD(nfreq,uint8_t,CT::ncap,e_nps)
+	FLD(succ0,uint16_t,CT::ncap,e_nfreq)
+	FLD(sinfo,uint16_t,CT::ncap,e_succ0)
+	FLD(npred,uint8_t,CT::ncap,e_sinfo)
+	FLD(pfrom,uint8_t,CT::ncap,e_npred)
+	FLD(pto,uint8_t,CT::ncap,e_pfrom)
+	FLD(cpfrom,uint8_t,CT::ncap,e_pto)
+	FLD(cpto,uint8_t,CT::ncap,e_cpfrom)
+	FLD(mfirst,uint64_t,keycap,e_cpto)
+	FLD(mlast,uint64_t,keycap,e_mfirst)
+	FLD(suplo8,uint8_t,FSUPCAP,e_mlast)
+	FLD(suphi8,uint8_t,FSUPCAP,e_suplo8)
+	// small scratch of the serial code (dynamically indexed, so it must not live in registers)
+	FLD(vrem,uint8_t,8,e_suphi8)
+	FLD(vadd,uint8_t,8,e_vrem)
+	FLD(vapos,uint8_t,8,e_vadd)
+	FLD(sstack,uint8_t,3*24,e_vapos)
+	FLD(chain,uint8_t,64,e_sstack)
+	static constexpr uint32_t ubase = e_chain;
+	// ---- overlay A: build phase ----
+	FLD(pre,uint64_t,CT::precap,ubase)
+	FLD(lastk,uint64_t,keycap,e_pre)
+	static constexpr uint32_t uA = e_lastk;
+	// ---- overlay B: traversal phase ----
+	FLD(sfirst,uint16_t,CT::scap,ubase)
+	FLD(slast,uint16_t,CT::scap,e_sfirst)
+	FLD(sslen,uint16_t,CT::scap,e_slast)
+	FLD(slink,uint16_t,CT::scap,e_sslen)
+	FLD(maskF,uint64_t,CT::scap,e_slink)
+	FLD(maskR,uint64_t,CT::scap,e_maskF)
+	FLD(woffF,uint16_t,CT::scap,e_maskR)
+	FLD(woffR,uint16_t,CT::scap,e_woffF)
+	FLD(links,uint16_t,CT::lcap,e_woffR)
+	FLD(wuF,uint64_t,CT::wcap,e_links)
+	FLD(wuR,uint64_t,CT::wcap,e_wuF)
+	FLD(fkmer,uint32_t,FNC,e_wuR)
+	FLD(lkmer,uint32_t,FNC,e_fkmer)
+	FLD(fnode,uint16_t,FNC,e_lkmer)
+	FLD(lnode,uint16_t,FNC,e_fnode)
+	FLD(parF,uint8_t,FNC,e_lnode)
+	FLD(posF,uint8_t,FNC,e_parF)
+	FLD(parL,uint8_t,FNC,e_posF)
+	FLD(posL,uint8_t,FNC,e_parL)
+	FLD(pieF,uint8_t,FNC,e_posL)      // first piece id of candidate i (second = +1), FNOPAR if none
+	FLD(pieL,uint8_t,FNC,e_pieF)
+	FLD(cdh,FCC,16,e_pieL)
+	FLD(ch,FCC,16,e_cdh)
+	FLD(acc,FCC,16,e_ch)
+	FLD(accerr,uint32_t,16,e_acc)
+	FLD(canderr,uint16_t,16*CT::maxs,e_accerr)
+	FLD(prevstr,uint8_t,MAXCONS,e_canderr)
+	FLD(curstr,uint8_t,MAXCONS,e_prevstr)
+	static constexpr uint32_t pbase = e_curstr;
 	// reverse cache
-	uint64_t * rc_w; uint8_t * rc_parent; uint8_t * rc_stretch; uint8_t * rc_pos; uint8_t * rc_len; uint8_t * rc_baselen; uint8_t * rc_ord; uint8_t * rc_arw;
-	uint16_t * rbase; uint8_t * rn; uint8_t * rnpool; uint8_t * rvalid;
+	FLD(rc_w,uint64_t,CT::rccap,pbase)
+	FLD(rc_parent,uint8_t,CT::rccap,e_rc_w)
+	FLD(rc_stretch,uint8_t,CT::rccap,e_rc_parent)
+	FLD(rc_pos,uint8_t,CT::rccap,e_rc_stretch)
+	FLD(rc_len,uint8_t,CT::rccap,e_rc_pos)
+	FLD(rc_baselen,uint8_t,CT::rccap,e_rc_len)
+	FLD(rc_ord,uint8_t,CT::rccap,e_rc_baselen)
+	FLD(rc_arw,uint8_t,CT::rccap,e_rc_ord)
+	FLD(rbase,uint16_t,FNC+1,e_rc_arw)
+	FLD(rn,uint8_t,FNC+1,e_rbase)
+	FLD(rnpool,uint8_t,FNC+1,e_rn)
+	FLD(rvalid,uint8_t,FNC+1,e_rnpool)
+	FLD(rmaxw,uint64_t,FNC+1,e_rvalid)
+	FLD(rtmask,uint64_t,FNC+1,e_rmaxw)
 	// forward pool
-	uint64_t * f_w; uint8_t * f_parent; uint8_t * f_stretch; uint8_t * f_pos; uint8_t * f_baselen; uint8_t * f_len; uint8_t * fpop;
+	FLD(f_w,uint64_t,CT::fcap,e_rtmask)
+	FLD(f_parent,uint8_t,CT::fcap,e_f_w)
+	FLD(f_stretch,uint8_t,CT::fcap,e_f_parent)
+	FLD(f_pos,uint8_t,CT::fcap,e_f_stretch)
+	FLD(f_baselen,uint8_t,CT::fcap,e_f_pos)
+	FLD(f_len,uint8_t,CT::fcap,e_f_baselen)
+	FLD(fpop,uint8_t,CT::fcap,e_f_len)
 	// heaps
-	uint8_t * rpst; uint8_t * hbl; uint8_t * hbl_n; FSI * siq;
-	FCC * cdh; FCC * ch; FCC * acc; uint32_t * accerr; uint16_t * canderr; uint8_t * prevstr; uint8_t * curstr;
+	FLD(rpst,uint8_t,256,e_fpop)
+	FLD(hbl,uint8_t,CT::blcap*12,e_rpst)
+	FLD(hbl_n,uint8_t,CT::blcap,e_hbl)
+	FLD(siq,FSI,CT::siqcap,e_hbl_n)
+	static constexpr uint32_t upool = e_siq;
 	// raw stretches (overlay of the caches)
-	uint16_t * tfirst; uint16_t * tlast; uint16_t * tslen; uint16_t * tlink; uint64_t * skey;
+	FLD(tfirst,uint16_t,CT::scap,pbase)
+	FLD(tlast,uint16_t,CT::scap,e_tfirst)
+	FLD(tslen,uint16_t,CT::scap,e_tlast)
+	FLD(tlink,uint16_t,CT::scap,e_tslen)
+	FLD(skey,uint64_t,fcpow2(CT::scap),e_tlink)
+	static constexpr uint32_t uraw = e_skey;
 	// final alignment (overlay of the caches)
-	uint64_t * alpv; uint64_t * almv; uint16_t * albot; uint8_t * alops;
+	FLD(alpv,uint64_t,MAXCONS+1,pbase)
+	FLD(almv,uint64_t,MAXCONS+1,e_alpv)
+	FLD(albot,uint16_t,MAXCONS+1,e_almv)
+	FLD(alops,uint8_t,2*MAXCONS+2*64+8,e_albot)
+	static constexpr uint32_t ualn = e_alops;
+	static constexpr uint32_t uend = fcmax(fcmax(uA,uraw),fcmax(upool,ualn));
+	// scratch behind the build overlay (gap filling)
+	FLD(gfbuf,uint64_t,(uend-uA)/8,uA)
+	static constexpr uint32_t gfcap = (uend-uA)/8;
+	// fixed-point model table [pos][row], row stride nrows+1 (run time size, hence last)
+	FLD(tab,uint32_t,0,uend)
+	HDEV static uint32_t bytes(uint32_t const nrows, uint32_t const nsup) { return (uend + 4u*(nrows+1)*nsup + 15u) & ~15u; }
 };
+#undef FLD
 
-struct FastGlobal { uint8_t * cons; };
+struct FastGlobal { GLBQ uint8_t * cons; };
 
-#define FCARVE(field,type,count) L.field = reinterpret_cast<type *>(base + o); o = (o + sizeof(type)*static_cast<uint64_t>(count) + 7) & ~static_cast<uint64_t>(7);
-
-HDEV uint32_t fast_lds_carve(FastLds & L, uint8_t * base, FastCaps const & C)
+template<typename CT>
+HDEV FastCaps fastCapsOf(uint32_t const nrows, uint32_t const nsup)
 {
-	uint64_t o = 0;
-	uint32_t const keycap = next_pow2(C.maxs < 2 ? 2 : C.maxs);
-	FCARVE(str,uint8_t,C.maxs*64)
-	FCARVE(slen,uint8_t,C.maxs)
-	FCARVE(peq,uint64_t,C.maxs*4)
-	FCARVE(ipos,uint8_t,C.precap)
-	FCARVE(irpos,uint8_t,C.precap)
-	FCARVE(nv,uint32_t,C.ncap)
-	FCARVE(nps,uint16_t,C.ncap+1)
-	FCARVE(nfreq,uint8_t,C.ncap)
-	FCARVE(succ0,uint16_t,C.ncap)
-	FCARVE(sinfo,uint16_t,C.ncap)
-	FCARVE(npred,uint8_t,C.ncap)
-	FCARVE(pfrom,uint8_t,C.ncap)
-	FCARVE(pto,uint8_t,C.ncap)
-	FCARVE(cpfrom,uint8_t,C.ncap)
-	FCARVE(cpto,uint8_t,C.ncap)
-	FCARVE(mfirst,uint64_t,keycap)
-	FCARVE(mlast,uint64_t,keycap)
-	FCARVE(tab,uint32_t,C.nrows*C.nsup)
-	FCARVE(suplo8,uint8_t,C.nsup)
-	FCARVE(suphi8,uint8_t,C.nsup)
-	uint64_t const ubase = o;
-	FCARVE(pre,uint64_t,C.precap)
-	FCARVE(lastk,uint64_t,keycap)
-	uint64_t const uA = o;
-	o = ubase;
-	FCARVE(sfirst,uint16_t,C.scap)
-	FCARVE(slast,uint16_t,C.scap)
-	FCARVE(sslen,uint16_t,C.scap)
-	FCARVE(slink,uint16_t,C.scap)
-	FCARVE(maskF,uint64_t,C.scap)
-	FCARVE(maskR,uint64_t,C.scap)
-	FCARVE(woffF,uint16_t,C.scap)
-	FCARVE(woffR,uint16_t,C.scap)
-	FCARVE(links,uint16_t,C.lcap)
-	FCARVE(wuF,uint64_t,C.wcap)
-	FCARVE(wuR,uint64_t,C.wcap)
-	FCARVE(ord,uint8_t,C.scap)
-	FCARVE(fkmer,uint32_t,FNC)
-	FCARVE(lkmer,uint32_t,FNC)
-	FCARVE(fnode,uint16_t,FNC)
-	FCARVE(lnode,uint16_t,FNC)
-	FCARVE(parF,uint8_t,FNC)
-	FCARVE(posF,uint8_t,FNC)
-	FCARVE(parL,uint8_t,FNC)
-	FCARVE(posL,uint8_t,FNC)
-	FCARVE(pieF,uint8_t,FNC)
-	FCARVE(pieL,uint8_t,FNC)
-	FCARVE(cdh,FCC,16)
-	FCARVE(ch,FCC,16)
-	FCARVE(acc,FCC,16)
-	FCARVE(accerr,uint32_t,16)
-	FCARVE(canderr,uint16_t,16*C.maxs)
-	FCARVE(prevstr,uint8_t,MAXCONS)
-	FCARVE(curstr,uint8_t,MAXCONS)
-	uint64_t const pbase = o;
-	FCARVE(rc_w,uint64_t,C.rccap)
-	FCARVE(rc_parent,uint8_t,C.rccap)
-	FCARVE(rc_stretch,uint8_t,C.rccap)
-	FCARVE(rc_pos,uint8_t,C.rccap)
-	FCARVE(rc_len,uint8_t,C.rccap)
-	FCARVE(rc_baselen,uint8_t,C.rccap)
-	FCARVE(rc_ord,uint8_t,C.rccap)
-	FCARVE(rc_arw,uint8_t,C.rccap)
-	FCARVE(rbase,uint16_t,FNC+1)
-	FCARVE(rn,uint8_t,FNC+1)
-	FCARVE(rnpool,uint8_t,FNC+1)
-	FCARVE(rvalid,uint8_t,FNC+1)
-	FCARVE(f_w,uint64_t,C.fcap)
-	FCARVE(f_parent,uint8_t,C.fcap)
-	FCARVE(f_stretch,uint8_t,C.fcap)
-	FCARVE(f_pos,uint8_t,C.fcap)
-	FCARVE(f_baselen,uint8_t,C.fcap)
-	FCARVE(f_len,uint8_t,C.fcap)
-	FCARVE(fpop,uint8_t,C.fcap)
-	FCARVE(rpst,uint8_t,256)
-	FCARVE(hbl,uint8_t,C.blcap*12)
-	FCARVE(hbl_n,uint8_t,C.blcap)
-	FCARVE(siq,FSI,C.siqcap)
-	uint64_t const upool = o;
-	o = pbase;
-	FCARVE(tfirst,uint16_t,C.scap)
-	FCARVE(tlast,uint16_t,C.scap)
-	FCARVE(tslen,uint16_t,C.scap)
-	FCARVE(tlink,uint16_t,C.scap)
-	FCARVE(skey,uint64_t,next_pow2(C.scap))
-	uint64_t const uraw = o;
-	o = pbase;
-	FCARVE(alpv,uint64_t,MAXCONS+1)
-	FCARVE(almv,uint64_t,MAXCONS+1)
-	FCARVE(albot,uint16_t,MAXCONS+1)
-	FCARVE(alops,uint8_t,2*MAXCONS+2*64+8)
-	uint64_t const ualn = o;
-	uint64_t m = uA;
-	if ( uraw > m ) m = uraw;
-	if ( upool > m ) m = upool;
-	if ( ualn > m ) m = ualn;
-	L.gfbuf = reinterpret_cast<uint64_t *>(base + uA); L.gfcap = static_cast<uint32_t>((m-uA)/8);
-	return static_cast<uint32_t>(m);
-}
-
-HDEV uint64_t fast_global_carve(FastGlobal & G, uint8_t * base, FastCaps const & C)
-{
-	G.cons = base;
-	return (C.conscap+255)&~255ull;
+	FastCaps C;
+	C.maxs = CT::maxs; C.precap = CT::precap; C.ncap = CT::ncap; C.scap = CT::scap; C.lcap = CT::lcap; C.wcap = CT::wcap; C.rccap = CT::rccap;
+	C.fcap = CT::fcap; C.siqcap = CT::siqcap; C.blcap = CT::blcap; C.conscap = CT::conscap; C.pad = 0; C.pad2 = 0;
+	C.nrows = nrows; C.nsup = nsup;
+	C.ldsbytes = FastLds<CT>::bytes(nrows,nsup);
+	C.gbytes = (static_cast<uint64_t>(CT::conscap)+255)&~255ull;
+	return C;
 }
 
 struct FastBatch
@@ -205,11 +215,17 @@ struct FastBatch
 	uint32_t * retry;           // [0] = count, [1..] = window indices to re-run generically
 };
 
-DEV void fast_load_tables(FastLds & L, FastCaps const & C, DevTables const & T, uint64_t const * vst)
+template<typename CT>
+DEV void fast_load_tables(FastLds<CT> const & L, uint32_t const nrows, uint32_t const nsup, DevTables const & T, uint64_t const * vst)
 {
 	int const lane = wv_lane();
-	for ( uint32_t i = lane; i < C.nrows*C.nsup; i += WSZ ) L.tab[i] = static_cast<uint32_t>(vst[i]);
-	for ( uint32_t i = lane; i < C.nsup; i += WSZ ) { L.suplo8[i] = T.suplo[i]; L.suphi8[i] = T.suphi[i]; }
+	// row stride nrows+1: the extra row is zero so that positions beyond the table can be clamped instead of branched on
+	for ( uint32_t i = lane; i < (nrows+1)*nsup; i += WSZ )
+	{
+		uint32_t const pos = i / (nrows+1), row = i - pos*(nrows+1);
+		L.tab()[i] = row < nrows ? static_cast<uint32_t>(vst[pos*nrows+row]) : 0u;
+	}
+	for ( uint32_t i = lane; i < nsup; i += WSZ ) { L.suplo8()[i] = T.suplo[i]; L.suphi8()[i] = T.suphi[i]; }
 	wv_sync();
 }
 
@@ -217,14 +233,16 @@ DEV void fast_load_tables(FastLds & L, FastCaps const & C, DevTables const & T, 
 #define FW_THRES_01   429496730ull      /* weight > 0.1 and weight >= 0.1 (no integer lies between) */
 #define FW_THRES_05   2147483648ull     /* weight >= 0.5 */
 
+template<typename CT>
 struct FastEngine
 {
-	FastLds L; FastGlobal G; FastCaps C; DevTables T; DevParams P;
+	FastLds<CT> L; FastGlobal G; DevTables T; DevParams P;
+	uint32_t nrows, nsup;
 	int lane; uint32_t flags;
 	uint64_t * prof;
 	uint32_t mao, k; uint64_t kmask;
 	uint32_t npre, nlast, nn, nmfirst, nmlast;
-	uint32_t n0, npool, nlinks, nwF, nwR, nview;
+	uint32_t n0, npool, nlinks, nwF, nwR;
 	uint32_t nF, nL;
 	uint32_t rctop;                      // used entries of the reverse cache
 	uint32_t np, nfpop, nsiq, ncdh, nacc, conso;
@@ -232,8 +250,19 @@ struct FastEngine
 	uint32_t prevlen;
 
 	DEV void over(uint32_t b) { flags |= b; }
+#if defined(DACC_PROFILE) && !defined(DACC_EMUL)
+	DEV void pcount(int id, uint64_t v) { if ( prof ) atomicAdd(reinterpret_cast<unsigned long long *>(prof+id),static_cast<unsigned long long>(v)); }
+	DEV uint64_t pclock() { return clock64(); }
+#else
+	DEV void pcount(int, uint64_t) {}
+	DEV uint64_t pclock() { return 0; }
+#endif
 #if defined(DACC_EMUL) && defined(DACC_FSTATS)
 	void fstat(int i, uint32_t v) { extern uint32_t g_fstat[16]; if ( v > g_fstat[i] ) g_fstat[i] = v; }
+	void fstatadd(int i, uint32_t v) { extern uint32_t g_fstat[16]; g_fstat[i] += v; }
+#else
+	DEV void fstat(int, uint32_t) {}
+	DEV void fstatadd(int, uint32_t) {}
 #endif
 
 	DEV int32_t findNode(uint32_t const v) const
@@ -242,7 +271,7 @@ struct FastEngine
 		while ( lo <= hi )
 		{
 			int32_t const mid = (lo+hi)>>1;
-			uint32_t const x = L.nv[mid];
+			uint32_t const x = L.nv()[mid];
 			if ( x == v ) return mid;
 			if ( x < v ) lo = mid+1; else hi = mid-1;
 		}
@@ -251,56 +280,56 @@ struct FastEngine
 	DEV uint32_t lowerNode(uint32_t const v) const
 	{
 		uint32_t lo = 0, hi = nn;
-		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.nv[mid] < v ) lo = mid+1; else hi = mid; }
+		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.nv()[mid] < v ) lo = mid+1; else hi = mid; }
 		return lo;
 	}
 	DEV int32_t succNode(uint32_t const z, uint32_t const i) const
 	{
-		uint32_t const sym = (L.sinfo[z]>>(2*i))&3;
-		uint32_t const target = static_cast<uint32_t>((static_cast<uint64_t>(L.nv[z])<<2) & kmask) | sym;
-		for ( uint32_t q = L.succ0[z]; q < nn; ++q )
+		uint32_t const sym = (L.sinfo()[z]>>(2*i))&3;
+		uint32_t const target = static_cast<uint32_t>((static_cast<uint64_t>(L.nv()[z])<<2) & kmask) | sym;
+		for ( uint32_t q = L.succ0()[z]; q < nn; ++q )
 		{
-			uint32_t const x = L.nv[q];
+			uint32_t const x = L.nv()[q];
 			if ( x == target ) return q;
 			if ( x > target ) break;
 		}
 		return -1;
 	}
-	DEV uint32_t nsucc(uint32_t z) const { return (L.sinfo[z]>>8)&7; }
-	DEV uint32_t nsuccact(uint32_t z) const { return (L.sinfo[z]>>11)&7; }
+	DEV uint32_t nsucc(uint32_t z) const { return (L.sinfo()[z]>>8)&7; }
+	DEV uint32_t nsuccact(uint32_t z) const { return (L.sinfo()[z]>>11)&7; }
 
 	// ================= build: instances, nodes, successors =================
 	DEV void buildInstances()
 	{
 		uint32_t base = 0;
-		for ( uint32_t j = 0; j < mao; ++j ) { uint32_t const len = L.slen[j]; base += (len >= k) ? (len-k+1) : 0; }
+		for ( uint32_t j = 0; j < mao; ++j ) { uint32_t const len = L.slen()[j]; base += (len >= k) ? (len-k+1) : 0; }
 		npre = base;
-		if ( npre > C.precap ) { over(1); npre = 0; return; }
+		if ( npre > CT::precap ) { over(1); npre = 0; return; }
 		uint32_t o = 0, lo = 0;
 		for ( uint32_t j = 0; j < mao; ++j )
 		{
-			uint32_t const len = L.slen[j];
+			uint32_t const len = L.slen()[j];
 			if ( len < k ) continue;
 			uint32_t const numk = len-k+1;
-			uint8_t const * s = L.str + j*64;
+			LDSQ uint8_t const * s = L.str() + j*64;
 			for ( uint32_t i = lane; i < numk; i += WSZ )
 			{
 				uint64_t v = 0;
 				for ( uint32_t q = 0; q < k; ++q ) v = (v<<2) | s[i+q];
 				uint64_t const word = (v<<32) | (static_cast<uint64_t>(i)<<16) | j;
-				L.pre[o+i] = word;
-				if ( i == numk-1 ) L.lastk[lo] = word;
+				L.pre()[o+i] = word;
+				if ( i == numk-1 ) L.lastk()[lo] = word;
 			}
 			o += numk; ++lo;
 		}
 		nlast = lo;
 		uint32_t const lp2 = next_pow2(nlast < 2 ? 2 : nlast);
-		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk[i] = ~0ull;
+		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk()[i] = ~0ull;
 		uint32_t const p2 = next_pow2(npre < 2 ? 2 : npre);
-		for ( uint32_t i = npre + lane; i < p2; i += WSZ ) L.pre[i] = ~0ull;
+		for ( uint32_t i = npre + lane; i < p2; i += WSZ ) L.pre()[i] = ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.lastk,lp2);
-		wv_bitonic_sort(L.pre,p2);
+		wv_bitonic_sort(L.lastk(),lp2);
+		wv_bitonic_sort(L.pre(),p2);
 	}
 
 	DEV void buildNodes(uint32_t const f)
@@ -310,76 +339,76 @@ struct FastEngine
 		{
 			uint32_t const i = c + lane;
 			uint32_t keep = 0, e = i;
-			if ( i < npre && (i == 0 || (L.pre[i]>>32) != (L.pre[i-1]>>32)) )
+			if ( i < npre && (i == 0 || (L.pre()[i]>>32) != (L.pre()[i-1]>>32)) )
 			{
-				uint64_t const km = L.pre[i]>>32;
+				uint64_t const km = L.pre()[i]>>32;
 				e = i+1;
-				while ( e < npre && (L.pre[e]>>32) == km ) ++e;
+				while ( e < npre && (L.pre()[e]>>32) == km ) ++e;
 				keep = (e-i) >= f;
 			}
 			uint32_t tot; uint32_t const pre = wv_scan_excl(keep,tot);
 			if ( keep )
 			{
 				uint32_t const z = base+pre;
-				if ( z < C.ncap ) { L.nv[z] = static_cast<uint32_t>(L.pre[i]>>32); L.nps[z] = i; L.nfreq[z] = (e-i) > 255 ? 255 : (e-i); if ( (e-i) > 255 ) over(2); }
+				if ( z < CT::ncap ) { L.nv()[z] = static_cast<uint32_t>(L.pre()[i]>>32); L.nps()[z] = i; L.nfreq()[z] = (e-i) > 255 ? 255 : (e-i); if ( (e-i) > 255 ) over(2); }
 			}
 			base += tot;
 		}
 		nn = base;
-		if ( nn > C.ncap ) { over(2); nn = 0; }
+		if ( nn > CT::ncap ) { over(2); nn = 0; }
 		for ( uint32_t i = lane; i < npre; i += WSZ )
 		{
-			uint32_t const pos = (L.pre[i]>>16)&0xFFFF, seq = L.pre[i]&0xFFFF;
-			L.ipos[i] = pos; L.irpos[i] = L.slen[seq]-pos-k;
+			uint32_t const pos = (L.pre()[i]>>16)&0xFFFF, seq = L.pre()[i]&0xFFFF;
+			L.ipos()[i] = pos; L.irpos()[i] = L.slen()[seq]-pos-k;
 		}
 		wv_sync();
-		if ( lane == 0 ) L.nps[nn] = npre;
+		if ( lane == 0 ) L.nps()[nn] = npre;
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
-			uint32_t const s0 = L.nps[z], f2 = L.nfreq[z];
-			uint32_t const lo = L.ipos[s0], hi = L.ipos[s0+f2-1];
+			uint32_t const s0 = L.nps()[z], f2 = L.nfreq()[z];
+			uint32_t const lo = L.ipos()[s0], hi = L.ipos()[s0+f2-1];
 			uint32_t rlo = 255, rhi = 0;
-			for ( uint32_t q = 0; q < f2; ++q ) { uint32_t const r = L.irpos[s0+q]; rlo = r < rlo ? r : rlo; rhi = r > rhi ? r : rhi; }
-			L.pfrom[z] = lo < C.nsup ? L.suplo8[lo] : C.nrows;
-			L.pto[z] = hi < C.nsup ? L.suphi8[hi] : C.nrows;
-			L.cpfrom[z] = rlo < C.nsup ? L.suplo8[rlo] : C.nrows;
-			L.cpto[z] = rhi < C.nsup ? L.suphi8[rhi] : C.nrows;
+			for ( uint32_t q = 0; q < f2; ++q ) { uint32_t const r = L.irpos()[s0+q]; rlo = r < rlo ? r : rlo; rhi = r > rhi ? r : rhi; }
+			L.pfrom()[z] = lo < nsup ? L.suplo8()[lo] : nrows;
+			L.pto()[z] = hi < nsup ? L.suphi8()[hi] : nrows;
+			L.cpfrom()[z] = rlo < nsup ? L.suplo8()[rlo] : nrows;
+			L.cpto()[z] = rhi < nsup ? L.suphi8()[rhi] : nrows;
 		}
-		uint32_t const kp2 = next_pow2(C.maxs < 2 ? 2 : C.maxs);
+		uint32_t const kp2 = next_pow2(CT::maxs < 2 ? 2 : CT::maxs);
 		base = 0;
 		for ( uint32_t c = 0; c < nn; c += WSZ )
 		{
 			uint32_t const z = c + lane;
 			uint32_t c0 = 0;
-			if ( z < nn ) { uint32_t const s = L.nps[z]; for ( uint32_t q = 0; q < L.nfreq[z] && L.ipos[s+q] == 0; ++q ) ++c0; }
+			if ( z < nn ) { uint32_t const s = L.nps()[z]; for ( uint32_t q = 0; q < L.nfreq()[z] && L.ipos()[s+q] == 0; ++q ) ++c0; }
 			uint32_t tot; uint32_t const pre = wv_scan_excl(c0 ? 1 : 0,tot);
-			if ( c0 && base+pre < kp2 ) L.mfirst[base+pre] = ~((static_cast<uint64_t>(c0)<<32) | L.nv[z]);
+			if ( c0 && base+pre < kp2 ) L.mfirst()[base+pre] = ~((static_cast<uint64_t>(c0)<<32) | L.nv()[z]);
 			base += tot;
 		}
 		nmfirst = base;
 		if ( nmfirst > kp2 ) { over(8); nmfirst = 0; }
 		uint32_t const p2 = next_pow2(nmfirst < 2 ? 2 : nmfirst);
-		for ( uint32_t i = nmfirst + lane; i < p2; i += WSZ ) L.mfirst[i] = ~0ull;
+		for ( uint32_t i = nmfirst + lane; i < p2; i += WSZ ) L.mfirst()[i] = ~0ull;
 		base = 0;
 		for ( uint32_t c = 0; c < nlast; c += WSZ )
 		{
 			uint32_t const i = c + lane;
-			uint32_t const head = (i < nlast) && (i == 0 || (L.lastk[i]>>32) != (L.lastk[i-1]>>32));
+			uint32_t const head = (i < nlast) && (i == 0 || (L.lastk()[i]>>32) != (L.lastk()[i-1]>>32));
 			uint32_t tot; uint32_t const pre = wv_scan_excl(head,tot);
 			if ( head )
 			{
 				uint32_t e = i+1;
-				while ( e < nlast && (L.lastk[e]>>32) == (L.lastk[i]>>32) ) ++e;
-				L.mlast[base+pre] = ~((static_cast<uint64_t>(e-i)<<32) | (L.lastk[i]>>32));
+				while ( e < nlast && (L.lastk()[e]>>32) == (L.lastk()[i]>>32) ) ++e;
+				L.mlast()[base+pre] = ~((static_cast<uint64_t>(e-i)<<32) | (L.lastk()[i]>>32));
 			}
 			base += tot;
 		}
 		nmlast = base;
 		uint32_t const q2 = next_pow2(nmlast < 2 ? 2 : nmlast);
-		for ( uint32_t i = nmlast + lane; i < q2; i += WSZ ) L.mlast[i] = ~0ull;
+		for ( uint32_t i = nmlast + lane; i < q2; i += WSZ ) L.mlast()[i] = ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.mfirst,p2);
-		wv_bitonic_sort(L.mlast,q2);
+		wv_bitonic_sort(L.mfirst(),p2);
+		wv_bitonic_sort(L.mlast(),q2);
 	}
 
 	DEV void buildSuccessors(uint32_t const no)
@@ -387,27 +416,31 @@ struct FastEngine
 		uint32_t const lim = T.klim[(k-P.klow)*T.kln + (no < static_cast<uint32_t>(T.kln) ? no : T.kln-1)];
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
-			uint32_t const masked = static_cast<uint32_t>((static_cast<uint64_t>(L.nv[z])<<2) & kmask);
+			uint32_t const masked = static_cast<uint32_t>((static_cast<uint64_t>(L.nv()[z])<<2) & kmask);
 			uint32_t const s0 = lowerNode(masked);
-			uint32_t Lk[4]; uint32_t n = 0;
-			for ( uint32_t q = s0; q < nn && L.nv[q] <= (masked|3); ++q )
-				Lk[n++] = (static_cast<uint32_t>(L.nfreq[q])<<8) | (L.nv[q]&3);
-			for ( uint32_t a = 1; a < n; ++a )
+			// up to four successors (freq<<8 | symbol), absent = 0; sorted descending by a fixed network (keys are distinct)
+			uint32_t k0 = 0, k1 = 0, k2 = 0, k3 = 0, n = 0;
+			for ( uint32_t q = s0; q < nn && L.nv()[q] <= (masked|3); ++q )
 			{
-				uint32_t const kv = Lk[a]; int32_t b = a;
-				while ( b > 0 && Lk[b-1] < kv ) { Lk[b] = Lk[b-1]; --b; }
-				Lk[b] = kv;
+				uint32_t const kv = (static_cast<uint32_t>(L.nfreq()[q])<<8) | (L.nv()[q]&3);
+				if ( n == 0 ) k0 = kv; else if ( n == 1 ) k1 = kv; else if ( n == 2 ) k2 = kv; else k3 = kv;
+				++n;
 			}
+			#define DACC_CX(a,b) { uint32_t const hi_ = a > b ? a : b, lo_ = a > b ? b : a; a = hi_; b = lo_; }
+			DACC_CX(k0,k1) DACC_CX(k2,k3) DACC_CX(k0,k2) DACC_CX(k1,k3) DACC_CX(k1,k2)
+			#undef DACC_CX
 			uint32_t act = 0;
 			if ( n )
 			{
-				act = 1;
-				while ( act < n && ( ((Lk[act]>>8) >= (Lk[0]>>8)/2) || (P.checklim && ((Lk[act]>>8) >= lim)) ) ) ++act;
+				uint32_t const half = (k0>>8)/2;
+				bool const a1 = n > 1 && ( ((k1>>8) >= half) || (P.checklim && ((k1>>8) >= lim)) );
+				bool const a2 = n > 2 && ( ((k2>>8) >= half) || (P.checklim && ((k2>>8) >= lim)) );
+				bool const a3 = n > 3 && ( ((k3>>8) >= half) || (P.checklim && ((k3>>8) >= lim)) );
+				act = 1 + (a1 ? (1 + (a2 ? (1 + (a3 ? 1 : 0)) : 0)) : 0);
 			}
-			uint32_t order = 0;
-			for ( uint32_t a = 0; a < n; ++a ) order |= (Lk[a]&3) << (2*a);
-			L.succ0[z] = s0;
-			L.sinfo[z] = order | (n<<8) | (act<<11);
+			uint32_t const order = (k0&3) | ((k1&3)<<2) | ((k2&3)<<4) | ((k3&3)<<6);
+			L.succ0()[z] = s0;
+			L.sinfo()[z] = order | (n<<8) | (act<<11);
 		}
 		wv_sync();
 	}
@@ -417,7 +450,7 @@ struct FastEngine
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 			if ( nsuccact(z) < nsucc(z) )
 			{
-				uint32_t const fq = L.nfreq[succNode(z,nsuccact(z))];
+				uint32_t const fq = L.nfreq()[succNode(z,nsuccact(z))];
 				best = fq > best ? fq : best;
 			}
 		best = wv_max(best);
@@ -425,8 +458,8 @@ struct FastEngine
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
 			uint32_t a = nsuccact(z); uint32_t const n = nsucc(z);
-			while ( a < n && L.nfreq[succNode(z,a)] == best ) ++a;
-			L.sinfo[z] = (L.sinfo[z] & 0x7FF) | (a<<11);
+			while ( a < n && L.nfreq()[succNode(z,a)] == best ) ++a;
+			L.sinfo()[z] = (L.sinfo()[z] & 0x7FF) | (a<<11);
 		}
 		wv_sync();
 		return true;
@@ -437,9 +470,9 @@ struct FastEngine
 	DEV void levelSuccessors2()
 	{
 		uint32_t const s = 2;
-		uint64_t * REC = L.gfbuf;          // records (from<<48 | to<<32 | cv)
-		uint32_t const cap = L.gfcap/2;    // second half holds the (cv,pos) candidates
-		uint64_t * ANE = L.gfbuf + cap;
+		LDSQ uint64_t * REC = L.gfbuf();          // records (from<<48 | to<<32 | cv)
+		uint32_t const cap = FastLds<CT>::gfcap/2;    // second half holds the (cv,pos) candidates
+		LDSQ uint64_t * ANE = L.gfbuf() + cap;
 		// pass 1: missing intermediate k-mers between nodes two steps apart
 		uint32_t base = 0;
 		for ( uint32_t c = 0; c < nn; c += WSZ )
@@ -448,20 +481,20 @@ struct FastEngine
 			uint32_t cnt = 0; uint32_t lo = 0; uint32_t low = 0, vhigh = 0;
 			if ( i < nn )
 			{
-				uint32_t const v = L.nv[i];
+				uint32_t const v = L.nv()[i];
 				low = static_cast<uint32_t>((static_cast<uint64_t>(v)<<(2*s)) & kmask);
 				vhigh = static_cast<uint32_t>((static_cast<uint64_t>(v)<<2) & kmask);
 				lo = lowerNode(low);
-				for ( uint32_t q = lo; q < nn && L.nv[q] <= (low|0xF); ++q )
-					if ( findNode((L.nv[q]>>2)|vhigh) < 0 ) ++cnt;
+				for ( uint32_t q = lo; q < nn && L.nv()[q] <= (low|0xF); ++q )
+					if ( findNode((L.nv()[q]>>2)|vhigh) < 0 ) ++cnt;
 			}
 			uint32_t tot; uint32_t const pre = wv_scan_excl(cnt,tot);
 			if ( i < nn && cnt && base+pre+cnt <= cap )
 			{
 				uint32_t o = base+pre;
-				for ( uint32_t q = lo; q < nn && L.nv[q] <= (low|0xF); ++q )
+				for ( uint32_t q = lo; q < nn && L.nv()[q] <= (low|0xF); ++q )
 				{
-					uint32_t const cv = (L.nv[q]>>2)|vhigh;
+					uint32_t const cv = (L.nv()[q]>>2)|vhigh;
 					if ( findNode(cv) < 0 ) REC[o++] = (static_cast<uint64_t>(i)<<48) | (static_cast<uint64_t>(q)<<32) | cv;
 				}
 			}
@@ -481,11 +514,11 @@ struct FastEngine
 				uint32_t const from = REC[r]>>48, to = (REC[r]>>32)&0xFFFF; uint32_t const cv = static_cast<uint32_t>(REC[r]);
 				uint64_t mweight = 0; uint32_t mp = 0;
 				// common position pp: from feasible at pp-s, to feasible at pp; ascending pp, strict > keeps the first maximum
-				for ( uint32_t pp = L.pfrom[to]; pp < L.pto[to]; ++pp )
+				for ( uint32_t pp = L.pfrom()[to]; pp < L.pto()[to]; ++pp )
 				{
 					if ( pp < s ) continue;
 					uint32_t const pf = pp-s;
-					if ( pf < L.pfrom[from] || pf >= L.pto[from] ) continue;
+					if ( pf < L.pfrom()[from] || pf >= L.pto()[from] ) continue;
 					uint64_t const ua = nodeU(from,pf,false), ub = nodeU(to,pp,false);
 					if ( ua < FW_THRES_FEAS || ub < FW_THRES_FEAS ) continue;
 					uint64_t const weight = ua+ub;
@@ -512,18 +545,18 @@ struct FastEngine
 			if ( i < nane )
 			{
 				pos = ANE[i]&0xFF; cv = ANE[i]>>8;
-				for ( uint32_t j = 0; j < mao; ++j ) if ( pos + k <= L.slen[j] ) { seqid = j; ok = 1; break; }
+				for ( uint32_t j = 0; j < mao; ++j ) if ( pos + k <= L.slen()[j] ) { seqid = j; ok = 1; break; }
 			}
 			uint32_t tot; uint32_t const pre = wv_scan_excl(ok,tot);
-			if ( ok && npre+base+pre < C.precap ) L.pre[npre+base+pre] = (cv<<32) | (static_cast<uint64_t>(pos)<<16) | seqid;
+			if ( ok && npre+base+pre < CT::precap ) L.pre()[npre+base+pre] = (cv<<32) | (static_cast<uint64_t>(pos)<<16) | seqid;
 			base += tot;
 		}
-		if ( npre + base > C.precap ) { over(1); return; }
+		if ( npre + base > CT::precap ) { over(1); return; }
 		npre += base;
 		uint32_t const q2 = next_pow2(npre < 2 ? 2 : npre);
-		for ( uint32_t i = npre + lane; i < q2; i += WSZ ) L.pre[i] = ~0ull;
+		for ( uint32_t i = npre + lane; i < q2; i += WSZ ) L.pre()[i] = ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.pre,q2);
+		wv_bitonic_sort(L.pre(),q2);
 	}
 
 	// ================= stretches, once per activation state =================
@@ -532,7 +565,7 @@ struct FastEngine
 		uint32_t const shift = 2*(k-1);
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
-			uint32_t const v = L.nv[z];
+			uint32_t const v = L.nv()[z];
 			uint32_t const masked = v>>2, sym = v&3;
 			uint32_t cnt = 0;
 			for ( uint32_t s = 0; s < 4; ++s )
@@ -540,21 +573,21 @@ struct FastEngine
 				int32_t const u = findNode(masked | (s<<shift));
 				if ( u >= 0 )
 				{
-					uint32_t const info = L.sinfo[u]; uint32_t const na = (info>>11)&7;
+					uint32_t const info = L.sinfo()[u]; uint32_t const na = (info>>11)&7;
 					for ( uint32_t i = 0; i < na; ++i ) if ( ((info>>(2*i))&3) == sym ) { ++cnt; break; }
 				}
 			}
-			L.npred[z] = cnt;
+			L.npred()[z] = cnt;
 		}
 		wv_sync();
 	}
-	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, uint16_t * out, uint32_t & lastnode)
+	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, LDSQ uint16_t * out, uint32_t & lastnode)
 	{
 		int32_t cur = succNode(z,i);
 		uint32_t len = 2;
 		if ( out ) { out[0] = z; out[1] = cur; }
 		bool loop = (cur == static_cast<int32_t>(z));
-		while ( !loop && nsuccact(cur) == 1 && L.npred[cur] == 1 )
+		while ( !loop && nsuccact(cur) == 1 && L.npred()[cur] == 1 )
 		{
 			cur = succNode(cur,0);
 			if ( out ) out[len] = cur;
@@ -570,7 +603,7 @@ struct FastEngine
 	{
 		return (static_cast<uint64_t>(first)<<42) | (static_cast<uint64_t>(ext)<<28) | (static_cast<uint64_t>(0x3FFF-len)<<14) | last;
 	}
-	DEV uint64_t poolKey(uint32_t const s) const { return sortKey(L.sfirst[s],L.links[L.slink[s]+1],L.sslen[s],L.slast[s]); }
+	DEV uint64_t poolKey(uint32_t const s) const { return sortKey(L.sfirst()[s],L.links()[L.slink()[s]+1],L.sslen()[s],L.slast()[s]); }
 
 	// raw stretches of the current activation state, sorted by Stretch::operator< (pool ids 0..n0-1)
 	DEV void computeBaseStretches()
@@ -581,43 +614,43 @@ struct FastEngine
 		{
 			uint32_t const z = c + lane;
 			uint32_t cnt = 0;
-			if ( z < nn ) { uint32_t const ns = nsuccact(z); if ( ns && (L.npred[z] != 1 || ns > 1) ) cnt = ns; }
+			if ( z < nn ) { uint32_t const ns = nsuccact(z); if ( ns && (L.npred()[z] != 1 || ns > 1) ) cnt = ns; }
 			uint32_t tot; uint32_t const pre = wv_scan_excl(cnt,tot);
-			if ( base+pre+cnt <= C.scap )
-				for ( uint32_t i = 0; i < cnt; ++i ) { L.tfirst[base+pre+i] = z; L.tlast[base+pre+i] = i; }
+			if ( base+pre+cnt <= CT::scap )
+				for ( uint32_t i = 0; i < cnt; ++i ) { L.tfirst()[base+pre+i] = z; L.tlast()[base+pre+i] = i; }
 			base += tot;
 		}
 		uint32_t const ns = base;
-		if ( ns + 2 > C.scap || ns > 250 || nn >= 0x3FFF ) { over(32); n0 = 0; return; }
+		if ( ns + 2 > CT::scap || ns > 250 || nn >= 0x3FFF ) { over(32); n0 = 0; return; }
 		wv_sync();
-		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; L.tslen[q] = walkStretch(L.tfirst[q],L.tlast[q],0,ln); }
+		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; L.tslen()[q] = walkStretch(L.tfirst()[q],L.tlast()[q],0,ln); }
 		wv_sync();
 		base = 0;
 		for ( uint32_t c = 0; c < ns; c += WSZ )
 		{
 			uint32_t const q = c + lane;
-			uint32_t const len = q < ns ? L.tslen[q] : 0;
+			uint32_t const len = q < ns ? L.tslen()[q] : 0;
 			uint32_t tot; uint32_t const pre = wv_scan_excl(len,tot);
-			if ( q < ns ) L.tlink[q] = base+pre;
+			if ( q < ns ) L.tlink()[q] = base+pre;
 			base += tot;
 		}
 		nlinks = base;
-		if ( nlinks > C.lcap ) { over(64); n0 = 0; return; }
+		if ( nlinks > CT::lcap ) { over(64); n0 = 0; return; }
 		wv_sync();
-		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; walkStretch(L.tfirst[q],L.tlast[q],L.links+L.tlink[q],ln); L.tlast[q] = ln; }
+		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; walkStretch(L.tfirst()[q],L.tlast()[q],L.links()+L.tlink()[q],ln); L.tlast()[q] = ln; }
 		wv_sync();
 		uint32_t const p2 = next_pow2(ns < 2 ? 2 : ns);
 		for ( uint32_t q = lane; q < p2; q += WSZ )
-			L.skey[q] = q < ns ? ((sortKey(L.tfirst[q],L.links[L.tlink[q]+1],L.tslen[q],L.tlast[q])<<8) | q) : ~0ull;
+			L.skey()[q] = q < ns ? ((sortKey(L.tfirst()[q],L.links()[L.tlink()[q]+1],L.tslen()[q],L.tlast()[q])<<8) | q) : ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.skey,p2);
+		wv_bitonic_sort(L.skey(),p2);
 		// distinct (first,ext) by construction; a duplicate would need stretchesUnique's tie handling -> generic engine
 		uint32_t dup = 0;
 		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
-			if ( q && (L.skey[q]>>36) == (L.skey[q-1]>>36) ) dup = 1;
-			uint32_t const raw = L.skey[q]&0xFF;
-			L.sfirst[q] = L.tfirst[raw]; L.slast[q] = L.tlast[raw]; L.sslen[q] = L.tslen[raw]; L.slink[q] = L.tlink[raw];
+			if ( q && (L.skey()[q]>>36) == (L.skey()[q-1]>>36) ) dup = 1;
+			uint32_t const raw = L.skey()[q]&0xFF;
+			L.sfirst()[q] = L.tfirst()[raw]; L.slast()[q] = L.tlast()[raw]; L.sslen()[q] = L.tslen()[raw]; L.slink()[q] = L.tlink()[raw];
 		}
 		if ( wv_any(dup) ) { over(32); n0 = 0; return; }
 		n0 = ns;
@@ -627,62 +660,64 @@ struct FastEngine
 	// pool stretch id = nodes [a,b] of parent stretch par
 	DEV void makePiece(uint32_t const id, uint32_t const par, uint32_t const a, uint32_t const b)
 	{
-		uint16_t const * Lk = L.links + L.slink[par];
-		L.sfirst[id] = Lk[a]; L.slast[id] = Lk[b]; L.sslen[id] = b-a+1; L.slink[id] = L.slink[par]+a;
+		LDSQ uint16_t const * Lk = L.links() + L.slink()[par];
+		L.sfirst()[id] = Lk[a]; L.slast()[id] = Lk[b]; L.sslen()[id] = b-a+1; L.slink()[id] = L.slink()[par]+a;
 	}
 	// candidates + the pool stretch each one splits (splitStretches :2772-2841: first occurrence strictly inside)
 	DEV void findCandidatesAndPieces()
 	{
-		uint32_t const firstthres = nmfirst ? ((static_cast<uint32_t>((~L.mfirst[0])>>32))*3)/4 : 0;
-		uint32_t const lastthres = nmlast ? ((static_cast<uint32_t>((~L.mlast[0])>>32))*3)/4 : 0;
+		uint32_t const firstthres = nmfirst ? ((static_cast<uint32_t>((~L.mfirst()[0])>>32))*3)/4 : 0;
+		uint32_t const lastthres = nmlast ? ((static_cast<uint32_t>((~L.mlast()[0])>>32))*3)/4 : 0;
 		uint32_t cf = 0, cl = 0;
-		while ( cf < nmfirst && static_cast<uint32_t>((~L.mfirst[cf])>>32) >= firstthres ) ++cf;
-		while ( cl < nmlast && static_cast<uint32_t>((~L.mlast[cl])>>32) >= lastthres ) ++cl;
+		while ( cf < nmfirst && static_cast<uint32_t>((~L.mfirst()[cf])>>32) >= firstthres ) ++cf;
+		while ( cl < nmlast && static_cast<uint32_t>((~L.mlast()[cl])>>32) >= lastthres ) ++cl;
 		nF = cf; nL = cl; npool = n0;
 		if ( nF > FNC || nL > FNC ) { over(8); return; }
-		for ( uint32_t i = lane; i < nF; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mfirst[i]); L.fkmer[i] = km; int32_t const z = findNode(km); L.fnode[i] = z < 0 ? 0xFFFF : z; L.parF[i] = FNOPAR; L.pieF[i] = FNOPAR; }
-		for ( uint32_t i = lane; i < nL; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mlast[i]); L.lkmer[i] = km; int32_t const z = findNode(km); L.lnode[i] = z < 0 ? 0xFFFF : z; L.parL[i] = FNOPAR; L.pieL[i] = FNOPAR; }
+		for ( uint32_t i = lane; i < nF; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mfirst()[i]); L.fkmer()[i] = km; int32_t const z = findNode(km); L.fnode()[i] = z < 0 ? 0xFFFF : z; L.parF()[i] = FNOPAR; L.pieF()[i] = FNOPAR; }
+		for ( uint32_t i = lane; i < nL; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mlast()[i]); L.lkmer()[i] = km; int32_t const z = findNode(km); L.lnode()[i] = z < 0 ? 0xFFFF : z; L.parL()[i] = FNOPAR; L.pieL()[i] = FNOPAR; }
 		wv_sync();
 		// parents: lanes over base stretches.  An interior node has a unique active predecessor and successor, so it
 		// lies strictly inside at most one stretch; anything else goes to the generic engine
 		uint32_t multi = 0;
 		for ( uint32_t s = lane; s < n0; s += WSZ )
 		{
-			uint32_t const len = L.sslen[s]; uint16_t const * Lk = L.links + L.slink[s];
+			uint32_t const len = L.sslen()[s]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
 			for ( uint32_t i = 1; i+1 < len; ++i )
 			{
 				uint32_t const z = Lk[i];
-				for ( uint32_t c = 0; c < nF; ++c ) if ( L.fnode[c] == z ) { if ( L.parF[c] == FNOPAR ) { L.parF[c] = s; L.posF[c] = i; } else if ( L.parF[c] != s ) multi = 1; }
-				for ( uint32_t c = 0; c < nL; ++c ) if ( L.lnode[c] == z ) { if ( L.parL[c] == FNOPAR ) { L.parL[c] = s; L.posL[c] = i; } else if ( L.parL[c] != s ) multi = 1; }
+				for ( uint32_t c = 0; c < nF; ++c ) if ( L.fnode()[c] == z ) { if ( L.parF()[c] == FNOPAR ) { L.parF()[c] = s; L.posF()[c] = i; } else if ( L.parF()[c] != s ) multi = 1; }
+				for ( uint32_t c = 0; c < nL; ++c ) if ( L.lnode()[c] == z ) { if ( L.parL()[c] == FNOPAR ) { L.parL()[c] = s; L.posL()[c] = i; } else if ( L.parL()[c] != s ) multi = 1; }
 			}
 		}
 		if ( wv_any(multi) ) { over(32); return; }
 		wv_sync();
 		{
 			uint32_t cnt = 0;
-			for ( uint32_t c = 0; c < nF; ++c ) cnt += (L.parF[c] != FNOPAR);
-			for ( uint32_t c = 0; c < nL; ++c ) cnt += (L.parL[c] != FNOPAR);
-			if ( n0 + 2*cnt + 1 > C.scap || n0 + 2*cnt + 1 > 250 ) { over(32); return; }
+			for ( uint32_t c = 0; c < nF; ++c ) cnt += (L.parF()[c] != FNOPAR);
+			for ( uint32_t c = 0; c < nL; ++c ) cnt += (L.parL()[c] != FNOPAR);
+			if ( n0 + 2*cnt + 1 > CT::scap || n0 + 2*cnt + 1 > 250 ) { over(32); return; }
 		}
 		if ( lane == 0 )
 		{
 			uint32_t id = n0;
-			for ( uint32_t c = 0; c < nF; ++c ) if ( L.parF[c] != FNOPAR ) { L.pieF[c] = id; makePiece(id,L.parF[c],0,L.posF[c]); makePiece(id+1,L.parF[c],L.posF[c],L.sslen[L.parF[c]]-1); id += 2; }
-			for ( uint32_t c = 0; c < nL; ++c ) if ( L.parL[c] != FNOPAR ) { L.pieL[c] = id; makePiece(id,L.parL[c],0,L.posL[c]); makePiece(id+1,L.parL[c],L.posL[c],L.sslen[L.parL[c]]-1); id += 2; }
+			for ( uint32_t c = 0; c < nF; ++c ) if ( L.parF()[c] != FNOPAR ) { L.pieF()[c] = id; makePiece(id,L.parF()[c],0,L.posF()[c]); makePiece(id+1,L.parF()[c],L.posF()[c],L.sslen()[L.parF()[c]]-1); id += 2; }
+			for ( uint32_t c = 0; c < nL; ++c ) if ( L.parL()[c] != FNOPAR ) { L.pieL()[c] = id; makePiece(id,L.parL()[c],0,L.posL()[c]); makePiece(id+1,L.parL()[c],L.posL()[c],L.sslen()[L.parL()[c]]-1); id += 2; }
 			npool = id;
 		}
 		wv_sync();
 		npool = wv_bcast(npool,0);
+		fstat(12,nF); fstat(13,nL); fstat(14,npool); fstat(15,n0);
 	}
 
 	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions ----
 	DEV void computeStretchFeas(uint32_t const sfrom, uint32_t const sto)
 	{
-		uint32_t const nrows = C.nrows;
+		uint32_t const stride = nrows+1;
+		uint64_t const ltmask = wv_lanemask_lt();
 		for ( uint32_t s = sfrom; s < sto; ++s )
 		{
-			uint32_t const len = L.sslen[s];
-			uint16_t const * Lk = L.links + L.slink[s];
+			uint32_t const len = L.sslen()[s];
+			LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
 			uint64_t mF = 0, mR = 0;
 			uint32_t bF = nwF, bR = nwR;
 			for ( uint32_t c = 0; c < nrows; c += WSZ )
@@ -693,33 +728,25 @@ struct FastEngine
 				for ( uint32_t j = 0; j < len; ++j )
 				{
 					uint32_t const p = Pp+j;
-					bool const in = p < nrows;
-					{
-						uint32_t const z = Lk[j]; uint32_t const i0 = L.nps[z], f = L.nfreq[z];
-						uint64_t u = 0;
-						for ( uint32_t q = 0; q < f; ++q ) u += in ? L.tab[static_cast<uint32_t>(L.ipos[i0+q])*nrows + p] : 0u;
-						ok = ok && in && p >= L.pfrom[z] && p < L.pto[z] && u >= FW_THRES_FEAS;
-						sum += u;
-					}
-					{
-						uint32_t const z = Lk[len-1-j]; uint32_t const i0 = L.nps[z], f = L.nfreq[z];
-						uint64_t u = 0;
-						for ( uint32_t q = 0; q < f; ++q ) u += in ? L.tab[static_cast<uint32_t>(L.irpos[i0+q])*nrows + p] : 0u;
-						okr = okr && in && p >= L.cpfrom[z] && p < L.cpto[z] && u >= FW_THRES_FEAS;
-						rsum += u;
-					}
+					uint32_t const pc = p < nrows ? p : nrows;       // clamped: row nrows is all zero
+					uint32_t const zf = Lk[j], zr = Lk[len-1-j];
+					uint32_t const i0f = L.nps()[zf], ff = L.nfreq()[zf], i0r = L.nps()[zr], fr = L.nfreq()[zr];
+					uint64_t uf = 0, ur = 0;
+					for ( uint32_t q = 0; q < ff; ++q ) uf += L.tab()[static_cast<uint32_t>(L.ipos()[i0f+q])*stride + pc];
+					for ( uint32_t q = 0; q < fr; ++q ) ur += L.tab()[static_cast<uint32_t>(L.irpos()[i0r+q])*stride + pc];
+					ok = ok & (p >= L.pfrom()[zf]) & (p < L.pto()[zf]) & (uf >= FW_THRES_FEAS);
+					okr = okr & (p >= L.cpfrom()[zr]) & (p < L.cpto()[zr]) & (ur >= FW_THRES_FEAS);
+					sum += uf; rsum += ur;
 				}
-				uint32_t tot; uint32_t const pre = wv_scan_excl(ok ? 1 : 0,tot);
-				if ( ok && bF+pre < C.wcap ) L.wuF[bF+pre] = sum;
-				mF |= wv_or64(ok ? (1ull<<Pp) : 0ull);
-				bF += tot;
-				uint32_t const prer = wv_scan_excl(okr ? 1 : 0,tot);
-				if ( okr && bR+prer < C.wcap ) L.wuR[bR+prer] = rsum;
-				mR |= wv_or64(okr ? (1ull<<Pp) : 0ull);
-				bR += tot;
+				uint64_t const bf = wv_ballot(ok), br = wv_ballot(okr);
+				uint32_t const pre = dacc_popc64(bf & ltmask), prer = dacc_popc64(br & ltmask);
+				if ( ok && bF+pre < CT::wcap ) L.wuF()[bF+pre] = sum;
+				if ( okr && bR+prer < CT::wcap ) L.wuR()[bR+prer] = rsum;
+				mF |= bf << c; mR |= br << c;
+				bF += dacc_popc64(bf); bR += dacc_popc64(br);
 			}
-			if ( bF > C.wcap || bR > C.wcap ) { over(128); return; }
-			if ( lane == 0 ) { L.maskF[s] = mF; L.maskR[s] = mR; L.woffF[s] = nwF; L.woffR[s] = nwR; }
+			if ( bF > CT::wcap || bR > CT::wcap ) { over(128); return; }
+			if ( lane == 0 ) { L.maskF()[s] = mF; L.maskR()[s] = mR; L.woffF()[s] = nwF; L.woffR()[s] = nwR; }
 			nwF = bF; nwR = bR;
 		}
 		wv_sync();
@@ -727,90 +754,118 @@ struct FastEngine
 	// fixed-point weight of a single node at (reverse) position p
 	DEV uint64_t nodeU(uint32_t const z, uint32_t const p, bool const rev) const
 	{
-		if ( p >= C.nrows ) return 0;
-		uint32_t const i0 = L.nps[z], f = L.nfreq[z];
-		uint8_t const * IP = rev ? L.irpos : L.ipos;
+		if ( p >= nrows ) return 0;
+		uint32_t const i0 = L.nps()[z], f = L.nfreq()[z];
+		LDSQ uint8_t const * IP = rev ? L.irpos() : L.ipos();
 		uint64_t u = 0;
-		for ( uint32_t q = 0; q < f; ++q ) u += L.tab[static_cast<uint32_t>(IP[i0+q])*C.nrows + p];
+		for ( uint32_t q = 0; q < f; ++q ) u += L.tab()[static_cast<uint32_t>(IP[i0+q])*(nrows+1) + p];
 		return u;
 	}
 	DEV int32_t sfFind(uint32_t const s, uint32_t const p) const
 	{
 		if ( p >= 64 ) return -1;
-		uint64_t const m = L.maskF[s];
+		uint64_t const m = L.maskF()[s];
 		if ( !((m>>p)&1) ) return -1;
-		return L.woffF[s] + dacc_popc64(m & ((1ull<<p)-1));
+		return L.woffF()[s] + dacc_popc64(m & ((1ull<<p)-1));
 	}
 	DEV int32_t csfFind(uint32_t const s, uint32_t const p) const
 	{
 		if ( p >= 64 ) return -1;
-		uint64_t const m = L.maskR[s];
+		uint64_t const m = L.maskR()[s];
 		if ( !((m>>p)&1) ) return -1;
-		return L.woffR[s] + dacc_popc64(m & ((1ull<<p)-1));
+		return L.woffR()[s] + dacc_popc64(m & ((1ull<<p)-1));
 	}
 	// getReverseStretchLinkWeight(A=i,B=b) >= 0.1 (computeStretchLinks :3388-3480), evaluated on demand
 	DEV bool linkOk(uint32_t const i, uint32_t const b) const
 	{
-		uint32_t const shift = L.sslen[b]-1;
+		uint32_t const shift = L.sslen()[b]-1;
 		if ( shift >= 64 ) return false;
-		uint64_t const mA = L.maskR[i], mB = L.maskR[b];
+		uint64_t const mA = L.maskR()[i], mB = L.maskR()[b];
 		uint64_t common = mA & (mB<<shift);
 		uint64_t weight = 0;
-		uint32_t const alast = L.slast[i];
+		uint32_t const alast = L.slast()[i];
 		while ( common )
 		{
 			uint32_t const pa = __builtin_ctzll(common); common &= common-1;
-			uint32_t const ia = L.woffR[i] + dacc_popc64(mA & ((1ull<<pa)-1));
+			uint32_t const ia = L.woffR()[i] + dacc_popc64(mA & ((1ull<<pa)-1));
 			uint32_t const pb = pa-shift;
-			uint32_t const ib = L.woffR[b] + dacc_popc64(mB & ((1ull<<pb)-1));
-			uint64_t const lweight = L.wuR[ib] + (L.wuR[ia] - nodeU(alast,pa,true));
+			uint32_t const ib = L.woffR()[b] + dacc_popc64(mB & ((1ull<<pb)-1));
+			uint64_t const lweight = L.wuR()[ib] + (L.wuR()[ia] - nodeU(alast,pa,true));
 			weight = lweight > weight ? lweight : weight;
 		}
 		return weight >= FW_THRES_01;
 	}
 
 	// ================= views: the stretch set of a pair in sorted order =================
-	// view = base stretches minus the split parents plus the pieces; ord[] lists pool ids in Stretch::operator< order
-	DEV void buildView(uint32_t const * rem, uint32_t const nrem, uint32_t const * add, uint32_t const nadd)
+	// view = base stretches (pool ids 0..n0-1, already in Stretch::operator< order) minus the split parents plus the
+	// pieces.  It is never materialised: an iterator merges the base order with <= 4 insertions.
+	struct View { uint32_t nrem, nadd; };   // removed / inserted pool ids and insertion positions live in L.vrem/vadd/vapos
+	struct VIt { uint32_t t, a; };
+	View V;
+	// number of base stretches whose key is smaller than the key of pool stretch s
+	DEV uint32_t basePos(uint32_t const s) const
 	{
-		uint64_t akey[4];
-		for ( uint32_t a = 0; a < nadd; ++a ) akey[a] = poolKey(add[a]);
-		for ( uint32_t s = lane; s < n0; s += WSZ )
-		{
-			bool removed = false; uint32_t before = 0;
-			for ( uint32_t r = 0; r < nrem; ++r ) { if ( rem[r] == s ) removed = true; else if ( rem[r] < s ) ++before; }
-			if ( !removed )
-			{
-				uint64_t const key = poolKey(s);
-				uint32_t ins = 0;
-				for ( uint32_t a = 0; a < nadd; ++a ) if ( akey[a] < key ) ++ins;
-				L.ord[s-before+ins] = s;
-			}
-		}
-		if ( lane == 0 )
-			for ( uint32_t a = 0; a < nadd; ++a )
-			{
-				uint32_t lo = 0, hi = n0;
-				while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( poolKey(mid) < akey[a] ) lo = mid+1; else hi = mid; }
-				uint32_t pos = lo;
-				for ( uint32_t r = 0; r < nrem; ++r ) if ( rem[r] < lo ) --pos;
-				for ( uint32_t b = 0; b < nadd; ++b ) if ( akey[b] < akey[a] ) ++pos;
-				L.ord[pos] = add[a];
-			}
-		nview = n0 - nrem + nadd;
-		wv_sync();
-	}
-	DEV uint32_t viewLowerBound(uint32_t const node) const
-	{
-		uint32_t lo = 0, hi = nview;
-		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.sfirst[L.ord[mid]] < node ) lo = mid+1; else hi = mid; }
+		uint64_t const key = poolKey(s);
+		uint32_t lo = 0, hi = n0;
+		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( poolKey(mid) < key ) lo = mid+1; else hi = mid; }
 		return lo;
 	}
+	DEV void viewClear() { V.nrem = 0; V.nadd = 0; }
+	DEV void viewRemove(uint32_t const s) { L.vrem()[V.nrem++] = s; }
+	DEV void viewAdd(uint32_t const s)
+	{
+		uint32_t const pos = basePos(s); uint64_t const key = poolKey(s);
+		uint32_t i = V.nadd++;
+		// keep the insertions sorted by (position, key)
+		while ( i > 0 && ( L.vapos()[i-1] > pos || (L.vapos()[i-1] == pos && poolKey(L.vadd()[i-1]) > key) ) ) { L.vadd()[i] = L.vadd()[i-1]; L.vapos()[i] = L.vapos()[i-1]; --i; }
+		L.vadd()[i] = s; L.vapos()[i] = pos;
+	}
+	DEV void vbegin(VIt & it) const { it.t = 0; it.a = 0; }
+	DEV int32_t vnext(VIt & it) const
+	{
+		while ( true )
+		{
+			if ( it.a < V.nadd && L.vapos()[it.a] <= it.t ) return L.vadd()[it.a++];
+			if ( it.t >= n0 ) return -1;
+			uint32_t const sx = it.t++;
+			bool removed = false;
+			for ( uint32_t r = 0; r < V.nrem; ++r ) if ( L.vrem()[r] == sx ) removed = true;
+			if ( !removed ) return sx;
+		}
+	}
+	// position the iterator at the first view stretch whose first node is >= node
+	DEV void vseekFirst(VIt & it, uint32_t const node) const
+	{
+		uint32_t lo = 0, hi = n0;
+		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.sfirst()[mid] < node ) lo = mid+1; else hi = mid; }
+		it.t = lo; it.a = 0;
+		while ( it.a < V.nadd && ( L.vapos()[it.a] < lo || L.sfirst()[L.vadd()[it.a]] < node ) ) ++it.a;
+	}
 
+	// 16 byte records are moved as two 64 bit words (struct copies cannot bind LDS lvalues to generic references)
+	template<typename TT> DEV static TT ldget(LDSQ TT const * p)
+	{
+		static_assert(sizeof(TT) == 16,"record size");
+		LDSQ uint64_t const * q = reinterpret_cast<LDSQ uint64_t const *>(p);
+		uint64_t u[2]; u[0] = q[0]; u[1] = q[1];
+		TT t; __builtin_memcpy(&t,u,16); return t;
+	}
+	template<typename TT> DEV static void ldput(LDSQ TT * p, TT const & t)
+	{
+		uint64_t u[2]; __builtin_memcpy(u,&t,16);
+		LDSQ uint64_t * q = reinterpret_cast<LDSQ uint64_t *>(p);
+		q[0] = u[0]; q[1] = u[1];
+	}
+	template<typename TT> DEV static void ldswap(LDSQ TT * a, LDSQ TT * b)
+	{
+		LDSQ uint64_t * x = reinterpret_cast<LDSQ uint64_t *>(a); LDSQ uint64_t * y = reinterpret_cast<LDSQ uint64_t *>(b);
+		uint64_t const x0 = x[0], x1 = x[1], y0 = y[0], y1 = y[1];
+		x[0] = y0; x[1] = y1; y[0] = x0; y[1] = x1;
+	}
 	// ---- heaps (same sift algorithm as oracle/o_heap.hpp) ----
 	template<bool MINHEAP> DEV static bool hless(uint64_t a, uint64_t b) { return MINHEAP ? (a < b) : (a > b); }
 	template<bool MINHEAP>
-	DEV void ipush(uint8_t * H, uint32_t & f, uint8_t const id, uint64_t const * W)
+	DEV void ipush(LDSQ uint8_t * H, uint32_t & f, uint8_t const id, LDSQ uint64_t const * W)
 	{
 		uint32_t i = f++; H[i] = id;
 		while ( i )
@@ -821,7 +876,7 @@ struct FastEngine
 		}
 	}
 	template<bool MINHEAP>
-	DEV void ipop(uint8_t * H, uint32_t & f, uint64_t const * W)
+	DEV void ipop(LDSQ uint8_t * H, uint32_t & f, LDSQ uint64_t const * W)
 	{
 		H[0] = H[--f];
 		uint32_t i = 0, r;
@@ -835,91 +890,91 @@ struct FastEngine
 		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { uint8_t const t = H[i]; H[i] = H[l]; H[l] = t; }
 	}
 	template<typename TT, bool MINHEAP>
-	DEV void spush(TT * H, uint32_t & f, TT const & e)
+	DEV void spush(LDSQ TT * H, uint32_t & f, TT const & e)
 	{
-		uint32_t i = f++; H[i] = e;
+		uint32_t i = f++; ldput(H+i,e);
 		while ( i )
 		{
 			uint32_t const p = (i-1)>>1;
-			if ( hless<MINHEAP>(H[i].w,H[p].w) ) { TT const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
+			if ( hless<MINHEAP>(H[i].w,H[p].w) ) { ldswap(H+i,H+p); i = p; }
 			else break;
 		}
 	}
 	template<typename TT, bool MINHEAP>
-	DEV void spop(TT * H, uint32_t & f)
+	DEV void spop(LDSQ TT * H, uint32_t & f)
 	{
-		H[0] = H[--f];
+		--f; ldput(H,ldget(H+f));
 		uint32_t i = 0, r;
 		while ( (r = 2*i+2) < f )
 		{
 			uint32_t const m = hless<MINHEAP>(H[r-1].w,H[r].w) ? (r-1) : r;
 			if ( hless<MINHEAP>(H[i].w,H[m].w) ) return;
-			TT const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
+			ldswap(H+i,H+m); i = m;
 		}
 		uint32_t const l = 2*i+1;
-		if ( l < f && !hless<MINHEAP>(H[i].w,H[l].w) ) { TT const t = H[i]; H[i] = H[l]; H[l] = t; }
+		if ( l < f && !hless<MINHEAP>(H[i].w,H[l].w) ) ldswap(H+i,H+l);
 	}
 
 	// ================= reverse enumeration on the current view (lane 0) =================
-	uint32_t rb, nrp, narp, rlastk;
+	uint32_t rb, nrp, narp, rlastk; uint64_t rmaxw, fmaxw;
 	DEV int32_t extendReversePath(uint32_t const parent, uint32_t const s)
 	{
-		if ( rb+nrp >= C.rccap || nrp >= 250 ) { over(512); return -1; }
+		if ( rb+nrp >= CT::rccap || nrp >= 250 ) { over(512); return -1; }
 		uint32_t const id = nrp++;
-		uint32_t const ppos = L.rc_pos[rb+parent], plen = L.rc_len[rb+parent];
+		uint32_t const ppos = L.rc_pos()[rb+parent], plen = L.rc_len()[rb+parent];
 		int32_t const sfo = csfFind(s,ppos);
-		uint64_t weight = L.rc_w[rb+parent]; uint32_t baselen = L.rc_baselen[rb+parent];
-		if ( plen == 0 ) { baselen = L.sslen[s]+k-1; weight = sfo >= 0 ? L.wuR[sfo] : 0; }
-		else { baselen += L.sslen[s]-1; if ( sfo >= 0 ) weight += L.wuR[sfo] - nodeU(L.slast[s],ppos,true); }
-		uint32_t const npos = ppos + L.sslen[s]-1;
+		uint64_t weight = L.rc_w()[rb+parent]; uint32_t baselen = L.rc_baselen()[rb+parent];
+		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? L.wuR()[sfo] : 0; }
+		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += L.wuR()[sfo] - nodeU(L.slast()[s],ppos,true); }
+		uint32_t const npos = ppos + L.sslen()[s]-1;
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --nrp; return -1; }
-		L.rc_parent[rb+id] = parent; L.rc_stretch[rb+id] = s; L.rc_len[rb+id] = plen+1; L.rc_pos[rb+id] = npos;
-		L.rc_w[rb+id] = weight; L.rc_baselen[rb+id] = baselen;
+		L.rc_parent()[rb+id] = parent; L.rc_stretch()[rb+id] = s; L.rc_len()[rb+id] = plen+1; L.rc_pos()[rb+id] = npos;
+		L.rc_w()[rb+id] = weight; L.rc_baselen()[rb+id] = baselen;
 		return id;
 	}
 	DEV bool checkReversePathFeasiblePosition(uint32_t const id) const
 	{
-		uint32_t const s = L.rc_stretch[rb+id];
-		uint32_t const checkpos = L.rc_pos[rb+id] - (L.sslen[s]-1);
+		uint32_t const s = L.rc_stretch()[rb+id];
+		uint32_t const checkpos = L.rc_pos()[rb+id] - (L.sslen()[s]-1);
 		int32_t const f = csfFind(s,checkpos);
-		return f >= 0 && L.wuR[f] >= FW_THRES_05;
+		return f >= 0 && L.wuR()[f] >= FW_THRES_05;
 	}
-	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len[rb+id] ? L.nv[L.sfirst[L.rc_stretch[rb+id]]] : rlastk; }
+	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len()[rb+id] ? L.nv()[L.sfirst()[L.rc_stretch()[rb+id]]] : rlastk; }
 	DEV bool arpLess(uint8_t const a, uint8_t const b) const
 	{
 		uint32_t const fa = rpFront(a), fb = rpFront(b);
 		if ( fa != fb ) return fa < fb;
-		return L.rc_baselen[rb+a] < L.rc_baselen[rb+b];
+		return L.rc_baselen()[rb+a] < L.rc_baselen()[rb+b];
 	}
-	DEV void arpULI(uint8_t * last) { uint8_t const val = *last; uint8_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
-	DEV void arpIns(uint8_t * first, uint8_t * last)
+	DEV void arpULI(LDSQ uint8_t * last) { uint8_t const val = *last; LDSQ uint8_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
+	DEV void arpIns(LDSQ uint8_t * first, LDSQ uint8_t * last)
 	{
 		if ( first == last ) return;
-		for ( uint8_t * i = first+1; i != last; ++i )
+		for ( LDSQ uint8_t * i = first+1; i != last; ++i )
 		{
-			if ( arpLess(*i,*first) ) { uint8_t const val = *i; for ( uint8_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
+			if ( arpLess(*i,*first) ) { uint8_t const val = *i; for ( LDSQ uint8_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
 			else arpULI(i);
 		}
 	}
 	// libstdc++ std::sort permutation (introsort + final insertion sort), see dbg_window.hpp arpSort
-	DEV void arpSort(uint8_t * first, uint8_t * last)
+	DEV void arpSort(LDSQ uint8_t * first, LDSQ uint8_t * last)
 	{
 		if ( first == last ) return;
 		int32_t const n = last-first;
 		if ( n > 16 )
 		{
 			int depth = 0; { int32_t t = n; while ( t > 1 ) { t >>= 1; ++depth; } depth *= 2; }
-			uint8_t stF[24], stL[24], stD[24]; int sp = 0;   // offsets from first
+			LDSQ uint8_t * stF = L.sstack(); LDSQ uint8_t * stL = stF+24; LDSQ uint8_t * stD = stF+48; int sp = 0;   // offsets from first
 			stF[0] = 0; stL[0] = n; stD[0] = depth; sp = 1;
 			while ( sp )
 			{
 				--sp;
-				uint8_t * f = first+stF[sp]; uint8_t * l = first+stL[sp]; int d = stD[sp];
+				LDSQ uint8_t * f = first+stF[sp]; LDSQ uint8_t * l = first+stL[sp]; int d = stD[sp];
 				while ( l-f > 16 )
 				{
 					if ( d == 0 ) { over(1024); return; }
 					--d;
-					uint8_t * mid = f + (l-f)/2; uint8_t * a = f+1; uint8_t * b = mid; uint8_t * c = l-1;
+					LDSQ uint8_t * mid = f + (l-f)/2; LDSQ uint8_t * a = f+1; LDSQ uint8_t * b = mid; LDSQ uint8_t * c = l-1;
 					if ( arpLess(*a,*b) )
 					{
 						if ( arpLess(*b,*c) ) { uint8_t t = *f; *f = *b; *b = t; }
@@ -929,7 +984,7 @@ struct FastEngine
 					else if ( arpLess(*a,*c) ) { uint8_t t = *f; *f = *a; *a = t; }
 					else if ( arpLess(*b,*c) ) { uint8_t t = *f; *f = *c; *c = t; }
 					else { uint8_t t = *f; *f = *b; *b = t; }
-					uint8_t * lo = f+1; uint8_t * hi = l;
+					LDSQ uint8_t * lo = f+1; LDSQ uint8_t * hi = l;
 					while ( true )
 					{
 						while ( arpLess(*lo,*f) ) ++lo;
@@ -944,7 +999,7 @@ struct FastEngine
 				}
 			}
 			arpIns(first,first+16);
-			for ( uint8_t * i = first+16; i != last; ++i ) arpULI(i);
+			for ( LDSQ uint8_t * i = first+16; i != last; ++i ) arpULI(i);
 		}
 		else arpIns(first,last);
 	}
@@ -953,89 +1008,117 @@ struct FastEngine
 	DEV void reverseEnumerate(uint32_t const lastkmer, int32_t const lastnode, int64_t const lmax)
 	{
 		nrp = 0; narp = 0; rlastk = lastkmer;
-		for ( uint32_t i = 0; i < C.blcap; ++i ) L.hbl_n[i] = 0;
+		for ( uint32_t i = 0; i < CT::blcap; ++i ) L.hbl_n()[i] = 0;
 		uint32_t nrpst = 0;
 		if ( lastnode >= 0 )
 		{
-			if ( rb >= C.rccap ) { over(512); return; }
+			if ( rb >= CT::rccap ) { over(512); return; }
 			uint32_t const id = nrp++;
-			L.rc_parent[rb+id] = 0xFF; L.rc_stretch[rb+id] = 0xFF; L.rc_len[rb+id] = 0; L.rc_pos[rb+id] = 0; L.rc_w[rb+id] = 0; L.rc_baselen[rb+id] = k;
-			L.rpst[nrpst++] = id;
+			L.rc_parent()[rb+id] = 0xFF; L.rc_stretch()[rb+id] = 0xFF; L.rc_len()[rb+id] = 0; L.rc_pos()[rb+id] = 0; L.rc_w()[rb+id] = 0; L.rc_baselen()[rb+id] = k;
+			L.rpst()[nrpst++] = id;
 		}
-		uint64_t const * W = L.rc_w + rb;
+		LDSQ uint64_t const * W = L.rc_w() + rb;
 		while ( nrpst )
 		{
-			uint32_t const rp = L.rpst[0];
-			ipop<false>(L.rpst,nrpst,W);
-			uint32_t const bl = L.rc_baselen[rb+rp];
-			if ( bl >= C.blcap ) { over(2048); return; }
-			uint8_t * H = L.hbl + 12*bl; uint32_t hn = L.hbl_n[bl];
+			uint32_t const rp = L.rpst()[0];
+			ipop<false>(L.rpst(),nrpst,W);
+			uint32_t const bl = L.rc_baselen()[rb+rp];
+			if ( bl >= CT::blcap ) { over(2048); return; }
+			LDSQ uint8_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
 			if ( hn == 12 )
 			{
 				if ( W[rp] <= W[H[0]] ) continue;
 				else ipop<true>(H,hn,W);
 			}
 			ipush<true>(H,hn,rp,W);
-			L.hbl_n[bl] = hn;
+			L.hbl_n()[bl] = hn;
 			if ( narp >= 250 ) { over(512); return; }
-			L.rc_ord[rb+narp++] = rp;
-			if ( L.rc_len[rb+rp] == 0 )
+			L.rc_ord()[rb+narp++] = rp;
+			if ( L.rc_len()[rb+rp] == 0 )
 			{
-				for ( uint32_t t = 0; t < nview; ++t )
+				VIt it; vbegin(it);
+				for ( int32_t sx = vnext(it); sx >= 0; sx = vnext(it) )
 				{
-					uint32_t const s = L.ord[t];
-					if ( L.slast[s] == lastnode )
+					uint32_t const s = sx;
+					if ( L.slast()[s] == lastnode )
 					{
 						int32_t const rpe = extendReversePath(rp,s);
 						if ( rpe < 0 ) return;
-						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst,nrpst,rpe,W); }
+						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst(),nrpst,rpe,W); }
 						else --nrp;
 					}
 				}
 			}
-			else if ( static_cast<int64_t>(L.rc_baselen[rb+rp]) < (lmax+1)/2 )
+			else if ( static_cast<int64_t>(L.rc_baselen()[rb+rp]) < (lmax+1)/2 )
 			{
-				uint32_t const b = L.rc_stretch[rb+rp];
-				uint32_t const bf = L.sfirst[b];
-				for ( uint32_t t = 0; t < nview; ++t )
+				uint32_t const b = L.rc_stretch()[rb+rp];
+				uint32_t const bf = L.sfirst()[b];
+				VIt it; vbegin(it);
+				for ( int32_t ax = vnext(it); ax >= 0; ax = vnext(it) )
 				{
-					uint32_t const a = L.ord[t];
-					if ( L.slast[a] == bf && linkOk(a,b) )
+					uint32_t const a = ax;
+					if ( L.slast()[a] == bf && linkOk(a,b) )
 					{
 						int32_t const rpe = extendReversePath(rp,a);
 						if ( rpe < 0 ) return;
-						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst,nrpst,rpe,W); }
+						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst(),nrpst,rpe,W); }
 						else --nrp;
 					}
 				}
 			}
 		}
-		arpSort(L.rc_ord+rb,L.rc_ord+rb+narp);
+		fstat(0,nrp); fstat(1,narp); fstatadd(8,1); fstatadd(9,narp);
+		{ uint32_t nb = 0, mx = 0; for ( uint32_t i = 0; i < CT::blcap; ++i ) if ( L.hbl_n()[i] ) { ++nb; mx = i; } fstat(2,nb); fstat(3,mx); }
+		rmaxw = 0;
+		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[rb+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
+		arpSort(L.rc_ord()+rb,L.rc_ord()+rb+narp);
 		for ( uint32_t i = 0; i < narp; ++i )
 		{
-			uint64_t const wi = W[L.rc_ord[rb+i]];
+			uint64_t const wi = W[L.rc_ord()[rb+i]];
 			uint32_t r = 0;
 			for ( uint32_t j = 0; j < narp; ++j )
 			{
-				uint64_t const wj = W[L.rc_ord[rb+j]];
+				uint64_t const wj = W[L.rc_ord()[rb+j]];
 				if ( wj < wi || (wj == wi && j < i) ) ++r;
 			}
-			L.rc_arw[rb+i] = r;
+			L.rc_arw()[rb+i] = r;
 		}
+	}
+	// one bit per scan target of the enumeration just finished (node id mod 64): a clear bit proves that a node was not a target
+	DEV uint64_t reverseTargetMask(int32_t const lastnode, int64_t const lmax) const
+	{
+		uint64_t m = lastnode >= 0 ? (1ull << (lastnode & 63)) : 0ull;
+		for ( uint32_t i = 0; i < narp; ++i )
+		{
+			uint32_t const rp = L.rc_ord()[rb+i];
+			if ( L.rc_len()[rb+rp] && static_cast<int64_t>(L.rc_baselen()[rb+rp]) < (lmax+1)/2 ) m |= 1ull << (L.sfirst()[L.rc_stretch()[rb+rp]] & 63);
+		}
+		return m;
+	}
+	DEV uint64_t forwardTargetMask(int32_t const firstnode, int64_t const lmax) const
+	{
+		uint64_t m = 1ull << (firstnode & 63);
+		for ( uint32_t i = 0; i < nfpop; ++i )
+		{
+			uint32_t const path = L.fpop()[i];
+			uint32_t const pbl = L.f_baselen()[path];
+			if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) ) m |= 1ull << (L.slast()[L.f_stretch()[path]] & 63);
+		}
+		return m;
 	}
 	// can the cached reverse block (computed on the view of `last` alone) be used when stretch `par` is split at node `fn`?
 	// the scans of the enumeration look for stretches whose last node equals a target; the split changes the answer
 	// only for targets par.last (parent vs second piece) and fn (first piece)
 	DEV bool reverseUnaffected(uint32_t const base, uint32_t const nacc2, int32_t const lastnode, uint32_t const par, uint32_t const fn, int64_t const lmax) const
 	{
-		uint32_t const plast = L.slast[par];
+		uint32_t const plast = L.slast()[par];
 		if ( lastnode >= 0 && (static_cast<uint32_t>(lastnode) == plast || static_cast<uint32_t>(lastnode) == fn) ) return false;
 		for ( uint32_t i = 0; i < nacc2; ++i )
 		{
-			uint32_t const rp = L.rc_ord[base+i];
-			if ( L.rc_len[base+rp] && static_cast<int64_t>(L.rc_baselen[base+rp]) < (lmax+1)/2 )
+			uint32_t const rp = L.rc_ord()[base+i];
+			if ( L.rc_len()[base+rp] && static_cast<int64_t>(L.rc_baselen()[base+rp]) < (lmax+1)/2 )
 			{
-				uint32_t const target = L.sfirst[L.rc_stretch[base+rp]];
+				uint32_t const target = L.sfirst()[L.rc_stretch()[base+rp]];
 				if ( target == plast || target == fn ) return false;
 			}
 		}
@@ -1046,32 +1129,32 @@ struct FastEngine
 	uint32_t apqlo, apqhi;
 	DEV int32_t extendPath(int32_t const parent, uint32_t const s)
 	{
-		if ( np >= C.fcap || np >= 250 ) { over(512); return -1; }
+		if ( np >= CT::fcap || np >= 250 ) { over(512); return -1; }
 		uint32_t const id = np++;
-		uint32_t const ppos = parent >= 0 ? L.f_pos[parent] : 0;
-		uint32_t const plen = parent >= 0 ? L.f_len[parent] : 0;
-		uint64_t weight = parent >= 0 ? L.f_w[parent] : 0;
-		uint32_t baselen = parent >= 0 ? L.f_baselen[parent] : 0;
+		uint32_t const ppos = parent >= 0 ? L.f_pos()[parent] : 0;
+		uint32_t const plen = parent >= 0 ? L.f_len()[parent] : 0;
+		uint64_t weight = parent >= 0 ? L.f_w()[parent] : 0;
+		uint32_t baselen = parent >= 0 ? L.f_baselen()[parent] : 0;
 		int32_t const sfo = sfFind(s,ppos);
-		if ( plen == 0 ) { baselen = L.sslen[s]+k-1; weight = sfo >= 0 ? L.wuF[sfo] : 0; }
-		else { baselen += L.sslen[s]-1; if ( sfo >= 0 ) weight += L.wuF[sfo] - nodeU(L.sfirst[s],ppos,false); }
-		uint32_t const npos = ppos + (L.sslen[s]-1);
+		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? L.wuF()[sfo] : 0; }
+		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += L.wuF()[sfo] - nodeU(L.sfirst()[s],ppos,false); }
+		uint32_t const npos = ppos + (L.sslen()[s]-1);
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --np; return -1; }
-		L.f_parent[id] = parent >= 0 ? parent : 0xFF; L.f_stretch[id] = s; L.f_len[id] = plen+1; L.f_pos[id] = npos;
-		L.f_w[id] = weight; L.f_baselen[id] = baselen;
+		L.f_parent()[id] = parent >= 0 ? parent : 0xFF; L.f_stretch()[id] = s; L.f_len()[id] = plen+1; L.f_pos()[id] = npos;
+		L.f_w()[id] = weight; L.f_baselen()[id] = baselen;
 		return id;
 	}
 	DEV bool apqPush(uint32_t const id)
 	{
-		uint32_t const bl = L.f_baselen[id];
-		if ( bl >= C.blcap ) { over(2048); return false; }
-		uint8_t * H = L.hbl + 12*bl; uint32_t hn = L.hbl_n[bl];
+		uint32_t const bl = L.f_baselen()[id];
+		if ( bl >= CT::blcap ) { over(2048); return false; }
+		LDSQ uint8_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
 		if ( hn == 12 )
 		{
-			if ( L.f_w[id] > L.f_w[H[0]] ) { ipop<true>(H,hn,L.f_w); ipush<true>(H,hn,id,L.f_w); }
+			if ( L.f_w()[id] > L.f_w()[H[0]] ) { ipop<true>(H,hn,L.f_w()); ipush<true>(H,hn,id,L.f_w()); }
 		}
-		else ipush<true>(H,hn,id,L.f_w);
-		L.hbl_n[bl] = hn;
+		else ipush<true>(H,hn,id,L.f_w());
+		L.hbl_n()[bl] = hn;
 		if ( bl < apqlo ) apqlo = bl;
 		if ( bl+1 > apqhi ) apqhi = bl+1;
 		return true;
@@ -1079,41 +1162,42 @@ struct FastEngine
 	// path tree of traverse :4838-5041 without the score-interval part (that one depends on the reverse block)
 	DEV void forwardEnumerate(int32_t const firstnode, int64_t const lmax)
 	{
-		np = 0; nfpop = 0;
-		for ( uint32_t i = 0; i < C.blcap; ++i ) L.hbl_n[i] = 0;
-		apqlo = C.blcap; apqhi = 0;
-		for ( uint32_t t = 0; t < nview; ++t )
+		np = 0; nfpop = 0; fmaxw = 0;
+		for ( uint32_t i = 0; i < CT::blcap; ++i ) L.hbl_n()[i] = 0;
+		apqlo = CT::blcap; apqhi = 0;
 		{
-			uint32_t const s = L.ord[t];
-			if ( L.sfirst[s] == firstnode )
+			VIt it; vseekFirst(it,firstnode);
+			for ( int32_t sx = vnext(it); sx >= 0 && L.sfirst()[sx] == static_cast<uint32_t>(firstnode); sx = vnext(it) )
 			{
-				int32_t const id = extendPath(-1,s);
+				int32_t const id = extendPath(-1,sx);
 				if ( id < 0 || !apqPush(id) ) return;
 			}
 		}
 		for ( uint32_t zz = apqlo; zz < apqhi; ++zz )
-			while ( L.hbl_n[zz] )
+			while ( L.hbl_n()[zz] )
 			{
-				uint8_t * H = L.hbl + 12*zz; uint32_t hn = L.hbl_n[zz];
+				LDSQ uint8_t * H = L.hbl() + 12*zz; uint32_t hn = L.hbl_n()[zz];
 				uint32_t const path = H[0];
-				ipop<true>(H,hn,L.f_w);
-				L.hbl_n[zz] = hn;
-				if ( nfpop >= C.fcap ) { over(512); return; }
-				L.fpop[nfpop++] = path;
-				uint32_t const pbl = L.f_baselen[path];
+				ipop<true>(H,hn,L.f_w());
+				L.hbl_n()[zz] = hn;
+				if ( nfpop >= CT::fcap ) { over(512); return; }
+				L.fpop()[nfpop++] = path;
+				if ( L.f_w()[path] > fmaxw ) fmaxw = L.f_w()[path];
+				uint32_t const pbl = L.f_baselen()[path];
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 				{
-					uint32_t const lastn = L.slast[L.f_stretch[path]];
-					for ( uint32_t t = viewLowerBound(lastn); t < nview && L.sfirst[L.ord[t]] == lastn; ++t )
+					uint32_t const lastn = L.slast()[L.f_stretch()[path]];
+					VIt it; vseekFirst(it,lastn);
+					for ( int32_t sx = vnext(it); sx >= 0 && L.sfirst()[sx] == lastn; sx = vnext(it) )
 					{
-						uint32_t const s = L.ord[t];
-						int32_t const sfo = sfFind(s,L.f_pos[path]);
-						uint64_t const eweight = sfo >= 0 ? L.wuF[sfo] : 0;
+						uint32_t const s = sx;
+						int32_t const sfo = sfFind(s,L.f_pos()[path]);
+						uint64_t const eweight = sfo >= 0 ? L.wuF()[sfo] : 0;
 						if ( eweight >= FW_THRES_01 )
 						{
 							int32_t const ep = extendPath(path,s);
 							if ( ep < 0 ) return;
-							if ( L.f_w[ep] >= FW_THRES_01 && static_cast<int64_t>(L.f_pos[ep]) + k <= lmax )
+							if ( L.f_w()[ep] >= FW_THRES_01 && static_cast<int64_t>(L.f_pos()[ep]) + k <= lmax )
 							{
 								if ( !apqPush(ep) ) return;
 							}
@@ -1127,15 +1211,15 @@ struct FastEngine
 	// changes the answer only for targets par.first (parent vs first piece) and ln (second piece)
 	DEV bool forwardUnaffected(int32_t const firstnode, uint32_t const par, uint32_t const ln, int64_t const lmax) const
 	{
-		uint32_t const pfirst = L.sfirst[par];
+		uint32_t const pfirst = L.sfirst()[par];
 		if ( static_cast<uint32_t>(firstnode) == pfirst || static_cast<uint32_t>(firstnode) == ln ) return false;
 		for ( uint32_t i = 0; i < nfpop; ++i )
 		{
-			uint32_t const path = L.fpop[i];
-			uint32_t const pbl = L.f_baselen[path];
+			uint32_t const path = L.fpop()[i];
+			uint32_t const pbl = L.f_baselen()[path];
 			if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 			{
-				uint32_t const target = L.slast[L.f_stretch[path]];
+				uint32_t const target = L.slast()[L.f_stretch()[path]];
 				if ( target == pfirst || target == ln ) return false;
 			}
 		}
@@ -1145,34 +1229,34 @@ struct FastEngine
 	// ================= combining a forward tree with a reverse block (score intervals + pair loop) =================
 	DEV uint64_t getPairScore(uint32_t const path, uint32_t const base, uint32_t const rp) const
 	{
-		uint32_t const s = L.f_stretch[path];
-		uint32_t const spos = L.f_pos[path] - (L.sslen[s]-1);
+		uint32_t const s = L.f_stretch()[path];
+		uint32_t const spos = L.f_pos()[path] - (L.sslen()[s]-1);
 		int32_t const sfo = sfFind(s,spos);
-		if ( sfo >= 0 ) return L.f_w[path] + L.rc_w[base+rp] - nodeU(L.slast[s],L.f_pos[path],false);
-		else return L.f_w[path] + L.rc_w[base+rp];
+		if ( sfo >= 0 ) return L.f_w()[path] + L.rc_w()[base+rp] - nodeU(L.slast()[s],L.f_pos()[path],false);
+		else return L.f_w()[path] + L.rc_w()[base+rp];
 	}
-	DEV uint32_t rcFront(uint32_t const base, uint32_t const rp, uint32_t const lastkmer) const { return L.rc_len[base+rp] ? L.nv[L.sfirst[L.rc_stretch[base+rp]]] : lastkmer; }
+	DEV uint32_t rcFront(uint32_t const base, uint32_t const rp, uint32_t const lastkmer) const { return L.rc_len()[base+rp] ? L.nv()[L.sfirst()[L.rc_stretch()[base+rp]]] : lastkmer; }
 	// decodePathPair :4267-4300 into dst (2-bit codes); returns length or ~0
-	DEV uint32_t decodePathPair(uint32_t const path, uint32_t const base, uint32_t const rp, uint8_t * dst)
+	DEV uint32_t decodePathPair(uint32_t const path, uint32_t const base, uint32_t const rp, LDSQ uint8_t * dst)
 	{
-		uint8_t chain[64]; uint32_t cl = 0;
-		for ( uint32_t q = path; q != 0xFF; q = L.f_parent[q] ) { if ( cl >= 64 ) { over(4096); return ~0u; } chain[cl++] = L.f_stretch[q]; }
+		LDSQ uint8_t * chain = L.chain(); uint32_t cl = 0;
+		for ( uint32_t q = path; q != 0xFF; q = L.f_parent()[q] ) { if ( cl >= 64 ) { over(4096); return ~0u; } chain[cl++] = L.f_stretch()[q]; }
 		uint32_t need = k;
-		for ( uint32_t i = 0; i < cl; ++i ) need += L.sslen[chain[i]]-1;
-		for ( uint32_t q = rp; L.rc_len[base+q]; q = L.rc_parent[base+q] ) need += L.sslen[L.rc_stretch[base+q]]-1;
+		for ( uint32_t i = 0; i < cl; ++i ) need += L.sslen()[chain[i]]-1;
+		for ( uint32_t q = rp; L.rc_len()[base+q]; q = L.rc_parent()[base+q] ) need += L.sslen()[L.rc_stretch()[base+q]]-1;
 		if ( need > MAXCONS ) { over(4096); return ~0u; }
 		uint32_t o = 0;
-		uint32_t const firstv = L.nv[L.sfirst[chain[cl-1]]];
+		uint32_t const firstv = L.nv()[L.sfirst()[chain[cl-1]]];
 		for ( uint32_t i = 0; i < k; ++i ) dst[o++] = (firstv >> (2*(k-1-i))) & 3;
 		for ( uint32_t ii = 0; ii < cl; ++ii )
 		{
-			uint32_t const s = chain[cl-1-ii]; uint16_t const * Lk = L.links + L.slink[s];
-			for ( uint32_t j = 1; j < L.sslen[s]; ++j ) dst[o++] = L.nv[Lk[j]] & 3;
+			uint32_t const s = chain[cl-1-ii]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+			for ( uint32_t j = 1; j < L.sslen()[s]; ++j ) dst[o++] = L.nv()[Lk[j]] & 3;
 		}
-		for ( uint32_t q = rp; L.rc_len[base+q]; q = L.rc_parent[base+q] )
+		for ( uint32_t q = rp; L.rc_len()[base+q]; q = L.rc_parent()[base+q] )
 		{
-			uint32_t const s = L.rc_stretch[base+q]; uint16_t const * Lk = L.links + L.slink[s];
-			for ( uint32_t j = 1; j < L.sslen[s]; ++j ) dst[o++] = L.nv[Lk[j]] & 3;
+			uint32_t const s = L.rc_stretch()[base+q]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+			for ( uint32_t j = 1; j < L.sslen()[s]; ++j ) dst[o++] = L.nv()[Lk[j]] & 3;
 		}
 		return o;
 	}
@@ -1181,80 +1265,81 @@ struct FastEngine
 		nsiq = 0;
 		for ( uint32_t pi = 0; pi < nfpop; ++pi )
 		{
-			uint32_t const path = L.fpop[pi];
-			int64_t const candlen = static_cast<int64_t>(L.f_pos[path]) + k;
-			uint32_t const front = L.nv[L.slast[L.f_stretch[path]]];
+			uint32_t const path = L.fpop()[pi];
+			int64_t const candlen = static_cast<int64_t>(L.f_pos()[path]) + k;
+			uint32_t const front = L.nv()[L.slast()[L.f_stretch()[path]]];
 			uint32_t lo = 0, hi = nacc2;
-			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( rcFront(base,L.rc_ord[base+mid],lastkmer) < front ) lo = mid+1; else hi = mid; }
+			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( rcFront(base,L.rc_ord()[base+mid],lastkmer) < front ) lo = mid+1; else hi = mid; }
 			uint32_t e = lo;
-			while ( e < nacc2 && rcFront(base,L.rc_ord[base+e],lastkmer) == front ) ++e;
+			while ( e < nacc2 && rcFront(base,L.rc_ord()[base+e],lastkmer) == front ) ++e;
 			int64_t bllo = lmin + static_cast<int64_t>(k) - candlen; if ( bllo < 0 ) bllo = 0;
 			int64_t blhi = lmax + static_cast<int64_t>(k) - candlen; if ( blhi < 0 ) blhi = 0;
 			uint32_t const bllo16 = static_cast<uint16_t>(bllo), blhi16 = static_cast<uint16_t>(blhi);
 			uint32_t sub = lo;
-			while ( sub < e && L.rc_baselen[base+L.rc_ord[base+sub]] < bllo16 ) ++sub;
+			while ( sub < e && L.rc_baselen()[base+L.rc_ord()[base+sub]] < bllo16 ) ++sub;
 			uint32_t sup = sub;
-			while ( sup < e && !(blhi16 < L.rc_baselen[base+L.rc_ord[base+sup]]) ) ++sup;
+			while ( sup < e && !(blhi16 < L.rc_baselen()[base+L.rc_ord()[base+sup]]) ) ++sup;
 			if ( sub != sup )
 			{
 				uint32_t mi = sub;
-				for ( uint32_t i = sub+1; i < sup; ++i ) if ( L.rc_arw[base+i] > L.rc_arw[base+mi] ) mi = i;
-				if ( nsiq >= C.siqcap ) { over(512); return; }
-				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = path; si.pad = 0; si.w = getPairScore(path,base,L.rc_ord[base+mi]);
-				spush<FSI,false>(L.siq,nsiq,si);
+				for ( uint32_t i = sub+1; i < sup; ++i ) if ( L.rc_arw()[base+i] > L.rc_arw()[base+mi] ) mi = i;
+				if ( nsiq >= CT::siqcap ) { over(512); return; }
+				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = path; si.pad = 0; si.w = getPairScore(path,base,L.rc_ord()[base+mi]);
+				spush<FSI,false>(L.siq(),nsiq,si);
+				fstat(6,nsiq);
 			}
 		}
 		prevlen = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
 		{
-			FSI const si = L.siq[0];
+			FSI const si = ldget(L.siq());
 			// the score intervals leave the heap in non increasing weight order and everything still inside is not
 			// heavier, so once the candidate heap is full and its top cannot be beaten, nothing of this pair can enter
-			if ( ncdh == 16 && si.w <= L.cdh[0].w ) break;
-			spop<FSI,false>(L.siq,nsiq);
+			if ( ncdh == 16 && si.w <= L.cdh()[0].w ) break;
+			spop<FSI,false>(L.siq(),nsiq);
 			{
-				uint32_t const v = L.rc_arw[base+si.current];
+				uint32_t const v = L.rc_arw()[base+si.current];
 				if ( v )
 				{
 					bool found = false; uint32_t bu = 0, bi = 0;
 					for ( uint32_t i = si.left; i < si.right; ++i )
 					{
-						uint32_t const r = L.rc_arw[base+i];
+						uint32_t const r = L.rc_arw()[base+i];
 						if ( r <= v-1 && (!found || r > bu) ) { found = true; bu = r; bi = i; }
 					}
 					if ( found )
 					{
-						FSI sic = si; sic.current = bi; sic.w = getPairScore(si.path,base,L.rc_ord[base+bi]);
-						if ( nsiq >= C.siqcap ) { over(512); return; }
-						spush<FSI,false>(L.siq,nsiq,sic);
+						FSI sic = si; sic.current = bi; sic.w = getPairScore(si.path,base,L.rc_ord()[base+bi]);
+						if ( nsiq >= CT::siqcap ) { over(512); return; }
+						spush<FSI,false>(L.siq(),nsiq,sic);
 					}
 				}
 			}
 			uint64_t const weight = si.w;
-			if ( ncdh == 16 ) spop<FCC,true>(L.cdh,ncdh);   // weight > top here
-			uint32_t const conslen = decodePathPair(si.path,base,L.rc_ord[base+si.current],L.curstr);
+			if ( ncdh == 16 ) spop<FCC,true>(L.cdh(),ncdh);   // weight > top here
+			uint32_t const conslen = decodePathPair(si.path,base,L.rc_ord()[base+si.current],L.curstr());
 			if ( conslen == ~0u ) return;
 			if ( conslen == prevlen )
 			{
 				bool eq = true;
-				for ( uint32_t i = 0; i < conslen; ++i ) if ( L.prevstr[i] != L.curstr[i] ) { eq = false; break; }
+				for ( uint32_t i = 0; i < conslen; ++i ) if ( L.prevstr()[i] != L.curstr()[i] ) { eq = false; break; }
 				if ( eq ) continue;
 			}
-			for ( uint32_t i = 0; i < conslen; ++i ) L.prevstr[i] = L.curstr[i];
+			for ( uint32_t i = 0; i < conslen; ++i ) L.prevstr()[i] = L.curstr()[i];
 			prevlen = conslen;
-			if ( conso + conslen > C.conscap - MAXCONS ) { over(4096); return; }
-			for ( uint32_t i = 0; i < conslen; ++i ) G.cons[conso+i] = L.curstr[i];
+			if ( conso + conslen > CT::conscap - MAXCONS ) { over(4096); return; }
+			for ( uint32_t i = 0; i < conslen; ++i ) G.cons[conso+i] = L.curstr()[i];
 			FCC cc; cc.w = weight; cc.o = conso; cc.l = conslen;
 			conso += conslen;
-			spush<FCC,true>(L.cdh,ncdh,cc);
+			spush<FCC,true>(L.cdh(),ncdh,cc);
 		}
 	}
 
-	DEV uint32_t myersDistance(uint32_t const j, uint8_t const * text, uint32_t const n) const
+	DEV uint32_t myersDistance(uint32_t const j, GLBQ uint8_t const * text, uint32_t const n) const
 	{
-		uint32_t const m = L.slen[j];
+		uint32_t const m = L.slen()[j];
 		if ( m == 0 ) return n;
-		uint64_t const * PEQ = L.peq + 4*j;
+		LDSQ uint64_t const * PEQ = L.peq() + 4*j;
 		uint32_t score = m;
 		uint64_t Pv = ~0ull, Mv = 0;
 		uint64_t const top = 1ull<<(m-1);
@@ -1276,16 +1361,127 @@ struct FastEngine
 	{
 		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
-			uint64_t e[4] = {0,0,0,0};
-			uint32_t const m = L.slen[j];
-			uint8_t const * s = L.str + j*64;
-			for ( uint32_t i = 0; i < m; ++i ) e[s[i]] |= 1ull<<i;
-			for ( uint32_t i = 0; i < 4; ++i ) L.peq[4*j+i] = e[i];
+			uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+			uint32_t const m = L.slen()[j];
+			LDSQ uint8_t const * s = L.str() + j*64;
+			for ( uint32_t i = 0; i < m; ++i )
+			{
+				uint32_t const c = s[i]; uint64_t const b = 1ull<<i;
+				e0 |= (c == 0) ? b : 0; e1 |= (c == 1) ? b : 0; e2 |= (c == 2) ? b : 0; e3 |= (c == 3) ? b : 0;
+			}
+			L.peq()[4*j+0] = e0; L.peq()[4*j+1] = e1; L.peq()[4*j+2] = e2; L.peq()[4*j+3] = e3;
 		}
 		wv_sync();
 	}
 
 	// ================= traverse (:4496-5170) for one activation state =================
+	// the pair loop runs on lane 0; it comes back to the wavefront only for the feasibility of a temporary middle
+	// piece (a stretch split at both its first and its last candidate)
+	uint32_t pl_fi, pl_li, pl_midA, pl_midB, pl_midpar; bool pl_midready; uint64_t ftmask;
+
+	// returns 0 = all pairs done, 1 = needs the middle piece [pl_midA,pl_midB] of stretch pl_midpar
+	DEV uint32_t pairLoop(int64_t const lmin, int64_t const lmax)
+	{
+		LDSQ uint64_t * RMAX = L.rmaxw();   // per last k-mer: heaviest accepted weight of its cached reverse block
+		for ( ; pl_fi < nF; ++pl_fi, pl_li = 0 )
+		{
+			uint32_t const fi = pl_fi;
+			int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
+			uint32_t const sf = L.parF()[fi];
+			for ( ; pl_li < nL; ++pl_li )
+			{
+				uint32_t const li = pl_li;
+				uint32_t const lastk = L.lkmer()[li];
+				int32_t const lastnode = L.lnode()[li] == 0xFFFF ? -1 : L.lnode()[li];
+				uint32_t const sl = L.parL()[li];
+				bool const same = (sf != FNOPAR && sf == sl);
+				bool rcached = false, fcached = false;
+				if ( !same )
+				{
+					// reverse block, cached per last k-mer (computed on the view split at `last` only)
+					if ( ! L.rvalid()[li] )
+					{
+						uint64_t const tq0 = pclock();
+						viewClear();
+						if ( sl != FNOPAR ) { viewRemove(sl); viewAdd(L.pieL()[li]); viewAdd(L.pieL()[li]+1); }
+						rb = rctop;
+						reverseEnumerate(lastk,lastnode,lmax);
+						if ( flags ) return 0;
+						L.rbase()[li] = rb; L.rn()[li] = narp; L.rnpool()[li] = nrp; L.rvalid()[li] = 1; RMAX[li] = rmaxw;
+						L.rtmask()[li] = reverseTargetMask(lastnode,lmax);
+						rctop = rb + nrp;
+						pcount(22,pclock()-tq0); pcount(25,1);
+					}
+					if ( sf == FNOPAR ) rcached = true;
+					else
+					{
+						uint64_t const tm = L.rtmask()[li];
+						rcached = !((tm >> (L.slast()[sf]&63))&1) && !((tm >> (L.fnode()[fi]&63))&1);
+						if ( !rcached ) rcached = reverseUnaffected(L.rbase()[li],L.rn()[li],lastnode,sf,L.fnode()[fi],lmax);
+					}
+					// forward tree, cached for the current first k-mer (computed on the view split at `first` only)
+					if ( fcur_fi != static_cast<int32_t>(fi) || fcur_li != -1 )
+					{
+						uint64_t const tq0 = pclock();
+						viewClear();
+						if ( sf != FNOPAR ) { viewRemove(sf); viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
+						forwardEnumerate(firstnode,lmax);
+						if ( flags ) return 0;
+						fcur_fi = fi; fcur_li = -1;
+						ftmask = forwardTargetMask(firstnode,lmax);
+						pcount(23,pclock()-tq0); pcount(26,1);
+					}
+					if ( sl == FNOPAR ) fcached = true;
+					else
+					{
+						fcached = !((ftmask >> (L.sfirst()[sl]&63))&1) && !((ftmask >> (L.lnode()[li]&63))&1);
+						if ( !fcached ) fcached = forwardUnaffected(firstnode,sl,L.lnode()[li],lmax);
+					}
+					pcount(27,1);
+					// no candidate of this pair can beat the lightest kept candidate: score <= path weight + reverse weight
+					if ( rcached && fcached && ncdh == 16 && fmaxw + RMAX[li] <= L.cdh()[0].w ) { pcount(28,1); continue; }
+				}
+				uint32_t base, nacc2;
+				uint32_t const swF = nwF, swR = nwR;
+				if ( !rcached || !fcached )
+				{
+					// exact stretch set of the pair (split at first, then at last)
+					viewClear();
+					if ( same )
+					{
+						uint32_t const pf = L.posF()[fi], pl = L.posL()[li];
+						viewRemove(sf);
+						if ( pf == pl ) { viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
+						else
+						{
+							if ( !pl_midready )
+							{
+								pl_midpar = sf; pl_midA = pf < pl ? pf : pl; pl_midB = pf < pl ? pl : pf;
+								return 1;
+							}
+							pl_midready = false;
+							if ( pf < pl ) { viewAdd(L.pieF()[fi]); viewAdd(L.pieL()[li]+1); } else { viewAdd(L.pieL()[li]); viewAdd(L.pieF()[fi]+1); }
+							viewAdd(npool);
+						}
+					}
+					else
+					{
+						if ( sf != FNOPAR ) { viewRemove(sf); viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
+						if ( sl != FNOPAR ) { viewRemove(sl); viewAdd(L.pieL()[li]); viewAdd(L.pieL()[li]+1); }
+					}
+					if ( !rcached ) { rb = rctop; reverseEnumerate(lastk,lastnode,lmax); if ( flags ) return 0; }
+					if ( !fcached ) { forwardEnumerate(firstnode,lmax); if ( flags ) return 0; fcur_fi = fi; fcur_li = li; }
+				}
+				if ( rcached ) { base = L.rbase()[li]; nacc2 = L.rn()[li]; } else { base = rb; nacc2 = narp; }
+				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,lastk,lmin,lmax,16); pcount(24,pclock()-tq0); }
+				if ( !rcached || !fcached ) pcount(21,1);
+				if ( flags ) return 0;
+				nwF = swF; nwR = swR;   // drop the weights of a temporary middle piece
+			}
+		}
+		return 0;
+	}
+
 	DEV bool traverse(int64_t const lmin, int64_t const lmax)
 	{
 		PROF_T0
@@ -1297,131 +1493,34 @@ struct FastEngine
 		flags = wv_or(flags); if ( flags ) return false;
 		computeStretchFeas(0,npool);
 		flags = wv_or(flags); if ( flags ) return false;
-		for ( uint32_t i = lane; i < FNC+1; i += WSZ ) L.rvalid[i] = 0;
+		for ( uint32_t i = lane; i < FNC+1; i += WSZ ) L.rvalid()[i] = 0;
 		wv_sync();
 		PROF(*this,9)
-#if defined(DACC_EMUL) && defined(DACC_FSTATS)
-		fstat(0,nwF); fstat(1,nwR); fstat(2,npool); fstat(3,nF); fstat(4,nL); fstat(5,nlinks); fstat(6,nn); fstat(7,npre);
-#endif
-		for ( uint32_t fi = 0; fi < nF; ++fi )
+		pl_fi = 0; pl_li = 0; pl_midready = false;
+		while ( true )
 		{
-			int32_t const firstnode = L.fnode[fi] == 0xFFFF ? -1 : L.fnode[fi];
-			uint32_t const sf = L.parF[fi];
-			for ( uint32_t li = 0; li < nL; ++li )
-			{
-				uint32_t const lastk = L.lkmer[li];
-				int32_t const lastnode = L.lnode[li] == 0xFFFF ? -1 : L.lnode[li];
-				uint32_t const sl = L.parL[li];
-				bool const same = (sf != FNOPAR && sf == sl);
-				// ---- the pair's exact stretch set (split at first, then at last)
-				uint32_t remX[2], addX[4]; uint32_t nremX = 0, naddX = 0; bool needMid = false; uint32_t midA = 0, midB = 0;
-				if ( same )
-				{
-					uint32_t const pf = L.posF[fi], pl = L.posL[li];
-					remX[nremX++] = sf;
-					if ( pf == pl ) { addX[naddX++] = L.pieF[fi]; addX[naddX++] = L.pieF[fi]+1; }
-					else if ( pf < pl ) { addX[naddX++] = L.pieF[fi]; addX[naddX++] = L.pieL[li]+1; needMid = true; midA = pf; midB = pl; }
-					else { addX[naddX++] = L.pieL[li]; addX[naddX++] = L.pieF[fi]+1; needMid = true; midA = pl; midB = pf; }
-				}
-				else
-				{
-					if ( sf != FNOPAR ) { remX[nremX++] = sf; addX[naddX++] = L.pieF[fi]; addX[naddX++] = L.pieF[fi]+1; }
-					if ( sl != FNOPAR ) { remX[nremX++] = sl; addX[naddX++] = L.pieL[li]; addX[naddX++] = L.pieL[li]+1; }
-				}
-				// ---- reverse block: cached per last k-mer when the first k-mer's split cannot touch it
-				bool rcached = false;
-				if ( !same )
-				{
-					if ( ! L.rvalid[li] )
-					{
-						uint32_t remL[1], addL[2]; uint32_t nr = 0, na = 0;
-						if ( sl != FNOPAR ) { remL[nr++] = sl; addL[na++] = L.pieL[li]; addL[na++] = L.pieL[li]+1; }
-						buildView(remL,nr,addL,na);
-						if ( lane == 0 )
-						{
-							rb = rctop;
-							reverseEnumerate(lastk,lastnode,lmax);
-							L.rbase[li] = rb; L.rn[li] = narp; L.rnpool[li] = nrp; L.rvalid[li] = 1;
-							rctop = rb + nrp;
-						}
-						wv_sync();
-						flags = wv_bcast(flags,0); if ( flags ) return false;
-						rctop = wv_bcast(rctop,0);
-					}
-					rcached = (sf == FNOPAR);
-					if ( !rcached )
-					{
-						uint32_t ok = 0;
-						if ( lane == 0 ) ok = reverseUnaffected(L.rbase[li],L.rn[li],lastnode,sf,L.fnode[fi],lmax) ? 1 : 0;
-						rcached = wv_bcast(ok,0) != 0;
-					}
-				}
-				// ---- forward tree: cached for the current first k-mer when the last k-mer's split cannot touch it
-				bool fcached = false;
-				if ( !same )
-				{
-					if ( fcur_fi != static_cast<int32_t>(fi) || fcur_li != -1 )
-					{
-						uint32_t remF[1], addF[2]; uint32_t nr = 0, na = 0;
-						if ( sf != FNOPAR ) { remF[nr++] = sf; addF[na++] = L.pieF[fi]; addF[na++] = L.pieF[fi]+1; }
-						buildView(remF,nr,addF,na);
-						if ( lane == 0 ) forwardEnumerate(firstnode,lmax);
-						wv_sync();
-						flags = wv_bcast(flags,0); if ( flags ) return false;
-						fcur_fi = fi; fcur_li = -1;
-					}
-					fcached = (sl == FNOPAR);
-					if ( !fcached )
-					{
-						uint32_t ok = 0;
-						if ( lane == 0 ) ok = forwardUnaffected(firstnode,sl,L.lnode[li],lmax) ? 1 : 0;
-						fcached = wv_bcast(ok,0) != 0;
-					}
-				}
-				// ---- exact enumeration where a cache cannot be used
-				uint32_t swF = nwF, swR = nwR;
-				if ( !rcached || !fcached )
-				{
-					if ( needMid )
-					{
-						// middle piece of a stretch split twice: a temporary pool entry with its own feasibility
-						if ( npool+1 > C.scap ) { over(32); return false; }
-						if ( lane == 0 ) makePiece(npool,sf,midA,midB);
-						wv_sync();
-						computeStretchFeas(npool,npool+1);
-						flags = wv_or(flags); if ( flags ) return false;
-						addX[naddX++] = npool;
-					}
-					buildView(remX,nremX,addX,naddX);
-					if ( lane == 0 )
-					{
-						if ( !rcached ) { rb = rctop; reverseEnumerate(lastk,lastnode,lmax); }
-						if ( !fcached && !flags ) forwardEnumerate(firstnode,lmax);
-					}
-					wv_sync();
-					flags = wv_bcast(flags,0); if ( flags ) return false;
-					if ( !fcached ) { fcur_fi = fi; fcur_li = li; }
-				}
-				if ( lane == 0 )
-				{
-					uint32_t base, nacc2;
-					if ( rcached ) { base = L.rbase[li]; nacc2 = L.rn[li]; } else { base = rb; nacc2 = narp; }
-					combinePair(base,nacc2,lastk,lmin,lmax,16);
-				}
-				wv_sync();
-				flags = wv_bcast(flags,0); if ( flags ) return false;
-				nwF = swF; nwR = swR;   // drop the weights of a temporary middle piece
-			}
+			uint32_t req = 0;
+			if ( lane == 0 ) req = pairLoop(lmin,lmax);
+			wv_sync();
+			flags = wv_bcast(flags,0); if ( flags ) return false;
+			req = wv_bcast(req,0);
+			if ( !req ) break;
+			// middle piece of a stretch split twice: temporary pool entry npool with its own feasibility
+			uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
+			nwF = wv_bcast(nwF,0); nwR = wv_bcast(nwR,0);
+			if ( npool+1 > CT::scap ) { over(32); return false; }
+			if ( lane == 0 ) makePiece(npool,par,ma,mb);
+			wv_sync();
+			computeStretchFeas(npool,npool+1);
+			flags = wv_or(flags); if ( flags ) return false;
+			if ( lane == 0 ) pl_midready = true;
 		}
 		PROF(*this,12)
-#if defined(DACC_EMUL) && defined(DACC_FSTATS)
-		fstat(8,rctop); fstat(9,np); fstat(10,conso);
-#endif
 		if ( lane == 0 )
 		{
 			uint32_t nch = 0;
-			while ( ncdh ) { FCC const c = L.cdh[0]; spop<FCC,true>(L.cdh,ncdh); spush<FCC,false>(L.ch,nch,c); }
-			while ( nch ) { L.acc[nacc++] = L.ch[0]; spop<FCC,false>(L.ch,nch); }
+			while ( ncdh ) { FCC const c = ldget(L.cdh()); spop<FCC,true>(L.cdh(),ncdh); spush<FCC,false>(L.ch(),nch,c); }
+			while ( nch ) { ldput(L.acc()+nacc,ldget(L.ch())); ++nacc; spop<FCC,false>(L.ch(),nch); }
 		}
 		wv_sync();
 		uint32_t const nc = wv_bcast(nacc,0);
@@ -1429,7 +1528,7 @@ struct FastEngine
 		for ( uint32_t t = lane; t < nc*mao; t += WSZ )
 		{
 			uint32_t const c = t / mao, j = t - c*mao;
-			L.canderr[t] = myersDistance(j,G.cons + L.acc[c].o,L.acc[c].l);
+			L.canderr()[t] = myersDistance(j,G.cons + L.acc()[c].o,L.acc()[c].l);
 		}
 		wv_sync();
 		if ( lane == 0 )
@@ -1437,22 +1536,22 @@ struct FastEngine
 			for ( uint32_t c = 0; c < nc; ++c )
 			{
 				uint32_t s = 0;
-				for ( uint32_t j = 0; j < mao; ++j ) s += L.canderr[c*mao+j];
-				L.accerr[c] = s;
+				for ( uint32_t j = 0; j < mao; ++j ) s += L.canderr()[c*mao+j];
+				L.accerr()[c] = s;
 			}
 			for ( uint32_t i = 1; i < nc; ++i )
 			{
-				FCC const v = L.acc[i]; uint32_t const e = L.accerr[i];
-				if ( e < L.accerr[0] )
+				FCC const v = ldget(L.acc()+i); uint32_t const e = L.accerr()[i];
+				if ( e < L.accerr()[0] )
 				{
-					for ( uint32_t q = i; q > 0; --q ) { L.acc[q] = L.acc[q-1]; L.accerr[q] = L.accerr[q-1]; }
-					L.acc[0] = v; L.accerr[0] = e;
+					for ( uint32_t q = i; q > 0; --q ) { ldput(L.acc()+q,ldget(L.acc()+q-1)); L.accerr()[q] = L.accerr()[q-1]; }
+					ldput(L.acc(),v); L.accerr()[0] = e;
 				}
 				else
 				{
 					uint32_t q = i;
-					while ( e < L.accerr[q-1] ) { L.acc[q] = L.acc[q-1]; L.accerr[q] = L.accerr[q-1]; --q; }
-					L.acc[q] = v; L.accerr[q] = e;
+					while ( e < L.accerr()[q-1] ) { ldput(L.acc()+q,ldget(L.acc()+q-1)); L.accerr()[q] = L.accerr()[q-1]; --q; }
+					ldput(L.acc()+q,v); L.accerr()[q] = e;
 				}
 			}
 		}
@@ -1467,7 +1566,7 @@ struct FastEngine
 		uint32_t mn = 0xFFFFFFFFu, mx = 0;
 		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
-			uint32_t const len = L.slen[j];
+			uint32_t const len = L.slen()[j];
 			uint32_t const lastpos = len ? len-1 : 0;
 			mn = lastpos < mn ? lastpos : mn; mx = lastpos > mx ? lastpos : mx;
 		}
@@ -1485,7 +1584,7 @@ struct FastEngine
 				vprod = 1.0;
 				for ( uint32_t j = 0; j < mao; ++j )
 				{
-					uint32_t const len = L.slen[j];
+					uint32_t const len = L.slen()[j];
 					if ( len ) vprod *= ((len-1) < static_cast<uint32_t>(T.nsup) ? row[len-1] : 0.0);
 				}
 			}
@@ -1506,7 +1605,7 @@ struct FastEngine
 			if ( lane == 0 )
 			{
 				uint32_t maxlen = 0;
-				for ( uint32_t j = 0; j < mao; ++j ) maxlen = L.slen[j] > maxlen ? L.slen[j] : maxlen;
+				for ( uint32_t j = 0; j < mao; ++j ) maxlen = L.slen()[j] > maxlen ? L.slen()[j] : maxlen;
 				int32_t maxoff = -1; double maxoffv = DACC_DBL_MIN;
 				for ( int32_t i = 0; i < T.nrows; ++i )
 				{
@@ -1519,7 +1618,7 @@ struct FastEngine
 						if ( jj < maxlen+1 )
 						{
 							uint32_t cnt = 0;
-							for ( uint32_t j = 0; j < mao; ++j ) cnt += (L.slen[j] == jj);
+							for ( uint32_t j = 0; j < mao; ++j ) cnt += (L.slen()[j] == jj);
 							double const o = cnt ? static_cast<double>(cnt-1) : 0.0;
 							sdot += V[jj] * o;
 						}
@@ -1534,14 +1633,14 @@ struct FastEngine
 		return maxvprodindex;
 	}
 
-	DEV void alignAndEmit(uint8_t const * cons, uint32_t const n, uint8_t * rec)
+	DEV void alignAndEmit(GLBQ uint8_t const * cons, uint32_t const n, uint8_t * rec)
 	{
 		uint32_t const m = P.w;
-		uint8_t const * a = L.str;
-		uint64_t const * PEQ = L.peq;
+		LDSQ uint8_t const * a = L.str();
+		LDSQ uint64_t const * PEQ = L.peq();
 		uint64_t const mask = (m == 64) ? ~0ull : ((1ull<<m)-1);
 		uint64_t Pv = mask, Mv = 0; uint32_t score = m;
-		L.alpv[0] = Pv; L.almv[0] = Mv; L.albot[0] = m;
+		L.alpv()[0] = Pv; L.almv()[0] = Mv; L.albot()[0] = m;
 		uint64_t const top = 1ull<<(m-1);
 		for ( uint32_t c = 0; c < n; ++c )
 		{
@@ -1554,7 +1653,7 @@ struct FastEngine
 			Ph = (Ph<<1) | 1ull; Mh <<= 1;
 			Pv = (Mh | ~(Xv | Ph)) & mask;
 			Mv = (Ph & Xv) & mask;
-			L.alpv[c+1] = Pv; L.almv[c+1] = Mv; L.albot[c+1] = score;
+			L.alpv()[c+1] = Pv; L.almv()[c+1] = Mv; L.albot()[c+1] = score;
 		}
 		uint32_t i = m, j = n; uint32_t d = score; uint32_t nops = 0;
 		while ( i || j )
@@ -1563,17 +1662,17 @@ struct FastEngine
 			if ( i && j )
 			{
 				uint64_t const sh = i-1;
-				uint32_t const dd = L.albot[j-1] - dacc_popc64(L.alpv[j-1]>>sh) + dacc_popc64(L.almv[j-1]>>sh);
+				uint32_t const dd = L.albot()[j-1] - dacc_popc64(L.alpv()[j-1]>>sh) + dacc_popc64(L.almv()[j-1]>>sh);
 				uint32_t const neq = (a[i-1] != cons[j-1]);
 				if ( dd + neq == d ) { op = neq ? 1 : 0; --i; --j; d = dd; done = true; }
 			}
 			if ( !done && i )
 			{
 				uint64_t const bit = 1ull<<(i-1);
-				if ( L.alpv[j] & bit ) { op = 3; --i; d = d-1; done = true; }
+				if ( L.alpv()[j] & bit ) { op = 3; --i; d = d-1; done = true; }
 			}
 			if ( !done ) { op = 2; --j; d = d-1; }
-			L.alops[nops++] = op;
+			L.alops()[nops++] = op;
 		}
 		uint8_t * off = rec+1; uint8_t * sym = rec + 1 + (m+2);
 		rec[0] = 1;
@@ -1581,10 +1680,10 @@ struct FastEngine
 		for ( uint32_t r = 0; r <= m; ++r )
 		{
 			off[r] = so;
-			while ( t && L.alops[t-1] == 2 ) { sym[so++] = cons[cpos++]; --t; }
+			while ( t && L.alops()[t-1] == 2 ) { sym[so++] = cons[cpos++]; --t; }
 			if ( r < m )
 			{
-				uint32_t const op = L.alops[--t];
+				uint32_t const op = L.alops()[--t];
 				sym[so++] = (op == 3) ? 4 : cons[cpos++];
 			}
 		}
@@ -1593,15 +1692,16 @@ struct FastEngine
 };
 
 // returns true if the window was completed on the fast path, false if it must be re-run generically
-DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * lds, uint8_t * garena)
+template<typename CT>
+DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, uint8_t * garena)
 {
 	WindowBatch const & B = FB.W;
-	FastEngine E;
-	E.C = FB.F; E.T = B.T; E.P = B.P;
+	FastEngine<CT> E;
+	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
-	fast_lds_carve(E.L,lds,FB.F);
-	fast_global_carve(E.G,garena,FB.F);
-	FastLds & L = E.L;
+	E.L.base = lds;
+	E.G.cons = (GLBQ uint8_t *)garena;
+	FastLds<CT> const & L = E.L;
 	int const lane = E.lane;
 	PROF_T0
 	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); } return false; }
@@ -1626,40 +1726,40 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 		uint32_t act = 0;
 		if ( z < pile.novl ) act = (ov[z].abpos <= static_cast<int32_t>(astart)) && (ov[z].aepos >= static_cast<int32_t>(aend));
 		uint32_t tot; uint32_t const pre = wv_scan_excl(act,tot);
-		if ( act && nact+pre < FB.F.precap ) L.pre[nact+pre] = (static_cast<uint64_t>(ov[z].ekey)<<32) | z;
+		if ( act && nact+pre < CT::precap ) L.pre()[nact+pre] = (static_cast<uint64_t>(ov[z].ekey)<<32) | z;
 		nact += tot;
 	}
-	if ( nact > FB.F.precap ) { FFAIL(2) }
+	if ( nact > CT::precap ) { FFAIL(2) }
 	uint32_t const ap2 = next_pow2(nact < 2 ? 2 : nact);
-	for ( uint32_t i = nact + lane; i < ap2; i += WSZ ) L.pre[i] = ~0ull;
+	for ( uint32_t i = nact + lane; i < ap2; i += WSZ ) L.pre()[i] = ~0ull;
 	wv_sync();
-	wv_bitonic_sort(L.pre,ap2);
+	wv_bitonic_sort(L.pre(),ap2);
 	uint32_t mao = 0;
 	if ( nact )
 	{
 		uint64_t const nb = (B.P.maxalign > 0) ? (B.P.maxalign-1) : 0;
 		mao = 1 + static_cast<uint32_t>(nact < nb ? nact : nb);
 	}
-	if ( mao > FB.F.maxs ) { FFAIL(3) }
+	if ( mao > CT::maxs ) { FFAIL(3) }
 	E.mao = mao; out.mao = mao;
 
 	uint32_t toolong = 0;
 	if ( mao )
 	{
 		uint64_t const aoff = B.boff[pile.aread];
-		for ( uint32_t p = lane; p < B.P.w; p += WSZ ) L.str[p] = readBase(B.bps,aoff,B.rlen[pile.aread],false,astart+p);
-		if ( lane == 0 ) L.slen[0] = B.P.w;
+		for ( uint32_t p = lane; p < B.P.w; p += WSZ ) L.str()[p] = readBase(B.bps,aoff,B.rlen[pile.aread],false,astart+p);
+		if ( lane == 0 ) L.slen()[0] = B.P.w;
 		for ( uint32_t j = 1; j < mao; ++j )
 		{
-			uint32_t const z = static_cast<uint32_t>(L.pre[j-1] & 0xFFFFFFFFu);
+			uint32_t const z = static_cast<uint32_t>(L.pre()[j-1] & 0xFFFFFFFFu);
 			DevOvl const & o = ov[z];
 			uint64_t const row = o.wtoff + (y - o.y0);
 			uint32_t const bs = B.wt_b[row], be = B.wt_e[row];
 			uint32_t const len = be-bs;
 			if ( len > 64 ) { toolong = 1; continue; }
 			uint64_t const off = B.boff[o.bread]; uint32_t const rl = B.rlen[o.bread]; bool const inv = o.flags & 1;
-			for ( uint32_t p = lane; p < len; p += WSZ ) L.str[j*64+p] = readBase(B.bps,off,rl,inv,bs+p);
-			if ( lane == 0 ) L.slen[j] = len;
+			for ( uint32_t p = lane; p < len; p += WSZ ) L.str()[j*64+p] = readBase(B.bps,off,rl,inv,bs+p);
+			if ( lane == 0 ) L.slen()[j] = len;
 		}
 	}
 	wv_sync();
@@ -1681,7 +1781,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 		uint64_t minrate = B.P.eminrate;
 		bool haveMin = false;
 		uint32_t bestlen = 0;
-		uint8_t * best = E.G.cons + (FB.F.conscap - MAXCONS);
+		GLBQ uint8_t * best = E.G.cons + (CT::conscap - MAXCONS);
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh; ++k )
 		{
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
@@ -1714,13 +1814,13 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, uint8_t * 
 					if ( E.flags ) { FFAIL(8) }
 					if ( consok )
 					{
-						uint64_t const err = L.accerr[0];
+						uint64_t const err = L.accerr()[0];
 						if ( err < minrate )
 						{
 							lconsok = true; minrate = err; haveMin = true;
-							bestlen = L.acc[0].l;
+							bestlen = L.acc()[0].l;
 							if ( bestlen > MAXCONS ) { FFAIL(9) }
-							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = E.G.cons[L.acc[0].o+i];
+							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = E.G.cons[L.acc()[0].o+i];
 							out.k = k; out.filterfreq = ff;
 							wv_sync();
 						}

@@ -28,6 +28,8 @@
   static inline int wv_any(int p) { return p; }
   static inline uint32_t wv_or(uint32_t v) { return v; }
   static inline uint64_t wv_or64(uint64_t v) { return v; }
+  static inline uint64_t wv_ballot(int p) { return p ? 1ull : 0ull; }
+  static inline uint64_t wv_lanemask_lt() { return 0ull; }
   static inline uint32_t wv_bcast(uint32_t v, int) { return v; }
   static inline uint64_t wv_bcast64(uint64_t v, int) { return v; }
   static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
@@ -98,6 +100,8 @@
 	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
 	return v;
   }
+  DEV uint64_t wv_ballot(int p) { return __ballot(p); }
+  DEV uint64_t wv_lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
   DEV uint32_t wv_bcast(uint32_t v, int src) { return __shfl(v,src,64); }
   DEV uint64_t wv_bcast64(uint64_t v, int src) { return __shfl(v,src,64); }
   DEV int dacc_popc64(uint64_t v) { return __popcll(v); }
@@ -105,10 +109,20 @@
   }
 #endif
 
+// address space qualifiers: on the device LDS pointers are 32 bit ds_* addresses, on the host (planning, emulation) plain pointers
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LDSQ __attribute__((address_space(3)))
+#define GLBQ __attribute__((address_space(1)))
+#else
+#define LDSQ
+#define GLBQ
+#endif
+
 namespace dacc {
 
 // ascending bitonic sort of n64 (power of two) 64-bit keys in memory; all lanes call
-DEV void wv_bitonic_sort(uint64_t * A, uint32_t const n)
+template<typename PT>
+DEV void wv_bitonic_sort(PT A, uint32_t const n)
 {
 	int const lane = wv_lane();
 	for ( uint32_t k = 2; k <= n; k <<= 1 )

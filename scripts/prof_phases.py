@@ -9,6 +9,7 @@ from daccord_amd.synth import SynthData
 NAMES = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors", "feasible", "gapfill", "firstlast",
          "stretches", "stretchfeas", "stretchlinks", "reverse-enum", "forward+pairs", "cand-errors", "align+emit", "-",
          " s:predcounts", " s:walk1", " s:walk2", " s:splits", " s:sort+uniq"]
+EXTRA = {21: "pairs exact (count)", 22: "R enum cycles", 23: "F enum cycles", 24: "combine cycles", 25: "R enums (count)", 26: "F enums (count)", 27: "pairs (count)", 28: "pairs pruned (count)"}
 npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 d = SynthData(250000, 1000, 5000, seed=3)
 ovl, piles = engine.pile_select(d.ovl, d.piles)
@@ -25,5 +26,7 @@ for k in (8, 14):
         for i, n in enumerate(NAMES):
             print("  %-16s %6.2f%%  %10.0f cyc/window" % (n, 100 * pr[i] / tot, pr[i] / max(1, t.nwindows)))
         print("  total cyc/window %.0f" % (tot / max(1, t.nwindows)))
+        for i, n in EXTRA.items():
+            print("  %-22s %12.1f per window" % (n, pr[i] / max(1, t.nwindows)))
         print("  block lifetime: clock64 sum %.3e wall_clock64 sum %.3e (100MHz) max wall %.3f ms; ratio clock/wall %.2f" % (pr[30], pr[31], pr[29]/1e5, pr[30]/max(pr[31],1)))
     E.close()

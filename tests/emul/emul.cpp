@@ -9,6 +9,10 @@
 #include <string>
 #include <cstring>
 #include <cstdlib>
+#if defined(DACC_FSTATS)
+namespace dacc { uint32_t g_fstat[16]; }
+static std::vector<uint32_t> g_all;
+#endif
 #include "../../daccord_amd/csrc/batch_plan.hpp"
 #include "../../daccord_amd/csrc/host_tables.hpp"
 #include "../../daccord_amd/csrc/window_main.hpp"
@@ -128,22 +132,22 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		FastBatch FB2 = FB; FB2.F = BP.fcaps2;
 		std::vector<uint8_t> lds(BP.fcaps.ldsbytes+64), garena(BP.fcaps.gbytes+64), lds2(BP.fcaps2.ldsbytes+64), garena2(BP.fcaps2.gbytes+64);
 		c->nfast = 0; c->nretry = 0; c->nfast2 = 0; for ( int i = 0; i < 64; ++i ) { c->reasons[i] = 0; c->reasons2[i] = 0; } for ( int i = 0; i < 24; ++i ) { c->flagbits[i] = 0; c->flagbits2[i] = 0; }
-		{ FastLds L; fast_lds_carve(L,lds.data(),BP.fcaps); fast_load_tables(L,BP.fcaps,T,c->H.dpsq_vst.data()); }
-		{ FastLds L; fast_lds_carve(L,lds2.data(),BP.fcaps2); fast_load_tables(L,BP.fcaps2,T,c->H.dpsq_vst.data()); }
+		{ FastLds< FastTier<1> > L; L.base = lds.data(); fast_load_tables(L,BP.fcaps.nrows,BP.fcaps.nsup,T,c->H.dpsq_vst.data()); }
+		{ FastLds< FastTier<2> > L; L.base = lds2.data(); fast_load_tables(L,BP.fcaps2.nrows,BP.fcaps2.nsup,T,c->H.dpsq_vst.data()); }
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
-		bool const usefast = c->usefast && !big && c->H.nrows <= 64;
+		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
 		{
 #if defined(DACC_FSTATS)
 			for ( int i = 0; i < 16; ++i ) dacc::g_fstat[i] = 0;
 #endif
-			bool fast = usefast && processWindowFast(FB,wdx,lds.data(),garena.data());
+			bool fast = usefast && processWindowFast< FastTier<1> >(FB,wdx,lds.data(),garena.data());
 #if defined(DACC_FSTATS)
 			for ( int i = 0; i < 16; ++i ) g_all.push_back(dacc::g_fstat[i]);
 #endif
 			if ( fast ) { ++c->nfast; continue; }
 			if ( usefast ) { uint32_t const f = wout[wdx].flags; c->reasons[(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbits[b]++; }
-			fast = usefast && processWindowFast(FB2,wdx,lds2.data(),garena2.data());
+			fast = usefast && processWindowFast< FastTier<2> >(FB2,wdx,lds2.data(),garena2.data());
 			if ( fast ) { ++c->nfast2; continue; }
 			if ( usefast ) { uint32_t const f = wout[wdx].flags; c->reasons2[(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbits2[b]++; }
 			++c->nretry; processWindow(WB,wdx,arena.data());

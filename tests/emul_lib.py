@@ -10,7 +10,7 @@ _ROOT = os.path.dirname(_HERE)
 sys.path.insert(0, _ROOT)
 from daccord_amd._structs import DaccParams, DaccFragment, DaccWindowResult  # noqa: E402
 
-_SO = os.path.join(_HERE, "emul", "libdacc_emul.so")
+_SO = os.environ.get("DACC_EMUL_LIB") or os.path.join(_HERE, "emul", "libdacc_emul.so")
 _SRCS = [os.path.join(_HERE, "emul", "emul.cpp")] + [os.path.join(_ROOT, "daccord_amd", "csrc", f)
                                                       for f in os.listdir(os.path.join(_ROOT, "daccord_amd", "csrc"))
                                                       if f.endswith((".hpp", ".cpp"))]
