@@ -53,54 +53,57 @@ __global__ void __launch_bounds__(256) k_trace(TraceBatch B)
 // placement, used for L2 affinity only): give every XCD a contiguous run of windows so that the
 // windows of one pile (which share the pile's overlaps and reads) hit one L2.
 // generic engine: all windows (list == 0) or the windows the LDS fast path handed back (list[0] = count)
-__global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag, uint32_t const * list)
+// Windows differ in cost by orders of magnitude, so the workgroups pull window indices from a counter (*work).
+__global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag, uint32_t const * list, uint32_t * work)
 {
-	uint32_t const G = gridDim.x;
-	uint32_t const b = blockIdx.x;
-	uint32_t const perx = G >> 3;
-	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
-	uint8_t * arena = B.arena + static_cast<uint64_t>(b)*B.C.bytes;
+	uint8_t * arena = B.arena + static_cast<uint64_t>(blockIdx.x)*B.C.bytes;
 	uint64_t const n = list ? list[0] : B.nwindows;
-	for ( uint64_t base = 0; base < n; base += G )
+	uint32_t it = 0;
+	while ( true )
 	{
-		uint64_t const i = base + (list ? b : slot);
-		if ( i < n )
+		uint32_t i = 0;
+		if ( work )
 		{
-			uint64_t const w = list ? list[1+i] : i;
-			processWindow(B,w,arena);
-			if ( threadIdx.x == 0 && B.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
+			if ( threadIdx.x == 0 ) i = atomicAdd(work,1u);
+			i = __builtin_amdgcn_readfirstlane(i);
 		}
+		else { i = it*gridDim.x + blockIdx.x; ++it; }
+		if ( i >= n ) break;
+		uint64_t const w = list ? list[1+i] : i;
+		processWindow(B,w,arena);
+		if ( threadIdx.x == 0 && B.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
 	}
 }
 
 // LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice.
 // list == 0: all windows; else the windows a smaller capacity tier handed over.  Windows that do not fit go to FB.retry.
 template<int TIER>
-__global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const * list)
+__global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const * list, uint32_t * work)
 {
 	typedef FastTier<TIER> CT;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
 	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
-	uint32_t const G = gridDim.x;
-	uint32_t const b = blockIdx.x;
-	uint32_t const perx = G >> 3;
-	uint32_t const slot = (G & 7) ? b : ((b & 7)*perx + (b >> 3));
-	uint8_t * garena = FB.garena + static_cast<uint64_t>(b)*FB.F.gbytes;
+	uint8_t * garena = 0;
 	{ FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
 #if defined(DACC_PROFILE)
 	uint64_t const t0c = clock64(), t0w = wall_clock64();
 #endif
 	uint64_t const n = list ? list[0] : FB.W.nwindows;
-	for ( uint64_t base = 0; base < n; base += G )
+	uint32_t it = 0;
+	while ( true )
 	{
-		uint64_t const i = base + (list ? b : slot);
-		if ( i < n )
+		uint32_t i = 0;
+		if ( work )
 		{
-			uint64_t const w = list ? list[1+i] : i;
-			bool const done = processWindowFast<CT>(FB,w,lds,garena);
-			if ( !done && threadIdx.x == 0 ) { uint32_t const q = atomicAdd(FB.retry,1u); FB.retry[1+q] = static_cast<uint32_t>(w); }
-			__syncthreads();
+			if ( threadIdx.x == 0 ) i = atomicAdd(work,1u);
+			i = __builtin_amdgcn_readfirstlane(i);
 		}
+		else { i = it*gridDim.x + blockIdx.x; ++it; }
+		if ( i >= n ) break;
+		uint64_t const w = list ? list[1+i] : i;
+		bool const done = processWindowFast<CT>(FB,w,lds,garena);
+		if ( !done && threadIdx.x == 0 ) { uint32_t const q = atomicAdd(FB.retry,1u); FB.retry[1+q] = static_cast<uint32_t>(w); }
+		__syncthreads();
 	}
 #if defined(DACC_PROFILE)
 	if ( threadIdx.x == 0 && FB.W.prof && !list ) { atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+30),static_cast<unsigned long long>(clock64()-t0c)); atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+31),static_cast<unsigned long long>(wall_clock64()-t0w)); atomicMax(reinterpret_cast<unsigned long long *>(FB.W.prof+29),static_cast<unsigned long long>(wall_clock64()-t0w)); }
@@ -166,7 +169,7 @@ struct dacc_ctx
 	dacc_params par;
 	int device;
 	hipStream_t stream;
-	hipEvent_t ev[6]; hipEvent_t evfast; float fast_ms;
+	hipEvent_t ev[6]; hipEvent_t evfast; hipEvent_t evfast2; float fast_ms;
 	std::string err;
 	bool haveprofile, havedb, havebatch;
 	double est_cor;
@@ -182,8 +185,8 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint8_t> d_garena, d_garena2; DevBuf<uint32_t> d_retry, d_retry2;
-	uint32_t fast_grid, fast2_grid, retry_grid; int usefast; uint32_t nretry_last, nretry2_last;
+	DevBuf<uint64_t> d_vst; DevBuf<uint8_t> d_garena, d_garena2; DevBuf<uint32_t> d_retry, d_retry2, d_work;
+	uint32_t fast_grid, fast2_grid, retry_grid; int usefast; int sched; uint32_t nretry_last, nretry2_last;
 	uint32_t tr_threads, win_grid;
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
@@ -219,7 +222,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	std::memset(&c->timing,0,sizeof(c->timing));
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
-	hipEventCreate(&c->evfast); c->fast_ms = 0;
+	hipEventCreate(&c->evfast); hipEventCreate(&c->evfast2); c->fast_ms = 0;
 	*out = c;
 	return DACC_OK;
 }
@@ -233,7 +236,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_garena.release(); c->d_retry.release(); c->d_garena2.release(); c->d_retry2.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_garena.release(); c->d_retry.release(); c->d_garena2.release(); c->d_retry2.release(); c->d_work.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -331,17 +334,19 @@ static int runDevice(dacc_ctx * c)
 		{
 			HIPCHK(hipMemsetAsync(c->d_retry.p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_retry2.p,0,sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s));
 			FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->d_vst.p; FB.garena = c->d_garena.p; FB.retry = c->d_retry.p;
-			hipLaunchKernelGGL(k_window_fast<1>,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB,static_cast<uint32_t const *>(0));
+			hipLaunchKernelGGL(k_window_fast<1>,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB,static_cast<uint32_t const *>(0),(c->sched&1) ? c->d_work.p : static_cast<uint32_t *>(0));
 			hipEventRecord(c->evfast,s);
 			// second tier: the windows that overflowed the small LDS layout, one wavefront per CU with a large layout
 			FastBatch FB2 = FB; FB2.F = BP.fcaps2; FB2.garena = c->d_garena2.p; FB2.retry = c->d_retry2.p;
-			hipLaunchKernelGGL(k_window_fast<2>,dim3(c->fast2_grid),dim3(64),BP.fcaps2.ldsbytes,s,FB2,static_cast<uint32_t const *>(c->d_retry.p));
+			hipLaunchKernelGGL(k_window_fast<2>,dim3(c->fast2_grid),dim3(64),BP.fcaps2.ldsbytes,s,FB2,static_cast<uint32_t const *>(c->d_retry.p),(c->sched&1) ? c->d_work.p+1 : static_cast<uint32_t *>(0));
+			hipEventRecord(c->evfast2,s);
 			// what is left (rare shapes) goes through the generic engine
-			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_retry2.p));
+			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_retry2.p),(c->sched&2) ? c->d_work.p+2 : static_cast<uint32_t *>(0));
 		}
 		else
-			hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0));
+			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+2 : static_cast<uint32_t *>(0)); }
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
 	if ( BP.piles.size() )
@@ -389,7 +394,7 @@ static int runDevice(dacc_ctx * c)
 	float ms = 0;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[1]); c->timing.trace_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[1],c->ev[2]); c->timing.window_ms = ms;
-	if ( c->usefast && BP.nwindows ) { hipEventElapsedTime(&ms,c->ev[1],c->evfast); c->timing.fast_ms = ms; } else c->timing.fast_ms = 0;
+	if ( c->usefast && BP.nwindows ) { hipEventElapsedTime(&ms,c->ev[1],c->evfast); c->timing.fast_ms = ms; hipEventElapsedTime(&ms,c->evfast,c->evfast2); c->timing.fast2_ms = ms; } else { c->timing.fast_ms = 0; c->timing.fast2_ms = 0; }
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
@@ -436,8 +441,10 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	{
 		char const * e = getenv("DACC_NOFAST");
 		c->usefast = !(e && e[0] == '1');
+		char const * sc = getenv("DACC_SCHED");   // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
+		c->sched = sc ? atoi(sc) : 1;
 		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
-		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP ) c->usefast = 0;
+		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP || (c->H.nrows+1)*c->H.nsup > FastLds< FastTier<1> >::tabcap ) c->usefast = 0;
 	}
 	if ( c->usefast )
 	{
@@ -452,15 +459,15 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		c->fast_grid = fg;
 		c->retry_grid = wg < 512 ? wg : 512;
 		c->win_grid = c->retry_grid;
-		HIPCHK(c->d_garena.ensure(fg*BP.fcaps.gbytes));
 		c->fast2_grid = fg < 256 ? fg : 256;
-		HIPCHK(c->d_garena2.ensure(static_cast<size_t>(c->fast2_grid)*BP.fcaps2.gbytes));
 		HIPCHK(c->d_retry.ensure(BP.nwindows+2)); HIPCHK(c->d_retry2.ensure(BP.nwindows+2));
+		HIPCHK(c->d_work.ensure(4));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));
 	}
 	else
 	{
 		c->win_grid = wg;
+		HIPCHK(c->d_work.ensure(4));
 		HIPCHK(c->d_arena.ensure(wg*BP.caps.bytes));
 	}
 	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));

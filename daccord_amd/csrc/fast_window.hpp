@@ -42,7 +42,8 @@ namespace dacc {
 enum { WS_RETRY = 4 };
 enum { FNC = 48 };          // max first / last k-mer candidates on the fast path
 enum { FNOPAR = 0xFF };
-enum { FSUPCAP = 128 };     // max width (read offsets) of the model table copy in LDS
+enum { FSUPCAP = 128 };
+enum { FSEQCAP = 48 };      // max stretches of one candidate path     // max width (read offsets) of the model table copy in LDS
 
 // run time description of a capacity tier (host planning, launch parameters)
 struct FastCaps
@@ -58,8 +59,8 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1408, rccap = 256, fcap = 224, siqcap = 128, blcap = 96, conscap = 16384 + MAXCONS }; };
-template<> struct FastTier<2> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2560, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
+template<> struct FastTier<1> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<2> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -103,7 +104,9 @@ struct FastLds
 	FLD(vrem,uint8_t,8,e_suphi8)
 	FLD(vadd,uint8_t,8,e_vrem)
 	FLD(vapos,uint8_t,8,e_vadd)
-	FLD(sstack,uint8_t,3*24,e_vapos)
+	FLD(vfn,uint16_t,8,e_vapos)
+	FLD(vln,uint16_t,8,e_vfn)
+	FLD(sstack,uint8_t,3*24,e_vln)
 	FLD(chain,uint8_t,64,e_sstack)
 	static constexpr uint32_t ubase = e_chain;
 	// ---- overlay A: build phase ----
@@ -120,9 +123,23 @@ struct FastLds
 	FLD(woffF,uint16_t,CT::scap,e_maskR)
 	FLD(woffR,uint16_t,CT::scap,e_woffF)
 	FLD(links,uint16_t,CT::lcap,e_woffR)
-	FLD(wuF,uint64_t,CT::wcap,e_links)
-	FLD(wuR,uint64_t,CT::wcap,e_wuF)
-	FLD(fkmer,uint32_t,FNC,e_wuR)
+	// weights of the feasible (stretch, position) pairs: whole stretch (48 bit), its first node in walking direction and,
+	// forward only, its last node (40 bit each), split into 32 bit low words and high parts
+	FLD(wF_lo,uint32_t,CT::wcap,e_links)
+	FLD(wF1_lo,uint32_t,CT::wcap,e_wF_lo)
+	FLD(wFl_lo,uint32_t,CT::wcap,e_wF1_lo)
+	FLD(wR_lo,uint32_t,CT::wcap,e_wFl_lo)
+	FLD(wR1_lo,uint32_t,CT::wcap,e_wR_lo)
+	FLD(wF_hi,uint16_t,CT::wcap,e_wR1_lo)
+	FLD(wR_hi,uint16_t,CT::wcap,e_wF_hi)
+	FLD(wF1_hi,uint8_t,CT::wcap,e_wR_hi)
+	FLD(wFl_hi,uint8_t,CT::wcap,e_wF1_hi)
+	FLD(wR1_hi,uint8_t,CT::wcap,e_wFl_hi)
+	// lookup of stretches by first / last node: head index per node, base stretches ordered by (last node, id)
+	FLD(lhead,uint8_t,CT::ncap,e_wR1_hi)
+	FLD(lord,uint32_t,CT::scap,e_lhead)
+	FLD(ppos,uint8_t,CT::scap,e_lord)      // pieces: number of base stretches sorting before them
+	FLD(fkmer,uint32_t,FNC,e_ppos)
 	FLD(lkmer,uint32_t,FNC,e_fkmer)
 	FLD(fnode,uint16_t,FNC,e_lkmer)
 	FLD(lnode,uint16_t,FNC,e_fnode)
@@ -136,10 +153,11 @@ struct FastLds
 	FLD(ch,FCC,16,e_cdh)
 	FLD(acc,FCC,16,e_ch)
 	FLD(accerr,uint32_t,16,e_acc)
-	FLD(canderr,uint16_t,16*CT::maxs,e_accerr)
-	FLD(prevstr,uint8_t,MAXCONS,e_canderr)
-	FLD(curstr,uint8_t,MAXCONS,e_prevstr)
-	static constexpr uint32_t pbase = e_curstr;
+	FLD(bestL,uint8_t,MAXCONS,e_accerr)    // best consensus so far (survives the tries)
+	FLD(canderr,uint8_t,16*CT::maxs,e_bestL)
+	FLD(cseq,uint8_t,18*FSEQCAP,e_canderr)      // stretch sequences of the kept candidates (16 slots) + current + previous
+	FLD(consL,uint8_t,16*MAXCONS,e_cseq)   // decoded candidates
+	static constexpr uint32_t pbase = e_consL;
 	// reverse cache
 	FLD(rc_w,uint64_t,CT::rccap,pbase)
 	FLD(rc_parent,uint8_t,CT::rccap,e_rc_w)
@@ -149,7 +167,9 @@ struct FastLds
 	FLD(rc_baselen,uint8_t,CT::rccap,e_rc_len)
 	FLD(rc_ord,uint8_t,CT::rccap,e_rc_baselen)
 	FLD(rc_arw,uint8_t,CT::rccap,e_rc_ord)
-	FLD(rbase,uint16_t,FNC+1,e_rc_arw)
+	FLD(rc_sbl,uint8_t,CT::rccap,e_rc_arw)         // base length of the i-th entry in sorted order
+	FLD(rc_front,uint32_t,CT::rccap,e_rc_sbl)      // front k-mer of the i-th entry in sorted order
+	FLD(rbase,uint16_t,FNC+1,e_rc_front)
 	FLD(rn,uint8_t,FNC+1,e_rbase)
 	FLD(rnpool,uint8_t,FNC+1,e_rn)
 	FLD(rvalid,uint8_t,FNC+1,e_rnpool)
@@ -163,8 +183,12 @@ struct FastLds
 	FLD(f_baselen,uint8_t,CT::fcap,e_f_pos)
 	FLD(f_len,uint8_t,CT::fcap,e_f_baselen)
 	FLD(fpop,uint8_t,CT::fcap,e_f_len)
+	// per popped path (pop order): k-mer of its last node, candidate length, weight minus the junction node
+	FLD(fp_cl,uint8_t,CT::fcap,e_fpop)
+	FLD(fp_front,uint32_t,CT::fcap,e_fp_cl)
+	FLD(fp_adj,uint64_t,CT::fcap,e_fp_front)
 	// heaps
-	FLD(rpst,uint8_t,256,e_fpop)
+	FLD(rpst,uint8_t,256,e_fp_adj)
 	FLD(hbl,uint8_t,CT::blcap*12,e_rpst)
 	FLD(hbl_n,uint8_t,CT::blcap,e_hbl)
 	FLD(siq,FSI,CT::siqcap,e_hbl_n)
@@ -184,11 +208,14 @@ struct FastLds
 	static constexpr uint32_t ualn = e_alops;
 	static constexpr uint32_t uend = fcmax(fcmax(uA,uraw),fcmax(upool,ualn));
 	// scratch behind the build overlay (gap filling)
-	FLD(gfbuf,uint64_t,(uend-uA)/8,uA)
-	static constexpr uint32_t gfcap = (uend-uA)/8;
-	// fixed-point model table [pos][row], row stride nrows+1 (run time size, hence last)
-	FLD(tab,uint32_t,0,uend)
-	HDEV static uint32_t bytes(uint32_t const nrows, uint32_t const nsup) { return (uend + 4u*(nrows+1)*nsup + 15u) & ~15u; }
+	FLD(gfbuf,uint64_t,(pbase-uA)/8,uA)
+	static constexpr uint32_t gfcap = (pbase-uA)/8;
+	// fixed-point model table [pos][row], row stride nrows+1.  It shares the bytes of the enumeration pools: it is
+	// (re)loaded from HBM/L2 for gap filling and for the stretch feasibility of a traverse call, both of which are over
+	// before the pools are used.
+	FLD(tab,uint32_t,(upool-o_canderr)/4,o_canderr)   // also over the candidate buffers, which are dead at that time
+	static constexpr uint32_t tabcap = (upool-o_canderr)/4;
+	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
 };
 #undef FLD
 
@@ -215,16 +242,11 @@ struct FastBatch
 	uint32_t * retry;           // [0] = count, [1..] = window indices to re-run generically
 };
 
+// once per workgroup: the support bounds of the model table
 template<typename CT>
 DEV void fast_load_tables(FastLds<CT> const & L, uint32_t const nrows, uint32_t const nsup, DevTables const & T, uint64_t const * vst)
 {
 	int const lane = wv_lane();
-	// row stride nrows+1: the extra row is zero so that positions beyond the table can be clamped instead of branched on
-	for ( uint32_t i = lane; i < (nrows+1)*nsup; i += WSZ )
-	{
-		uint32_t const pos = i / (nrows+1), row = i - pos*(nrows+1);
-		L.tab()[i] = row < nrows ? static_cast<uint32_t>(vst[pos*nrows+row]) : 0u;
-	}
 	for ( uint32_t i = lane; i < nsup; i += WSZ ) { L.suplo8()[i] = T.suplo[i]; L.suphi8()[i] = T.suphi[i]; }
 	wv_sync();
 }
@@ -238,6 +260,7 @@ struct FastEngine
 {
 	FastLds<CT> L; FastGlobal G; DevTables T; DevParams P;
 	uint32_t nrows, nsup;
+	uint64_t const * vst;        // [nsup][nrows] fixed-point model table in HBM
 	int lane; uint32_t flags;
 	uint64_t * prof;
 	uint32_t mao, k; uint64_t kmask;
@@ -245,9 +268,8 @@ struct FastEngine
 	uint32_t n0, npool, nlinks, nwF, nwR;
 	uint32_t nF, nL;
 	uint32_t rctop;                      // used entries of the reverse cache
-	uint32_t np, nfpop, nsiq, ncdh, nacc, conso;
+	uint32_t np, nfpop, nsiq, ncdh, nacc;
 	int32_t fcur_fi; int32_t fcur_li;    // what the forward pool holds: F(fi) on view(fi) (li = -1) or an exact pair view
-	uint32_t prevlen;
 
 	DEV void over(uint32_t b) { flags |= b; }
 #if defined(DACC_PROFILE) && !defined(DACC_EMUL)
@@ -655,6 +677,19 @@ struct FastEngine
 		if ( wv_any(dup) ) { over(32); n0 = 0; return; }
 		n0 = ns;
 		wv_sync();
+		// lookup by first node (base order is sorted by it) and by last node (ordered by (last, id))
+		for ( uint32_t z = lane; z < nn; z += WSZ ) { L.npred()[z] = 0xFF; L.lhead()[z] = 0xFF; }
+		for ( uint32_t q = lane; q < p2; q += WSZ ) L.skey()[q] = q < ns ? ((static_cast<uint64_t>(L.slast()[q])<<8) | q) : ~0ull;
+		wv_sync();
+		for ( uint32_t q = lane; q < ns; q += WSZ ) if ( q == 0 || L.sfirst()[q-1] != L.sfirst()[q] ) L.npred()[L.sfirst()[q]] = q;
+		wv_bitonic_sort(L.skey(),p2);
+		for ( uint32_t q = lane; q < ns; q += WSZ )
+		{
+			uint64_t const e = L.skey()[q];
+			L.lord()[q] = static_cast<uint32_t>(e);
+			if ( q == 0 || (L.skey()[q-1]>>8) != (e>>8) ) L.lhead()[e>>8] = q;
+		}
+		wv_sync();
 	}
 
 	// pool stretch id = nodes [a,b] of parent stretch par
@@ -706,10 +741,30 @@ struct FastEngine
 		}
 		wv_sync();
 		npool = wv_bcast(npool,0);
+		for ( uint32_t id = n0 + lane; id < npool; id += WSZ ) L.ppos()[id] = basePos(id);
+		wv_sync();
 		fstat(12,nF); fstat(13,nL); fstat(14,npool); fstat(15,n0);
 	}
 
-	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions ----
+	// copy of the model table in LDS, row stride nrows+1: the extra row is zero so that positions beyond the table can be
+	// clamped instead of branched on
+	DEV void loadTab()
+	{
+		for ( uint32_t i = lane; i < (nrows+1)*nsup; i += WSZ )
+		{
+			uint32_t const pos = i / (nrows+1), row = i - pos*(nrows+1);
+			L.tab()[i] = row < nrows ? static_cast<uint32_t>(vst[pos*nrows+row]) : 0u;
+		}
+		wv_sync();
+	}
+	template<bool GT> DEV uint32_t tabAt(uint32_t const pos, uint32_t const pc, uint32_t const stride) const
+	{
+		if ( GT ) return pc < nrows ? static_cast<uint32_t>(vst[pos*nrows+pc]) : 0u;
+		else return L.tab()[pos*stride+pc];
+	}
+	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions; GT: read the table from HBM
+	// (middle pieces created while the LDS copy is overlaid by the enumeration pools) ----
+	template<bool GT>
 	DEV void computeStretchFeas(uint32_t const sfrom, uint32_t const sto)
 	{
 		uint32_t const stride = nrows+1;
@@ -724,7 +779,7 @@ struct FastEngine
 			{
 				uint32_t const Pp = c + lane;
 				bool ok = Pp < nrows, okr = ok;
-				uint64_t sum = 0, rsum = 0;
+				uint64_t sum = 0, rsum = 0, f1 = 0, fl = 0, r1 = 0;
 				for ( uint32_t j = 0; j < len; ++j )
 				{
 					uint32_t const p = Pp+j;
@@ -732,16 +787,29 @@ struct FastEngine
 					uint32_t const zf = Lk[j], zr = Lk[len-1-j];
 					uint32_t const i0f = L.nps()[zf], ff = L.nfreq()[zf], i0r = L.nps()[zr], fr = L.nfreq()[zr];
 					uint64_t uf = 0, ur = 0;
-					for ( uint32_t q = 0; q < ff; ++q ) uf += L.tab()[static_cast<uint32_t>(L.ipos()[i0f+q])*stride + pc];
-					for ( uint32_t q = 0; q < fr; ++q ) ur += L.tab()[static_cast<uint32_t>(L.irpos()[i0r+q])*stride + pc];
+					for ( uint32_t q = 0; q < ff; ++q ) uf += tabAt<GT>(L.ipos()[i0f+q],pc,stride);
+					for ( uint32_t q = 0; q < fr; ++q ) ur += tabAt<GT>(L.irpos()[i0r+q],pc,stride);
 					ok = ok & (p >= L.pfrom()[zf]) & (p < L.pto()[zf]) & (uf >= FW_THRES_FEAS);
 					okr = okr & (p >= L.cpfrom()[zr]) & (p < L.cpto()[zr]) & (ur >= FW_THRES_FEAS);
 					sum += uf; rsum += ur;
+					if ( j == 0 ) { f1 = uf; r1 = ur; }
+					fl = uf;
 				}
 				uint64_t const bf = wv_ballot(ok), br = wv_ballot(okr);
 				uint32_t const pre = dacc_popc64(bf & ltmask), prer = dacc_popc64(br & ltmask);
-				if ( ok && bF+pre < CT::wcap ) L.wuF()[bF+pre] = sum;
-				if ( okr && bR+prer < CT::wcap ) L.wuR()[bR+prer] = rsum;
+				if ( ok && bF+pre < CT::wcap )
+				{
+					uint32_t const o = bF+pre;
+					L.wF_lo()[o] = static_cast<uint32_t>(sum); L.wF_hi()[o] = static_cast<uint16_t>(sum>>32);
+					L.wF1_lo()[o] = static_cast<uint32_t>(f1); L.wF1_hi()[o] = static_cast<uint8_t>(f1>>32);
+					L.wFl_lo()[o] = static_cast<uint32_t>(fl); L.wFl_hi()[o] = static_cast<uint8_t>(fl>>32);
+				}
+				if ( okr && bR+prer < CT::wcap )
+				{
+					uint32_t const o = bR+prer;
+					L.wR_lo()[o] = static_cast<uint32_t>(rsum); L.wR_hi()[o] = static_cast<uint16_t>(rsum>>32);
+					L.wR1_lo()[o] = static_cast<uint32_t>(r1); L.wR1_hi()[o] = static_cast<uint8_t>(r1>>32);
+				}
 				mF |= bf << c; mR |= br << c;
 				bF += dacc_popc64(bf); bR += dacc_popc64(br);
 			}
@@ -751,6 +819,13 @@ struct FastEngine
 		}
 		wv_sync();
 	}
+	// weights of feasible (stretch, position) entry i.  A node weight is a sum of at most 255 table words (< 2^40), a
+	// feasible stretch has at most nrows <= 64 nodes (< 2^46)
+	DEV uint64_t wuF(uint32_t const i) const { return L.wF_lo()[i] | (static_cast<uint64_t>(L.wF_hi()[i])<<32); }
+	DEV uint64_t w1F(uint32_t const i) const { return L.wF1_lo()[i] | (static_cast<uint64_t>(L.wF1_hi()[i])<<32); }   // first node at the start position
+	DEV uint64_t wlF(uint32_t const i) const { return L.wFl_lo()[i] | (static_cast<uint64_t>(L.wFl_hi()[i])<<32); }   // last node at the end position
+	DEV uint64_t wuR(uint32_t const i) const { return L.wR_lo()[i] | (static_cast<uint64_t>(L.wR_hi()[i])<<32); }
+	DEV uint64_t w1R(uint32_t const i) const { return L.wR1_lo()[i] | (static_cast<uint64_t>(L.wR1_hi()[i])<<32); }   // last node (first in reverse direction)
 	// fixed-point weight of a single node at (reverse) position p
 	DEV uint64_t nodeU(uint32_t const z, uint32_t const p, bool const rev) const
 	{
@@ -783,14 +858,13 @@ struct FastEngine
 		uint64_t const mA = L.maskR()[i], mB = L.maskR()[b];
 		uint64_t common = mA & (mB<<shift);
 		uint64_t weight = 0;
-		uint32_t const alast = L.slast()[i];
 		while ( common )
 		{
 			uint32_t const pa = __builtin_ctzll(common); common &= common-1;
 			uint32_t const ia = L.woffR()[i] + dacc_popc64(mA & ((1ull<<pa)-1));
 			uint32_t const pb = pa-shift;
 			uint32_t const ib = L.woffR()[b] + dacc_popc64(mB & ((1ull<<pb)-1));
-			uint64_t const lweight = L.wuR()[ib] + (L.wuR()[ia] - nodeU(alast,pa,true));
+			uint64_t const lweight = wuR(ib) + (wuR(ia) - w1R(ia));
 			weight = lweight > weight ? lweight : weight;
 		}
 		return weight >= FW_THRES_01;
@@ -798,9 +872,10 @@ struct FastEngine
 
 	// ================= views: the stretch set of a pair in sorted order =================
 	// view = base stretches (pool ids 0..n0-1, already in Stretch::operator< order) minus the split parents plus the
-	// pieces.  It is never materialised: an iterator merges the base order with <= 4 insertions.
-	struct View { uint32_t nrem, nadd; };   // removed / inserted pool ids and insertion positions live in L.vrem/vadd/vapos
-	struct VIt { uint32_t t, a; };
+	// pieces.  It is never materialised: the enumerations look stretches up by first / last node (fhead = npred region,
+	// lhead/lord) and merge the <= 6 inserted pieces by their position ppos among the base stretches.
+	struct View { uint32_t nadd; uint32_t r0, r1; };
+	struct MIt { uint32_t i, a, target; };
 	View V;
 	// number of base stretches whose key is smaller than the key of pool stretch s
 	DEV uint32_t basePos(uint32_t const s) const
@@ -810,37 +885,52 @@ struct FastEngine
 		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( poolKey(mid) < key ) lo = mid+1; else hi = mid; }
 		return lo;
 	}
-	DEV void viewClear() { V.nrem = 0; V.nadd = 0; }
-	DEV void viewRemove(uint32_t const s) { L.vrem()[V.nrem++] = s; }
+	DEV void viewClear() { V.nadd = 0; V.r0 = 0xFFFF; V.r1 = 0xFFFF; }
+	DEV void viewRemove(uint32_t const s) { if ( V.r0 == 0xFFFF ) V.r0 = s; else V.r1 = s; }
 	DEV void viewAdd(uint32_t const s)
 	{
-		uint32_t const pos = basePos(s); uint64_t const key = poolKey(s);
+		uint32_t const pos = L.ppos()[s];
 		uint32_t i = V.nadd++;
 		// keep the insertions sorted by (position, key)
-		while ( i > 0 && ( L.vapos()[i-1] > pos || (L.vapos()[i-1] == pos && poolKey(L.vadd()[i-1]) > key) ) ) { L.vadd()[i] = L.vadd()[i-1]; L.vapos()[i] = L.vapos()[i-1]; --i; }
-		L.vadd()[i] = s; L.vapos()[i] = pos;
+		while ( i > 0 && ( L.vapos()[i-1] > pos || (L.vapos()[i-1] == pos && poolKey(L.vadd()[i-1]) > poolKey(s)) ) )
+		{
+			L.vadd()[i] = L.vadd()[i-1]; L.vapos()[i] = L.vapos()[i-1]; L.vfn()[i] = L.vfn()[i-1]; L.vln()[i] = L.vln()[i-1];
+			--i;
+		}
+		L.vadd()[i] = s; L.vapos()[i] = pos; L.vfn()[i] = L.sfirst()[s]; L.vln()[i] = L.slast()[s];
 	}
-	DEV void vbegin(VIt & it) const { it.t = 0; it.a = 0; }
-	DEV int32_t vnext(VIt & it) const
+	DEV bool viewRemoved(uint32_t const s) const { return s == V.r0 || s == V.r1; }
+	// view stretches whose first node is `node`, in view order
+	DEV void byFirstBegin(MIt & it, uint32_t const node) const { it.i = fheadOf(node); it.a = 0; it.target = node; }
+	DEV int32_t byFirstNext(MIt & it) const
 	{
 		while ( true )
 		{
-			if ( it.a < V.nadd && L.vapos()[it.a] <= it.t ) return L.vadd()[it.a++];
-			if ( it.t >= n0 ) return -1;
-			uint32_t const sx = it.t++;
-			bool removed = false;
-			for ( uint32_t r = 0; r < V.nrem; ++r ) if ( L.vrem()[r] == sx ) removed = true;
-			if ( !removed ) return sx;
+			while ( it.a < V.nadd && L.vfn()[it.a] != it.target ) ++it.a;
+			bool const haveb = it.i < n0 && L.sfirst()[it.i] == it.target;
+			if ( it.a < V.nadd && ( !haveb || L.vapos()[it.a] <= it.i ) ) return L.vadd()[it.a++];
+			if ( !haveb ) return -1;
+			uint32_t const sx = it.i++;
+			if ( !viewRemoved(sx) ) return sx;
 		}
 	}
-	// position the iterator at the first view stretch whose first node is >= node
-	DEV void vseekFirst(VIt & it, uint32_t const node) const
+	// view stretches whose last node is `node`, in view order
+	DEV void byLastBegin(MIt & it, uint32_t const node) const { it.i = L.lhead()[node]; it.a = 0; it.target = node; }
+	DEV int32_t byLastNext(MIt & it) const
 	{
-		uint32_t lo = 0, hi = n0;
-		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.sfirst()[mid] < node ) lo = mid+1; else hi = mid; }
-		it.t = lo; it.a = 0;
-		while ( it.a < V.nadd && ( L.vapos()[it.a] < lo || L.sfirst()[L.vadd()[it.a]] < node ) ) ++it.a;
+		while ( true )
+		{
+			while ( it.a < V.nadd && L.vln()[it.a] != it.target ) ++it.a;
+			uint32_t const e = it.i < n0 ? L.lord()[it.i] : 0xFFFFFFFFu;
+			bool const haveb = (e>>8) == it.target;
+			uint32_t const sx = e & 0xFF;
+			if ( it.a < V.nadd && ( !haveb || L.vapos()[it.a] <= sx ) ) return L.vadd()[it.a++];
+			if ( !haveb ) return -1;
+			++it.i;
+			if ( !viewRemoved(sx) ) return sx;
+		}
 	}
+	DEV uint32_t fheadOf(uint32_t const node) const { return L.npred()[node]; }   // npred is free once the stretches are walked
 
 	// 16 byte records are moved as two 64 bit words (struct copies cannot bind LDS lvalues to generic references)
 	template<typename TT> DEV static TT ldget(LDSQ TT const * p)
@@ -924,8 +1014,8 @@ struct FastEngine
 		uint32_t const ppos = L.rc_pos()[rb+parent], plen = L.rc_len()[rb+parent];
 		int32_t const sfo = csfFind(s,ppos);
 		uint64_t weight = L.rc_w()[rb+parent]; uint32_t baselen = L.rc_baselen()[rb+parent];
-		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? L.wuR()[sfo] : 0; }
-		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += L.wuR()[sfo] - nodeU(L.slast()[s],ppos,true); }
+		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? wuR(sfo) : 0; }
+		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += wuR(sfo) - w1R(sfo); }
 		uint32_t const npos = ppos + L.sslen()[s]-1;
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --nrp; return -1; }
 		L.rc_parent()[rb+id] = parent; L.rc_stretch()[rb+id] = s; L.rc_len()[rb+id] = plen+1; L.rc_pos()[rb+id] = npos;
@@ -937,7 +1027,7 @@ struct FastEngine
 		uint32_t const s = L.rc_stretch()[rb+id];
 		uint32_t const checkpos = L.rc_pos()[rb+id] - (L.sslen()[s]-1);
 		int32_t const f = csfFind(s,checkpos);
-		return f >= 0 && L.wuR()[f] >= FW_THRES_05;
+		return f >= 0 && wuR(f) >= FW_THRES_05;
 	}
 	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len()[rb+id] ? L.nv()[L.sfirst()[L.rc_stretch()[rb+id]]] : rlastk; }
 	DEV bool arpLess(uint8_t const a, uint8_t const b) const
@@ -1036,28 +1126,24 @@ struct FastEngine
 			L.rc_ord()[rb+narp++] = rp;
 			if ( L.rc_len()[rb+rp] == 0 )
 			{
-				VIt it; vbegin(it);
-				for ( int32_t sx = vnext(it); sx >= 0; sx = vnext(it) )
+				MIt it; byLastBegin(it,lastnode);
+				for ( int32_t sx = byLastNext(it); sx >= 0; sx = byLastNext(it) )
 				{
-					uint32_t const s = sx;
-					if ( L.slast()[s] == lastnode )
-					{
-						int32_t const rpe = extendReversePath(rp,s);
-						if ( rpe < 0 ) return;
-						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst(),nrpst,rpe,W); }
-						else --nrp;
-					}
+					int32_t const rpe = extendReversePath(rp,sx);
+					if ( rpe < 0 ) return;
+					if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst(),nrpst,rpe,W); }
+					else --nrp;
 				}
 			}
 			else if ( static_cast<int64_t>(L.rc_baselen()[rb+rp]) < (lmax+1)/2 )
 			{
 				uint32_t const b = L.rc_stretch()[rb+rp];
 				uint32_t const bf = L.sfirst()[b];
-				VIt it; vbegin(it);
-				for ( int32_t ax = vnext(it); ax >= 0; ax = vnext(it) )
+				MIt it; byLastBegin(it,bf);
+				for ( int32_t ax = byLastNext(it); ax >= 0; ax = byLastNext(it) )
 				{
 					uint32_t const a = ax;
-					if ( L.slast()[a] == bf && linkOk(a,b) )
+					if ( linkOk(a,b) )
 					{
 						int32_t const rpe = extendReversePath(rp,a);
 						if ( rpe < 0 ) return;
@@ -1082,6 +1168,8 @@ struct FastEngine
 				if ( wj < wi || (wj == wi && j < i) ) ++r;
 			}
 			L.rc_arw()[rb+i] = r;
+			uint32_t const rp = L.rc_ord()[rb+i];
+			L.rc_front()[rb+i] = rpFront(rp); L.rc_sbl()[rb+i] = L.rc_baselen()[rb+rp];
 		}
 	}
 	// one bit per scan target of the enumeration just finished (node id mod 64): a clear bit proves that a node was not a target
@@ -1136,8 +1224,8 @@ struct FastEngine
 		uint64_t weight = parent >= 0 ? L.f_w()[parent] : 0;
 		uint32_t baselen = parent >= 0 ? L.f_baselen()[parent] : 0;
 		int32_t const sfo = sfFind(s,ppos);
-		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? L.wuF()[sfo] : 0; }
-		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += L.wuF()[sfo] - nodeU(L.sfirst()[s],ppos,false); }
+		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? wuF(sfo) : 0; }
+		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += wuF(sfo) - w1F(sfo); }
 		uint32_t const npos = ppos + (L.sslen()[s]-1);
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --np; return -1; }
 		L.f_parent()[id] = parent >= 0 ? parent : 0xFF; L.f_stretch()[id] = s; L.f_len()[id] = plen+1; L.f_pos()[id] = npos;
@@ -1166,8 +1254,8 @@ struct FastEngine
 		for ( uint32_t i = 0; i < CT::blcap; ++i ) L.hbl_n()[i] = 0;
 		apqlo = CT::blcap; apqhi = 0;
 		{
-			VIt it; vseekFirst(it,firstnode);
-			for ( int32_t sx = vnext(it); sx >= 0 && L.sfirst()[sx] == static_cast<uint32_t>(firstnode); sx = vnext(it) )
+			MIt it; byFirstBegin(it,firstnode);
+			for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
 			{
 				int32_t const id = extendPath(-1,sx);
 				if ( id < 0 || !apqPush(id) ) return;
@@ -1181,18 +1269,26 @@ struct FastEngine
 				ipop<true>(H,hn,L.f_w());
 				L.hbl_n()[zz] = hn;
 				if ( nfpop >= CT::fcap ) { over(512); return; }
+				{
+					// what the score intervals need of this path: junction k-mer, candidate length, weight without the junction node
+					uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path];
+					uint64_t const pw = L.f_w()[path];
+					int32_t const psfo = sfFind(ps,ppos - (L.sslen()[ps]-1));
+					L.fp_front()[nfpop] = L.nv()[L.slast()[ps]]; L.fp_cl()[nfpop] = ppos;
+					L.fp_adj()[nfpop] = psfo >= 0 ? (pw - wlF(psfo)) : pw;
+					if ( pw > fmaxw ) fmaxw = pw;
+				}
 				L.fpop()[nfpop++] = path;
-				if ( L.f_w()[path] > fmaxw ) fmaxw = L.f_w()[path];
 				uint32_t const pbl = L.f_baselen()[path];
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 				{
 					uint32_t const lastn = L.slast()[L.f_stretch()[path]];
-					VIt it; vseekFirst(it,lastn);
-					for ( int32_t sx = vnext(it); sx >= 0 && L.sfirst()[sx] == lastn; sx = vnext(it) )
+					MIt it; byFirstBegin(it,lastn);
+					for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
 					{
 						uint32_t const s = sx;
 						int32_t const sfo = sfFind(s,L.f_pos()[path]);
-						uint64_t const eweight = sfo >= 0 ? L.wuF()[sfo] : 0;
+						uint64_t const eweight = sfo >= 0 ? wuF(sfo) : 0;
 						if ( eweight >= FW_THRES_01 )
 						{
 							int32_t const ep = extendPath(path,s);
@@ -1227,69 +1323,67 @@ struct FastEngine
 	}
 
 	// ================= combining a forward tree with a reverse block (score intervals + pair loop) =================
-	DEV uint64_t getPairScore(uint32_t const path, uint32_t const base, uint32_t const rp) const
+	uint32_t cfree;   // free candidate sequence slots
+	// A candidate is kept as its sequence of view stretches (forward chain, then reverse chain).  Within one view two
+	// candidates spell the same string iff their sequences are equal (nodes are distinct k-mers and every edge lies on
+	// exactly one stretch of the view), so the duplicate test of traverse (:5098-5110) compares sequences; strings are
+	// decoded once, for the final candidates (decodePathPair :4267-4300).
+	DEV uint32_t buildSeq(uint32_t const path, uint32_t const base, uint32_t const rp, LDSQ uint8_t * dst, uint32_t & conslen)
 	{
-		uint32_t const s = L.f_stretch()[path];
-		uint32_t const spos = L.f_pos()[path] - (L.sslen()[s]-1);
-		int32_t const sfo = sfFind(s,spos);
-		if ( sfo >= 0 ) return L.f_w()[path] + L.rc_w()[base+rp] - nodeU(L.slast()[s],L.f_pos()[path],false);
-		else return L.f_w()[path] + L.rc_w()[base+rp];
+		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[base+rp];
+		if ( nf + nr > FSEQCAP ) { over(4096); return ~0u; }
+		conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[base+rp];
+		if ( conslen > MAXCONS ) { over(4096); return ~0u; }
+		uint32_t i = nf;
+		for ( uint32_t q = path; i; q = L.f_parent()[q] ) dst[--i] = L.f_stretch()[q];
+		i = nf;
+		for ( uint32_t q = rp; L.rc_len()[base+q]; q = L.rc_parent()[base+q] ) dst[i++] = L.rc_stretch()[base+q];
+		return nf+nr;
 	}
-	DEV uint32_t rcFront(uint32_t const base, uint32_t const rp, uint32_t const lastkmer) const { return L.rc_len()[base+rp] ? L.nv()[L.sfirst()[L.rc_stretch()[base+rp]]] : lastkmer; }
-	// decodePathPair :4267-4300 into dst (2-bit codes); returns length or ~0
-	DEV uint32_t decodePathPair(uint32_t const path, uint32_t const base, uint32_t const rp, LDSQ uint8_t * dst)
+	DEV uint32_t decodeSeq(LDSQ uint8_t const * seq, uint32_t const n, LDSQ uint8_t * dst) const
 	{
-		LDSQ uint8_t * chain = L.chain(); uint32_t cl = 0;
-		for ( uint32_t q = path; q != 0xFF; q = L.f_parent()[q] ) { if ( cl >= 64 ) { over(4096); return ~0u; } chain[cl++] = L.f_stretch()[q]; }
-		uint32_t need = k;
-		for ( uint32_t i = 0; i < cl; ++i ) need += L.sslen()[chain[i]]-1;
-		for ( uint32_t q = rp; L.rc_len()[base+q]; q = L.rc_parent()[base+q] ) need += L.sslen()[L.rc_stretch()[base+q]]-1;
-		if ( need > MAXCONS ) { over(4096); return ~0u; }
 		uint32_t o = 0;
-		uint32_t const firstv = L.nv()[L.sfirst()[chain[cl-1]]];
+		uint32_t const firstv = L.nv()[L.sfirst()[seq[0]]];
 		for ( uint32_t i = 0; i < k; ++i ) dst[o++] = (firstv >> (2*(k-1-i))) & 3;
-		for ( uint32_t ii = 0; ii < cl; ++ii )
+		for ( uint32_t ii = 0; ii < n; ++ii )
 		{
-			uint32_t const s = chain[cl-1-ii]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
-			for ( uint32_t j = 1; j < L.sslen()[s]; ++j ) dst[o++] = L.nv()[Lk[j]] & 3;
-		}
-		for ( uint32_t q = rp; L.rc_len()[base+q]; q = L.rc_parent()[base+q] )
-		{
-			uint32_t const s = L.rc_stretch()[base+q]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
-			for ( uint32_t j = 1; j < L.sslen()[s]; ++j ) dst[o++] = L.nv()[Lk[j]] & 3;
+			uint32_t const s = seq[ii]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+			uint32_t const len = L.sslen()[s];
+			for ( uint32_t j = 1; j < len; ++j ) dst[o++] = L.nv()[Lk[j]] & 3;
 		}
 		return o;
 	}
-	DEV void combinePair(uint32_t const base, uint32_t const nacc2, uint32_t const lastkmer, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
+	DEV void combinePair(uint32_t const base, uint32_t const nacc2, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
 	{
 		nsiq = 0;
 		for ( uint32_t pi = 0; pi < nfpop; ++pi )
 		{
-			uint32_t const path = L.fpop()[pi];
-			int64_t const candlen = static_cast<int64_t>(L.f_pos()[path]) + k;
-			uint32_t const front = L.nv()[L.slast()[L.f_stretch()[path]]];
+			int64_t const candlen = static_cast<int64_t>(L.fp_cl()[pi]) + k;
+			uint32_t const front = L.fp_front()[pi];
 			uint32_t lo = 0, hi = nacc2;
-			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( rcFront(base,L.rc_ord()[base+mid],lastkmer) < front ) lo = mid+1; else hi = mid; }
+			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.rc_front()[base+mid] < front ) lo = mid+1; else hi = mid; }
 			uint32_t e = lo;
-			while ( e < nacc2 && rcFront(base,L.rc_ord()[base+e],lastkmer) == front ) ++e;
+			while ( e < nacc2 && L.rc_front()[base+e] == front ) ++e;
+			if ( e == lo ) continue;
 			int64_t bllo = lmin + static_cast<int64_t>(k) - candlen; if ( bllo < 0 ) bllo = 0;
 			int64_t blhi = lmax + static_cast<int64_t>(k) - candlen; if ( blhi < 0 ) blhi = 0;
 			uint32_t const bllo16 = static_cast<uint16_t>(bllo), blhi16 = static_cast<uint16_t>(blhi);
 			uint32_t sub = lo;
-			while ( sub < e && L.rc_baselen()[base+L.rc_ord()[base+sub]] < bllo16 ) ++sub;
+			while ( sub < e && L.rc_sbl()[base+sub] < bllo16 ) ++sub;
 			uint32_t sup = sub;
-			while ( sup < e && !(blhi16 < L.rc_baselen()[base+L.rc_ord()[base+sup]]) ) ++sup;
+			while ( sup < e && !(blhi16 < L.rc_sbl()[base+sup]) ) ++sup;
 			if ( sub != sup )
 			{
-				uint32_t mi = sub;
-				for ( uint32_t i = sub+1; i < sup; ++i ) if ( L.rc_arw()[base+i] > L.rc_arw()[base+mi] ) mi = i;
+				uint32_t mi = sub, mr = L.rc_arw()[base+sub];
+				for ( uint32_t i = sub+1; i < sup; ++i ) { uint32_t const r = L.rc_arw()[base+i]; if ( r > mr ) { mi = i; mr = r; } }
 				if ( nsiq >= CT::siqcap ) { over(512); return; }
-				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = path; si.pad = 0; si.w = getPairScore(path,base,L.rc_ord()[base+mi]);
+				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = pi; si.pad = 0; si.w = L.fp_adj()[pi] + L.rc_w()[base+L.rc_ord()[base+mi]];
 				spush<FSI,false>(L.siq(),nsiq,si);
 				fstat(6,nsiq);
 			}
 		}
-		prevlen = ~0u;
+		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
+		uint32_t pn = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
 		{
 			FSI const si = ldget(L.siq());
@@ -1309,33 +1403,33 @@ struct FastEngine
 					}
 					if ( found )
 					{
-						FSI sic = si; sic.current = bi; sic.w = getPairScore(si.path,base,L.rc_ord()[base+bi]);
+						FSI sic = si; sic.current = bi; sic.w = L.fp_adj()[si.path] + L.rc_w()[base+L.rc_ord()[base+bi]];
 						if ( nsiq >= CT::siqcap ) { over(512); return; }
 						spush<FSI,false>(L.siq(),nsiq,sic);
 					}
 				}
 			}
 			uint64_t const weight = si.w;
-			if ( ncdh == 16 ) spop<FCC,true>(L.cdh(),ncdh);   // weight > top here
-			uint32_t const conslen = decodePathPair(si.path,base,L.rc_ord()[base+si.current],L.curstr());
-			if ( conslen == ~0u ) return;
-			if ( conslen == prevlen )
+			if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
+			uint32_t conslen = 0;
+			uint32_t const n = buildSeq(L.fpop()[si.path],base,L.rc_ord()[base+si.current],cur,conslen);
+			if ( n == ~0u ) return;
+			if ( n == pn )
 			{
 				bool eq = true;
-				for ( uint32_t i = 0; i < conslen; ++i ) if ( L.prevstr()[i] != L.curstr()[i] ) { eq = false; break; }
+				for ( uint32_t i = 0; i < n; ++i ) if ( prev[i] != cur[i] ) { eq = false; break; }
 				if ( eq ) continue;
 			}
-			for ( uint32_t i = 0; i < conslen; ++i ) L.prevstr()[i] = L.curstr()[i];
-			prevlen = conslen;
-			if ( conso + conslen > CT::conscap - MAXCONS ) { over(4096); return; }
-			for ( uint32_t i = 0; i < conslen; ++i ) G.cons[conso+i] = L.curstr()[i];
-			FCC cc; cc.w = weight; cc.o = conso; cc.l = conslen;
-			conso += conslen;
+			uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
+			LDSQ uint8_t * dst = L.cseq() + FSEQCAP*slot;
+			for ( uint32_t i = 0; i < n; ++i ) { uint8_t const c = cur[i]; prev[i] = c; dst[i] = c; }
+			pn = n;
+			FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
 			spush<FCC,true>(L.cdh(),ncdh,cc);
 		}
 	}
 
-	DEV uint32_t myersDistance(uint32_t const j, GLBQ uint8_t const * text, uint32_t const n) const
+	DEV uint32_t myersDistance(uint32_t const j, LDSQ uint8_t const * text, uint32_t const n) const
 	{
 		uint32_t const m = L.slen()[j];
 		if ( m == 0 ) return n;
@@ -1442,7 +1536,6 @@ struct FastEngine
 					if ( rcached && fcached && ncdh == 16 && fmaxw + RMAX[li] <= L.cdh()[0].w ) { pcount(28,1); continue; }
 				}
 				uint32_t base, nacc2;
-				uint32_t const swF = nwF, swR = nwR;
 				if ( !rcached || !fcached )
 				{
 					// exact stretch set of the pair (split at first, then at last)
@@ -1461,7 +1554,7 @@ struct FastEngine
 							}
 							pl_midready = false;
 							if ( pf < pl ) { viewAdd(L.pieF()[fi]); viewAdd(L.pieL()[li]+1); } else { viewAdd(L.pieL()[li]); viewAdd(L.pieF()[fi]+1); }
-							viewAdd(npool);
+							viewAdd(npool-1);   // the middle piece just appended to the pool
 						}
 					}
 					else
@@ -1473,10 +1566,9 @@ struct FastEngine
 					if ( !fcached ) { forwardEnumerate(firstnode,lmax); if ( flags ) return 0; fcur_fi = fi; fcur_li = li; }
 				}
 				if ( rcached ) { base = L.rbase()[li]; nacc2 = L.rn()[li]; } else { base = rb; nacc2 = narp; }
-				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,lastk,lmin,lmax,16); pcount(24,pclock()-tq0); }
+				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,lmin,lmax,16); pcount(24,pclock()-tq0); }
 				if ( !rcached || !fcached ) pcount(21,1);
 				if ( flags ) return 0;
-				nwF = swF; nwR = swR;   // drop the weights of a temporary middle piece
 			}
 		}
 		return 0;
@@ -1485,16 +1577,18 @@ struct FastEngine
 	DEV bool traverse(int64_t const lmin, int64_t const lmax)
 	{
 		PROF_T0
-		conso = 0; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; rctop = 0; fcur_fi = -1; fcur_li = -1;
+		cfree = 0xFFFFu; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; rctop = 0; fcur_fi = -1; fcur_li = -1;
 		computeBaseStretches();
 		flags = wv_or(flags); if ( flags ) return false;
 		PROF(*this,8)
 		findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
-		computeStretchFeas(0,npool);
+		loadTab();
+		computeStretchFeas<false>(0,npool);
 		flags = wv_or(flags); if ( flags ) return false;
 		for ( uint32_t i = lane; i < FNC+1; i += WSZ ) L.rvalid()[i] = 0;
 		wv_sync();
+		fstat(4,nwF); fstat(5,nwR); fstat(7,nlinks);
 		PROF(*this,9)
 		pl_fi = 0; pl_li = 0; pl_midready = false;
 		while ( true )
@@ -1505,14 +1599,14 @@ struct FastEngine
 			flags = wv_bcast(flags,0); if ( flags ) return false;
 			req = wv_bcast(req,0);
 			if ( !req ) break;
-			// middle piece of a stretch split twice: temporary pool entry npool with its own feasibility
+			// middle piece of a stretch split twice: appended to the pool (kept, candidates may refer to it)
 			uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
-			nwF = wv_bcast(nwF,0); nwR = wv_bcast(nwR,0);
-			if ( npool+1 > CT::scap ) { over(32); return false; }
-			if ( lane == 0 ) makePiece(npool,par,ma,mb);
+			if ( npool+1 > CT::scap || npool+1 > 250 ) { over(32); return false; }
+			if ( lane == 0 ) { makePiece(npool,par,ma,mb); L.ppos()[npool] = basePos(npool); }
 			wv_sync();
-			computeStretchFeas(npool,npool+1);
+			computeStretchFeas<true>(npool,npool+1);
 			flags = wv_or(flags); if ( flags ) return false;
+			++npool;
 			if ( lane == 0 ) pl_midready = true;
 		}
 		PROF(*this,12)
@@ -1525,10 +1619,18 @@ struct FastEngine
 		wv_sync();
 		uint32_t const nc = wv_bcast(nacc,0);
 		nacc = nc;
+		// decode the kept candidates, one lane each
+		for ( uint32_t c = lane; c < nc; c += WSZ )
+		{
+			uint32_t const slot = L.acc()[c].o, n = L.acc()[c].l & 0xFF;
+			uint32_t const len = decodeSeq(L.cseq()+FSEQCAP*slot,n,L.consL()+c*MAXCONS);
+			L.acc()[c].o = c*MAXCONS; L.acc()[c].l = len;
+		}
+		wv_sync();
 		for ( uint32_t t = lane; t < nc*mao; t += WSZ )
 		{
 			uint32_t const c = t / mao, j = t - c*mao;
-			L.canderr()[t] = myersDistance(j,G.cons + L.acc()[c].o,L.acc()[c].l);
+			L.canderr()[t] = myersDistance(j,L.consL() + L.acc()[c].o,L.acc()[c].l);
 		}
 		wv_sync();
 		if ( lane == 0 )
@@ -1633,7 +1735,7 @@ struct FastEngine
 		return maxvprodindex;
 	}
 
-	DEV void alignAndEmit(GLBQ uint8_t const * cons, uint32_t const n, uint8_t * rec)
+	DEV void alignAndEmit(LDSQ uint8_t const * cons, uint32_t const n, uint8_t * rec)
 	{
 		uint32_t const m = P.w;
 		LDSQ uint8_t const * a = L.str();
@@ -1697,7 +1799,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 {
 	WindowBatch const & B = FB.W;
 	FastEngine<CT> E;
-	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup;
+	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 	E.L.base = lds;
 	E.G.cons = (GLBQ uint8_t *)garena;
@@ -1781,7 +1883,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 		uint64_t minrate = B.P.eminrate;
 		bool haveMin = false;
 		uint32_t bestlen = 0;
-		GLBQ uint8_t * best = E.G.cons + (CT::conscap - MAXCONS);
+		LDSQ uint8_t * best = L.bestL();
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh; ++k )
 		{
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
@@ -1797,6 +1899,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 				if ( ff == 0 )
 				{
 					// gap filling (HandleContext.hpp:2233-2268)
+					E.loadTab();
 					E.levelSuccessors2();
 					E.flags = wv_or(E.flags);
 					if ( E.flags ) { FFAIL(6) }
@@ -1820,7 +1923,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 							lconsok = true; minrate = err; haveMin = true;
 							bestlen = L.acc()[0].l;
 							if ( bestlen > MAXCONS ) { FFAIL(9) }
-							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = E.G.cons[L.acc()[0].o+i];
+							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = L.consL()[L.acc()[0].o+i];
 							out.k = k; out.filterfreq = ff;
 							wv_sync();
 						}

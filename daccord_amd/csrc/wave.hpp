@@ -57,53 +57,60 @@
 	total = __shfl(x,63,64);
 	return x - v;
   }
+  // value of the first active lane as a wave-uniform (scalar) value: keeps the control flow that depends on it uniform
+  DEV uint32_t wv_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+  DEV uint64_t wv_uni64(uint64_t v)
+  {
+	uint32_t const lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v>>32));
+	return (static_cast<uint64_t>(hi)<<32) | lo;
+  }
   DEV uint32_t wv_sum(uint32_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) v += __shfl_xor(v,d,64);
-	return v;
+	return wv_uni(v);
   }
   DEV uint64_t wv_sum64(uint64_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) v += __shfl_xor(v,d,64);
-	return v;
+	return wv_uni64(v);
   }
   DEV uint32_t wv_max(uint32_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) { uint32_t const o = __shfl_xor(v,d,64); v = o > v ? o : v; }
-	return v;
+	return wv_uni(v);
   }
   DEV uint64_t wv_max64(uint64_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) { uint64_t const o = __shfl_xor(v,d,64); v = o > v ? o : v; }
-	return v;
+	return wv_uni64(v);
   }
   DEV uint64_t wv_min64(uint64_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) { uint64_t const o = __shfl_xor(v,d,64); v = o < v ? o : v; }
-	return v;
+	return wv_uni64(v);
   }
   DEV int wv_any(int p) { return __any(p); }
   DEV uint32_t wv_or(uint32_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
-	return v;
+	return wv_uni(v);
   }
   DEV uint64_t wv_or64(uint64_t v)
   {
 	#pragma unroll
 	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
-	return v;
+	return wv_uni64(v);
   }
   DEV uint64_t wv_ballot(int p) { return __ballot(p); }
   DEV uint64_t wv_lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
-  DEV uint32_t wv_bcast(uint32_t v, int src) { return __shfl(v,src,64); }
-  DEV uint64_t wv_bcast64(uint64_t v, int src) { return __shfl(v,src,64); }
+  DEV uint32_t wv_bcast(uint32_t v, int src) { return wv_uni(__shfl(v,src,64)); }
+  DEV uint64_t wv_bcast64(uint64_t v, int src) { return wv_uni64(__shfl(v,src,64)); }
   DEV int dacc_popc64(uint64_t v) { return __popcll(v); }
   DEV void atomicOrFlag(uint32_t * f) { atomicOr(f,1u); }
   }

@@ -141,6 +141,8 @@ typedef struct dacc_timing {
 	uint64_t nretry;         /* windows the LDS fast path handed to the generic engine */
 	float fast_ms;           /* first-tier LDS kernel alone (window_ms = all tiers) */
 	uint32_t nretry2;        /* windows that also overflowed the second LDS tier (generic engine) */
+	float fast2_ms;          /* second-tier LDS kernel alone */
+	uint32_t pad;
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 

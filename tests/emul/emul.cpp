@@ -135,7 +135,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		{ FastLds< FastTier<1> > L; L.base = lds.data(); fast_load_tables(L,BP.fcaps.nrows,BP.fcaps.nsup,T,c->H.dpsq_vst.data()); }
 		{ FastLds< FastTier<2> > L; L.base = lds2.data(); fast_load_tables(L,BP.fcaps2.nrows,BP.fcaps2.nsup,T,c->H.dpsq_vst.data()); }
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
-		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
+		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP && (c->H.nrows+1)*c->H.nsup <= FastLds< FastTier<1> >::tabcap;
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
 		{
 #if defined(DACC_FSTATS)
