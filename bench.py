@@ -72,22 +72,13 @@ def main():
     tfirst = time.time() - t0
     tm0 = E.timing()
 
-    def gather_bases(nb):
-        if world == 1:
-            return
-        # final RCCL gather of corrected bases to rank 0 (counts first, then padded payloads)
-        cnt = torch.tensor([nb], dtype=torch.int64, device="cuda")
-        allc = torch.empty(world, dtype=torch.int64, device="cuda")
-        dist.all_gather_into_tensor(allc, cnt)
-        mx = int(allc.max().item())
-        buf = torch.zeros(mx, dtype=torch.uint8, device="cuda")
-        buf[:nb] = torch.frombuffer(bytearray(E.collect()[1]), dtype=torch.uint8).cuda()
-        out = [torch.empty(mx, dtype=torch.uint8, device="cuda") for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, out, dst=0)
+    from daccord_amd import shard
 
     def step():
         E.rerun()
-        gather_bases(len(E.collect()[1]))
+        fr, ba = E.collect()
+        # the only communication of a step: corrected fragments of all ranks to rank 0 (RCCL gather; no-op at N=1)
+        shard.gather_fragments(fr, ba, device="cuda")
 
     for _ in range(args.warmup):
         step()

@@ -173,3 +173,6 @@ def fasta(frags, bases, start_well=0):
         for i in range(0, len(s), 80):
             out.append(s[i:i + 80] + "\n")
     return "".join(out)
+
+
+from .shard import shard_range, shard_piles, gather_fragments  # noqa: E402,F401  (multi-GPU layer: SURVEY.md 8e)
