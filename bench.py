@@ -86,13 +86,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    wsum = tsum = vsum = f1sum = f2sum = 0.0
-    nretry = nretry2 = 0
+    wsum = tsum = vsum = 0.0
+    tsums = [0.0, 0.0, 0.0]
+    touts = [0, 0, 0]
     for _ in range(args.steps):
         step()
         t = E.timing()
-        wsum += t.window_ms; tsum += t.trace_ms; vsum += t.vote_ms; f1sum += t.fast_ms; f2sum += t.fast2_ms
-        nretry, nretry2 = int(t.nretry), int(t.nretry2)
+        wsum += t.window_ms; tsum += t.trace_ms; vsum += t.vote_ms
+        for i in range(3):
+            tsums[i] += t.tier_ms[i]; touts[i] = int(t.tier_out[i])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -125,9 +127,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None,
                          "algo_bytes_per_launch": int(t.algo_bytes), "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
-                         "window_tiers_ms": {"lds_tier1": round(f1sum / args.steps, 3), "lds_tier2": round(f2sum / args.steps, 3),
-                                             "generic": round((wsum - f1sum - f2sum) / args.steps, 3)},
-                         "windows_to_tier2": nretry, "windows_to_generic": nretry2},
+                         "window_tiers_ms": {"lds_tier1": round(tsums[0] / args.steps, 3), "lds_tier2": round(tsums[1] / args.steps, 3),
+                                             "lds_tier3": round(tsums[2] / args.steps, 3),
+                                             "generic": round((wsum - sum(tsums)) / args.steps, 3)},
+                         "windows_handed_on": {"tier1": touts[0], "tier2": touts[1], "tier3_to_generic": touts[2]}},
             "setup_s": {"generate": round(tgen, 2), "first_pass_incl_h2d": round(tfirst, 2), "h2d_ms": round(tm0.h2d_ms, 2)},
         }
         if world == 1 and not args.no_cpu:

@@ -33,7 +33,7 @@ class DaccFragment(C.Structure):
 class DaccTiming(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("trace_ms", C.c_float), ("window_ms", C.c_float), ("vote_ms", C.c_float),
                 ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("nwindows", C.c_uint64), ("nblocks", C.c_uint64),
-                ("algo_bytes", C.c_uint64), ("nretry", C.c_uint64), ("fast_ms", C.c_float), ("nretry2", C.c_uint32), ("fast2_ms", C.c_float), ("pad", C.c_uint32)]
+                ("algo_bytes", C.c_uint64), ("tier_ms", C.c_float * 3), ("tier_out", C.c_uint32 * 3)]
 
 
 class DaccWindowResult(C.Structure):

@@ -41,7 +41,8 @@ struct BatchPlan
 	uint64_t nwindows, nblocks, nwt, npos, nfragslots, algo_bytes;
 	uint32_t maxdepth, maxcols;
 	ArenaCaps caps;
-	FastCaps fcaps, fcaps2;   // LDS fast path: small tier (several wavefronts per CU) and large tier (one per CU)
+	enum { NTIER = 3 };
+	FastCaps ftier[NTIER];    // LDS fast path capacity tiers: 3, 2, 1 wavefronts per CU
 
 	int plan(dacc_params const & par, dacc_pile const * P, uint64_t const np, dacc_overlap const * O, uint64_t const no,
 		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err,
@@ -144,8 +145,9 @@ struct BatchPlan
 		caps.conscap = 32768 + MAXCONS;
 		caps.pad = 0; caps.bytes = 0;
 		// LDS fast path capacity tiers (compile time, fast_window.hpp); windows beyond them are re-run by the generic engine
-		fcaps = fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
-		fcaps2 = fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup);
+		ftier[0] = fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
+		ftier[1] = fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup);
+		ftier[2] = fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;
 	}
 };

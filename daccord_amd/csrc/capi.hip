@@ -169,7 +169,7 @@ struct dacc_ctx
 	dacc_params par;
 	int device;
 	hipStream_t stream;
-	hipEvent_t ev[6]; hipEvent_t evfast; hipEvent_t evfast2; float fast_ms;
+	hipEvent_t ev[6]; hipEvent_t evtier[3];
 	std::string err;
 	bool haveprofile, havedb, havebatch;
 	double est_cor;
@@ -185,8 +185,8 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint8_t> d_garena, d_garena2; DevBuf<uint32_t> d_retry, d_retry2, d_work;
-	uint32_t fast_grid, fast2_grid, retry_grid; int usefast; int sched; uint32_t nretry_last, nretry2_last;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work;
+	uint32_t tier_grid[3], retry_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_threads, win_grid;
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
@@ -222,7 +222,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	std::memset(&c->timing,0,sizeof(c->timing));
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
-	hipEventCreate(&c->evfast); hipEventCreate(&c->evfast2); c->fast_ms = 0;
+	for ( int i = 0; i < 3; ++i ) hipEventCreate(&c->evtier[i]);
 	*out = c;
 	return DACC_OK;
 }
@@ -236,7 +236,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_garena.release(); c->d_retry.release(); c->d_garena2.release(); c->d_retry2.release(); c->d_work.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -332,21 +332,28 @@ static int runDevice(dacc_ctx * c)
 		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = c->d_prof.p;
 		if ( c->usefast )
 		{
-			HIPCHK(hipMemsetAsync(c->d_retry.p,0,sizeof(uint32_t),s));
-			HIPCHK(hipMemsetAsync(c->d_retry2.p,0,sizeof(uint32_t),s));
+			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s));
-			FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->d_vst.p; FB.garena = c->d_garena.p; FB.retry = c->d_retry.p;
-			hipLaunchKernelGGL(k_window_fast<1>,dim3(c->fast_grid),dim3(64),BP.fcaps.ldsbytes,s,FB,static_cast<uint32_t const *>(0),(c->sched&1) ? c->d_work.p : static_cast<uint32_t *>(0));
-			hipEventRecord(c->evfast,s);
-			// second tier: the windows that overflowed the small LDS layout, one wavefront per CU with a large layout
-			FastBatch FB2 = FB; FB2.F = BP.fcaps2; FB2.garena = c->d_garena2.p; FB2.retry = c->d_retry2.p;
-			hipLaunchKernelGGL(k_window_fast<2>,dim3(c->fast2_grid),dim3(64),BP.fcaps2.ldsbytes,s,FB2,static_cast<uint32_t const *>(c->d_retry.p),(c->sched&1) ? c->d_work.p+1 : static_cast<uint32_t *>(0));
-			hipEventRecord(c->evfast2,s);
+			// capacity tiers: every tier takes the windows the previous one handed over (list = 0: all windows)
+			uint32_t const * list = 0;
+			for ( int t = 0; t < 3; ++t )
+			{
+				if ( c->tier_ok[t] )
+				{
+					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.garena = 0; FB.retry = c->d_retry[t].p;
+					uint32_t * const work = (c->sched&1) ? c->d_work.p+t : static_cast<uint32_t *>(0);
+					if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					list = c->d_retry[t].p;
+				}
+				hipEventRecord(c->evtier[t],s);
+			}
 			// what is left (rare shapes) goes through the generic engine
-			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_retry2.p),(c->sched&2) ? c->d_work.p+2 : static_cast<uint32_t *>(0));
+			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+3 : static_cast<uint32_t *>(0));
 		}
 		else
-			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+2 : static_cast<uint32_t *>(0)); }
+			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+3 : static_cast<uint32_t *>(0)); }
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
 	if ( BP.piles.size() )
@@ -364,9 +371,8 @@ static int runDevice(dacc_ctx * c)
 	size_t const symbytes = 2*BP.npos + 64*BP.piles.size() + 64;
 	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
 	HIPCHK(hipMemcpyAsync(herr,c->d_err.p,sizeof(herr),hipMemcpyDeviceToHost,s));
-	c->nretry_last = 0;
-	c->nretry2_last = 0;
-	if ( c->usefast && BP.nwindows ) { HIPCHK(hipMemcpyAsync(&c->nretry_last,c->d_retry.p,sizeof(uint32_t),hipMemcpyDeviceToHost,s)); HIPCHK(hipMemcpyAsync(&c->nretry2_last,c->d_retry2.p,sizeof(uint32_t),hipMemcpyDeviceToHost,s)); }
+	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
+	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpyAsync(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost,s));
 	if ( BP.piles.size() )
 	{
 		HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
@@ -394,11 +400,11 @@ static int runDevice(dacc_ctx * c)
 	float ms = 0;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[1]); c->timing.trace_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[1],c->ev[2]); c->timing.window_ms = ms;
-	if ( c->usefast && BP.nwindows ) { hipEventElapsedTime(&ms,c->ev[1],c->evfast); c->timing.fast_ms = ms; hipEventElapsedTime(&ms,c->evfast,c->evfast2); c->timing.fast2_ms = ms; } else { c->timing.fast_ms = 0; c->timing.fast2_ms = 0; }
+	for ( int i = 0; i < 3; ++i ) { c->timing.tier_ms[i] = 0; c->timing.tier_out[i] = c->tier_out[i]; }
+	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) { hipEventElapsedTime(&ms,i ? c->evtier[i-1] : c->ev[1],c->evtier[i]); c->timing.tier_ms[i] = ms; }
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
-	c->timing.nretry = c->nretry_last; c->timing.nretry2 = c->nretry2_last;
 	c->timing.nwindows = BP.nwindows; c->timing.nblocks = BP.nblocks; c->timing.algo_bytes = BP.algo_bytes + nbases;
 	return DACC_OK;
 }
@@ -444,23 +450,30 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		char const * sc = getenv("DACC_SCHED");   // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		c->sched = sc ? atoi(sc) : 1;
 		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
-		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP || (c->H.nrows+1)*c->H.nsup > FastLds< FastTier<1> >::tabcap ) c->usefast = 0;
+		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP ) c->usefast = 0;
 	}
 	if ( c->usefast )
 	{
-		// fast path: LDS bound, floor(160 KiB / ldsbytes) wavefronts per CU
-		uint64_t percu = (160*1024) / (BP.fcaps.ldsbytes ? BP.fcaps.ldsbytes : 1);
-		if ( percu > 8 ) percu = 8;
-		if ( percu < 1 ) percu = 1;
-		uint64_t fg = ((BP.nwindows+7)/8)*8;
-		if ( fg > 256*percu ) fg = 256*percu;
-		{ uint32_t const mx = BP.fcaps.ldsbytes > BP.fcaps2.ldsbytes ? BP.fcaps.ldsbytes : BP.fcaps2.ldsbytes; if ( mx > 160*1024 ) { c->err = "LDS layout exceeds 160 KiB"; return DACC_ENOTSUP; } if ( BP.fcaps.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.fcaps.ldsbytes)); if ( BP.fcaps2.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.fcaps2.ldsbytes)); }
-		if ( fg < 8 ) fg = 8;
-		c->fast_grid = fg;
+		// LDS tiers: floor(160 KiB / ldsbytes) wavefronts per CU; a tier whose table overlay cannot hold the model table is skipped
+		for ( int t = 0; t < 3; ++t )
+		{
+			FastCaps const & F = BP.ftier[t];
+			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= F.pad) && F.ldsbytes <= 160*1024;
+			{ char const * tm = getenv("DACC_TIERS"); if ( tm && !((atoi(tm)>>t)&1) ) c->tier_ok[t] = 0; }   // debugging: bit t enables tier t+1
+			uint64_t percu = (160*1024) / (F.ldsbytes ? F.ldsbytes : 1);
+			if ( percu > 8 ) percu = 8;
+			if ( percu < 1 ) percu = 1;
+			uint64_t fg = ((BP.nwindows+7)/8)*8;
+			if ( fg > 256*percu ) fg = 256*percu;
+			if ( fg < 8 ) fg = 8;
+			c->tier_grid[t] = fg;
+			HIPCHK(c->d_retry[t].ensure(BP.nwindows+2));
+		}
+		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
+		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
+		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = wg < 512 ? wg : 512;
 		c->win_grid = c->retry_grid;
-		c->fast2_grid = fg < 256 ? fg : 256;
-		HIPCHK(c->d_retry.ensure(BP.nwindows+2)); HIPCHK(c->d_retry2.ensure(BP.nwindows+2));
 		HIPCHK(c->d_work.ensure(4));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));
 	}

@@ -59,8 +59,9 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
-template<> struct FastTier<2> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
+template<> struct FastTier<1> { enum : uint32_t { maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 616, rccap = 128, fcap = 96, siqcap = 64, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<2> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<3> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -80,6 +81,7 @@ struct FastLds
 {
 	LDSQ uint8_t * base;
 	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
+	static_assert((CT::precap & (CT::precap-1)) == 0,"precap must be a power of two: the bitonic sorts pad to one");
 	// ---- live during the whole window ----
 	FLD(str,uint8_t,CT::maxs*64,0)
 	FLD(slen,uint8_t,CT::maxs,e_str)
@@ -230,6 +232,7 @@ HDEV FastCaps fastCapsOf(uint32_t const nrows, uint32_t const nsup)
 	C.nrows = nrows; C.nsup = nsup;
 	C.ldsbytes = FastLds<CT>::bytes(nrows,nsup);
 	C.gbytes = (static_cast<uint64_t>(CT::conscap)+255)&~255ull;
+	C.pad = FastLds<CT>::tabcap;   // words available for the model table copy
 	return C;
 }
 
@@ -326,6 +329,7 @@ struct FastEngine
 		uint32_t base = 0;
 		for ( uint32_t j = 0; j < mao; ++j ) { uint32_t const len = L.slen()[j]; base += (len >= k) ? (len-k+1) : 0; }
 		npre = base;
+		nlast = 0;
 		if ( npre > CT::precap ) { over(1); npre = 0; return; }
 		uint32_t o = 0, lo = 0;
 		for ( uint32_t j = 0; j < mao; ++j )
@@ -1799,6 +1803,12 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 {
 	WindowBatch const & B = FB.W;
 	FastEngine<CT> E;
+#if defined(DACC_EMUL)
+	{ char const * pz = getenv("DACC_EMUL_POISON"); if ( pz ) __builtin_memset(static_cast<void *>(&E),atoi(pz),sizeof(E)); }   // debugging aid: no member may be read before it is set
+#endif
+	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
+	E.rctop = 0; E.np = E.nfpop = E.nsiq = E.ncdh = E.nacc = 0; E.fcur_fi = E.fcur_li = -1; E.rb = E.nrp = E.narp = E.rlastk = 0; E.rmaxw = E.fmaxw = 0;
+	E.apqlo = E.apqhi = 0; E.cfree = 0; E.pl_fi = E.pl_li = E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false; E.ftmask = 0; E.V.nadd = 0; E.V.r0 = E.V.r1 = 0xFFFF;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 	E.L.base = lds;
@@ -1891,8 +1901,11 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 			{
 				PROF_T0
 				E.buildInstances();
+				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only
 				PROF(E,2)
 				E.buildNodes(ff > 1 ? ff : 1);
+				E.flags = wv_or(E.flags);
+				if ( E.flags ) { FFAIL(7) }
 				PROF(E,3)
 				E.buildSuccessors(mao);
 				PROF(E,4)
@@ -1904,6 +1917,8 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 					E.flags = wv_or(E.flags);
 					if ( E.flags ) { FFAIL(6) }
 					E.buildNodes(1);
+					E.flags = wv_or(E.flags);
+					if ( E.flags ) { FFAIL(7) }
 					E.buildSuccessors(mao);
 					PROF(E,6)
 				}

@@ -138,11 +138,8 @@ typedef struct dacc_timing {
 	uint64_t nwindows;       /* windows processed */
 	uint64_t nblocks;        /* trace blocks aligned */
 	uint64_t algo_bytes;     /* algorithmic bytes of the batch */
-	uint64_t nretry;         /* windows the LDS fast path handed to the generic engine */
-	float fast_ms;           /* first-tier LDS kernel alone (window_ms = all tiers) */
-	uint32_t nretry2;        /* windows that also overflowed the second LDS tier (generic engine) */
-	float fast2_ms;          /* second-tier LDS kernel alone */
-	uint32_t pad;
+	float tier_ms[3];        /* LDS capacity tiers of the window kernel (3, 2, 1 wavefronts per CU); window_ms = all + generic */
+	uint32_t tier_out[3];    /* windows each tier handed on (tier_out[2] = windows run by the generic engine) */
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 

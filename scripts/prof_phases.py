@@ -18,8 +18,8 @@ for k in (8, 14):
     t0 = time.time(); fr, ba = E(piles[:npiles], ovl, d.trace); t1 = time.time() - t0
     t = E.timing(); pr = E.profile().astype(np.float64)
     w = E.debug_windows()
-    print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms retry=%d/%d fast=%.1fms fast2=%.1fms" % (
-        k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms, t.nretry, t.nretry2, t.fast_ms, t.fast2_ms))
+    print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms tiers_out=%s tiers_ms=%s" % (
+        k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms, list(t.tier_out), [round(x, 1) for x in t.tier_ms]))
     print("  status", dict(zip(*np.unique(w["status"], return_counts=True))), "ff", dict(zip(*np.unique(w["filterfreq"][w["status"] == 1], return_counts=True))), "mean mao %.1f" % w["mao"].mean())
     tot = pr[:15].sum()
     if tot > 0:

@@ -32,8 +32,8 @@ struct EmulCtx
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<dacc_window_result> windows;
 	std::string err;
-	bool usefast; uint64_t nfast, nretry, nfast2;
-	uint64_t reasons[64]; uint64_t flagbits[24]; uint64_t reasons2[64]; uint64_t flagbits2[24];
+	bool usefast; uint64_t ntier[3], nretry;
+	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
 
 static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
@@ -50,12 +50,13 @@ static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 
 extern "C" {
 
-void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->nfast = c->nretry = 0; return c; }
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; return c; }
 void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
-void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasons2[i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbits2[i]; }
-void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasons[i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbits[i]; }
-void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { *nf = static_cast<EmulCtx *>(v)->nfast; *nr = static_cast<EmulCtx *>(v)->nretry; }
-void emul_counts3(void * v, uint64_t * nf, uint64_t * nf2, uint64_t * nr) { *nf = static_cast<EmulCtx *>(v)->nfast; *nf2 = static_cast<EmulCtx *>(v)->nfast2; *nr = static_cast<EmulCtx *>(v)->nretry; }
+void emul_reasons_tier(void * v, int t, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasonsT[t][i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbitsT[t][i]; }
+void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,1,r,fb); }
+void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,0,r,fb); }
+void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
+void emul_counts4(void * v, uint64_t * n) { EmulCtx * c = static_cast<EmulCtx *>(v); n[0] = c->ntier[0]; n[1] = c->ntier[1]; n[2] = c->ntier[2]; n[3] = c->nretry; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
 
@@ -128,29 +129,49 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
 		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data(); WB.prof = 0;
-		FastBatch FB; FB.W = WB; FB.F = BP.fcaps; FB.dpsq_vst = c->H.dpsq_vst.data(); FB.garena = 0; FB.retry = 0;
-		FastBatch FB2 = FB; FB2.F = BP.fcaps2;
-		std::vector<uint8_t> lds(BP.fcaps.ldsbytes+64), garena(BP.fcaps.gbytes+64), lds2(BP.fcaps2.ldsbytes+64), garena2(BP.fcaps2.gbytes+64);
-		c->nfast = 0; c->nretry = 0; c->nfast2 = 0; for ( int i = 0; i < 64; ++i ) { c->reasons[i] = 0; c->reasons2[i] = 0; } for ( int i = 0; i < 24; ++i ) { c->flagbits[i] = 0; c->flagbits2[i] = 0; }
-		{ FastLds< FastTier<1> > L; L.base = lds.data(); fast_load_tables(L,BP.fcaps.nrows,BP.fcaps.nsup,T,c->H.dpsq_vst.data()); }
-		{ FastLds< FastTier<2> > L; L.base = lds2.data(); fast_load_tables(L,BP.fcaps2.nrows,BP.fcaps2.nsup,T,c->H.dpsq_vst.data()); }
+		FastBatch FB[3];
+		std::vector<uint8_t> lds[3];
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
-		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP && (c->H.nrows+1)*c->H.nsup <= FastLds< FastTier<1> >::tabcap;
+		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
+		bool tierok[3];
+		for ( int t = 0; t < 3; ++t )
+		{
+			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].garena = 0; FB[t].retry = 0;
+			lds[t].resize(BP.ftier[t].ldsbytes+64);
+			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= BP.ftier[t].pad;
+			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
+		}
+		c->nretry = 0;
+		{ FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
+		{ FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+		{ FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
 		{
 #if defined(DACC_FSTATS)
 			for ( int i = 0; i < 16; ++i ) dacc::g_fstat[i] = 0;
 #endif
-			bool fast = usefast && processWindowFast< FastTier<1> >(FB,wdx,lds.data(),garena.data());
+			bool done = false;
+			for ( int t = 0; t < 3 && !done; ++t )
+			{
+				if ( !tierok[t] ) continue;
+				if ( getenv("DACC_EMUL_POISON") )
+				{
+					// debugging aid: no window may depend on what an earlier window (or kernel) left in LDS
+					std::memset(lds[t].data(),atoi(getenv("DACC_EMUL_POISON")),lds[t].size());
+					if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
+					else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+					else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
+				}
+				if ( t == 0 ) done = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),0);
+				else if ( t == 1 ) done = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),0);
+				else done = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),0);
+				if ( done ) ++c->ntier[t];
+				else { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++; }
 #if defined(DACC_FSTATS)
-			for ( int i = 0; i < 16; ++i ) g_all.push_back(dacc::g_fstat[i]);
+				if ( t == 0 ) for ( int i = 0; i < 16; ++i ) g_all.push_back(dacc::g_fstat[i]);
 #endif
-			if ( fast ) { ++c->nfast; continue; }
-			if ( usefast ) { uint32_t const f = wout[wdx].flags; c->reasons[(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbits[b]++; }
-			fast = usefast && processWindowFast< FastTier<2> >(FB2,wdx,lds2.data(),garena2.data());
-			if ( fast ) { ++c->nfast2; continue; }
-			if ( usefast ) { uint32_t const f = wout[wdx].flags; c->reasons2[(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbits2[b]++; }
-			++c->nretry; processWindow(WB,wdx,arena.data());
+			}
+			if ( !done ) { ++c->nretry; processWindow(WB,wdx,arena.data()); }
 		}
 	}
 	c->windows.clear();

@@ -45,7 +45,7 @@ def lib():
         L.emul_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.emul_set_fast.argtypes = [C.c_void_p, C.c_int]
         L.emul_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.emul_counts3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.emul_counts4.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -68,9 +68,9 @@ class Emul:
         self.L.emul_set_fast(self.h, 1 if on else 0)
 
     def counts(self):
-        a = C.c_uint64(); b = C.c_uint64(); c = C.c_uint64()
-        self.L.emul_counts3(self.h, C.byref(a), C.byref(b), C.byref(c))
-        return a.value, b.value, c.value
+        n = (C.c_uint64 * 4)()
+        self.L.emul_counts4(self.h, n)
+        return tuple(int(x) for x in n)
 
     def set_error_profile(self, p_i, p_d, est_cor):
         self.L.emul_set_error_profile(self.h, p_i, p_d, est_cor)
