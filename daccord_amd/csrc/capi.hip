@@ -49,6 +49,26 @@ __global__ void __launch_bounds__(256) k_trace(TraceBatch B)
 		traceBlock(B,task,tid);
 }
 
+// Work distribution of the window kernels.  Windows differ in cost by orders of magnitude, so workgroups pull indices
+// from counters; workgroup b runs on XCD b%8 (observed placement), and the windows of one pile share its overlaps and
+// reads, so every XCD first drains its own contiguous eighth of the index range (its L2 keeps the pile's data) and
+// then steals from the other XCDs.  work[0..7] = per-XCD counters.  Returns false when nothing is left.
+__device__ __forceinline__ bool next_window(uint32_t * work, uint64_t const n, uint32_t & state, uint32_t & idx)
+{
+	uint32_t const home = blockIdx.x & 7;
+	while ( state < 8 )
+	{
+		uint32_t const q = (home + state) & 7;
+		uint64_t const lo = (n*q)>>3, hi = (n*(q+1))>>3;
+		uint32_t i = 0;
+		if ( threadIdx.x == 0 ) i = atomicAdd(work+q,1u);
+		i = __builtin_amdgcn_readfirstlane(i);
+		if ( lo + i < hi ) { idx = static_cast<uint32_t>(lo+i); return true; }
+		++state;
+	}
+	return false;
+}
+
 // one wavefront per workgroup, grid-stride over windows.  Workgroup b lands on XCD b%8 (observed
 // placement, used for L2 affinity only): give every XCD a contiguous run of windows so that the
 // windows of one pile (which share the pile's overlaps and reads) hit one L2.
@@ -57,6 +77,7 @@ __global__ void __launch_bounds__(256) k_trace(TraceBatch B)
 __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag, uint32_t const * list, uint32_t * work)
 {
 	uint8_t * arena = B.arena + static_cast<uint64_t>(blockIdx.x)*B.C.bytes;
+	if ( B.prof ) B.prof += 32*(blockIdx.x & 4095);
 	uint64_t const n = list ? list[0] : B.nwindows;
 	uint32_t it = 0;
 	while ( true )
@@ -81,6 +102,7 @@ template<int TIER>
 __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const * list, uint32_t * work)
 {
 	typedef FastTier<TIER> CT;
+	if ( FB.W.prof ) FB.W.prof += 32*(blockIdx.x & 4095);
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
 	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
 	uint8_t * garena = 0;
@@ -89,15 +111,11 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 	uint64_t const t0c = clock64(), t0w = wall_clock64();
 #endif
 	uint64_t const n = list ? list[0] : FB.W.nwindows;
-	uint32_t it = 0;
+	uint32_t it = 0, qstate = 0;
 	while ( true )
 	{
 		uint32_t i = 0;
-		if ( work )
-		{
-			if ( threadIdx.x == 0 ) i = atomicAdd(work,1u);
-			i = __builtin_amdgcn_readfirstlane(i);
-		}
+		if ( work ) { if ( !next_window(work,n,qstate,i) ) break; }
 		else { i = it*gridDim.x + blockIdx.x; ++it; }
 		if ( i >= n ) break;
 		uint64_t const w = list ? list[1+i] : i;
@@ -333,7 +351,7 @@ static int runDevice(dacc_ctx * c)
 		if ( c->usefast )
 		{
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
-			HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s));
 			// capacity tiers: every tier takes the windows the previous one handed over (list = 0: all windows)
 			uint32_t const * list = 0;
 			for ( int t = 0; t < 3; ++t )
@@ -341,7 +359,7 @@ static int runDevice(dacc_ctx * c)
 				if ( c->tier_ok[t] )
 				{
 					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.garena = 0; FB.retry = c->d_retry[t].p;
-					uint32_t * const work = (c->sched&1) ? c->d_work.p+t : static_cast<uint32_t *>(0);
+					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
 					if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
@@ -350,10 +368,10 @@ static int runDevice(dacc_ctx * c)
 				hipEventRecord(c->evtier[t],s);
 			}
 			// what is left (rare shapes) goes through the generic engine
-			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+3 : static_cast<uint32_t *>(0));
+			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0));
 		}
 		else
-			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,4*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+3 : static_cast<uint32_t *>(0)); }
+			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0)); }
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
 	if ( BP.piles.size() )
@@ -422,7 +440,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	if ( rc ) return rc;
 	hipStream_t const s = c->stream;
 	HIPCHK(c->d_err.ensure(4));
-	HIPCHK(c->d_prof.ensure(32)); HIPCHK(hipMemsetAsync(c->d_prof.p,0,32*sizeof(uint64_t),s));
+	HIPCHK(c->d_prof.ensure(32*4096)); HIPCHK(hipMemsetAsync(c->d_prof.p,0,32*4096*sizeof(uint64_t),s));   // one row of counters per workgroup (no contention)
 	HIPCHK(hipEventRecord(c->ev[5],s));
 	if ( (rc = upload(c,c->d_piles,BP.piles.data(),BP.piles.size())) ) return rc;
 	if ( (rc = upload(c,c->d_ovl,BP.ovl.data(),BP.ovl.size())) ) return rc;
@@ -474,13 +492,13 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = wg < 512 ? wg : 512;
 		c->win_grid = c->retry_grid;
-		HIPCHK(c->d_work.ensure(4));
+		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));
 	}
 	else
 	{
 		c->win_grid = wg;
-		HIPCHK(c->d_work.ensure(4));
+		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(wg*BP.caps.bytes));
 	}
 	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
@@ -526,7 +544,12 @@ int dacc_debug_profile(dacc_ctx * c, uint64_t * out32)
 	if ( !c || !out32 ) return DACC_EINVAL;
 	if ( !c->havebatch ) return DACC_ESTATE;
 	hipSetDevice(c->device);
-	HIPCHK(hipMemcpy(out32,c->d_prof.p,32*sizeof(uint64_t),hipMemcpyDeviceToHost));
+	{
+		std::vector<uint64_t> H(32*4096);
+		HIPCHK(hipMemcpy(H.data(),c->d_prof.p,32*4096*sizeof(uint64_t),hipMemcpyDeviceToHost));
+		for ( int i = 0; i < 32; ++i ) out32[i] = 0;
+		for ( int b = 0; b < 4096; ++b ) for ( int i = 0; i < 32; ++i ) { if ( i == 29 ) out32[i] = std::max(out32[i],H[32*b+i]); else out32[i] += H[32*b+i]; }
+	}
 	return DACC_OK;
 }
 

@@ -59,7 +59,7 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { enum : uint32_t { maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 616, rccap = 128, fcap = 96, siqcap = 64, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<1> { enum : uint32_t { maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 64, blcap = 96, conscap = 16384 + MAXCONS }; };
 template<> struct FastTier<2> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
 template<> struct FastTier<3> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
 
@@ -82,6 +82,7 @@ struct FastLds
 	LDSQ uint8_t * base;
 	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
 	static_assert((CT::precap & (CT::precap-1)) == 0,"precap must be a power of two: the bitonic sorts pad to one");
+	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
 	// ---- live during the whole window ----
 	FLD(str,uint8_t,CT::maxs*64,0)
 	FLD(slen,uint8_t,CT::maxs,e_str)
@@ -177,8 +178,9 @@ struct FastLds
 	FLD(rvalid,uint8_t,FNC+1,e_rnpool)
 	FLD(rmaxw,uint64_t,FNC+1,e_rvalid)
 	FLD(rtmask,uint64_t,FNC+1,e_rmaxw)
+	FLD(rfmask,uint64_t,FNC+1,e_rtmask)    // one bit per front k-mer (value mod 64) of the accepted reverse paths
 	// forward pool
-	FLD(f_w,uint64_t,CT::fcap,e_rtmask)
+	FLD(f_w,uint64_t,CT::fcap,e_rfmask)
 	FLD(f_parent,uint8_t,CT::fcap,e_f_w)
 	FLD(f_stretch,uint8_t,CT::fcap,e_f_parent)
 	FLD(f_pos,uint8_t,CT::fcap,e_f_stretch)
@@ -351,11 +353,9 @@ struct FastEngine
 		nlast = lo;
 		uint32_t const lp2 = next_pow2(nlast < 2 ? 2 : nlast);
 		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk()[i] = ~0ull;
-		uint32_t const p2 = next_pow2(npre < 2 ? 2 : npre);
-		for ( uint32_t i = npre + lane; i < p2; i += WSZ ) L.pre()[i] = ~0ull;
 		wv_sync();
 		wv_bitonic_sort(L.lastk(),lp2);
-		wv_bitonic_sort(L.pre(),p2);
+		wv_bitonic_sort_n(L.pre(),npre);
 	}
 
 	DEV void buildNodes(uint32_t const f)
@@ -579,10 +579,8 @@ struct FastEngine
 		}
 		if ( npre + base > CT::precap ) { over(1); return; }
 		npre += base;
-		uint32_t const q2 = next_pow2(npre < 2 ? 2 : npre);
-		for ( uint32_t i = npre + lane; i < q2; i += WSZ ) L.pre()[i] = ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.pre(),q2);
+		wv_bitonic_sort_n(L.pre(),npre);
 	}
 
 	// ================= stretches, once per activation state =================
@@ -1101,8 +1099,8 @@ struct FastEngine
 	// prepareTraverse :3582-3765 on the current view; result block at rc_*[rb ..rb+nrp), sorted order rc_ord, ranks rc_arw
 	DEV void reverseEnumerate(uint32_t const lastkmer, int32_t const lastnode, int64_t const lmax)
 	{
-		nrp = 0; narp = 0; rlastk = lastkmer;
-		for ( uint32_t i = 0; i < CT::blcap; ++i ) L.hbl_n()[i] = 0;
+		nrp = 0; narp = 0; rlastk = lastkmer; rfmcur = 0;
+		{ LDSQ uint64_t * Z = reinterpret_cast<LDSQ uint64_t *>(L.hbl_n()); for ( uint32_t i = 0; i < CT::blcap/8; ++i ) Z[i] = 0; }
 		uint32_t nrpst = 0;
 		if ( lastnode >= 0 )
 		{
@@ -1157,7 +1155,7 @@ struct FastEngine
 				}
 			}
 		}
-		fstat(0,nrp); fstat(1,narp); fstatadd(8,1); fstatadd(9,narp);
+		fstatadd(8,1); fstatadd(9,narp);
 		{ uint32_t nb = 0, mx = 0; for ( uint32_t i = 0; i < CT::blcap; ++i ) if ( L.hbl_n()[i] ) { ++nb; mx = i; } fstat(2,nb); fstat(3,mx); }
 		rmaxw = 0;
 		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[rb+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
@@ -1173,7 +1171,9 @@ struct FastEngine
 			}
 			L.rc_arw()[rb+i] = r;
 			uint32_t const rp = L.rc_ord()[rb+i];
-			L.rc_front()[rb+i] = rpFront(rp); L.rc_sbl()[rb+i] = L.rc_baselen()[rb+rp];
+			uint32_t const fr = rpFront(rp);
+			L.rc_front()[rb+i] = fr; L.rc_sbl()[rb+i] = L.rc_baselen()[rb+rp];
+			rfmcur |= 1ull << (fr & 63);
 		}
 	}
 	// one bit per scan target of the enumeration just finished (node id mod 64): a clear bit proves that a node was not a target
@@ -1218,7 +1218,7 @@ struct FastEngine
 	}
 
 	// ================= forward enumeration on the current view (lane 0) =================
-	uint32_t apqlo, apqhi;
+	uint64_t apqm0, apqm1;   // non empty base length buckets of the forward queue (base length < 128)
 	DEV int32_t extendPath(int32_t const parent, uint32_t const s)
 	{
 		if ( np >= CT::fcap || np >= 250 ) { over(512); return -1; }
@@ -1247,16 +1247,15 @@ struct FastEngine
 		}
 		else ipush<true>(H,hn,id,L.f_w());
 		L.hbl_n()[bl] = hn;
-		if ( bl < apqlo ) apqlo = bl;
-		if ( bl+1 > apqhi ) apqhi = bl+1;
+		if ( bl < 64 ) apqm0 |= 1ull << bl; else apqm1 |= 1ull << (bl-64);
 		return true;
 	}
 	// path tree of traverse :4838-5041 without the score-interval part (that one depends on the reverse block)
 	DEV void forwardEnumerate(int32_t const firstnode, int64_t const lmax)
 	{
-		np = 0; nfpop = 0; fmaxw = 0;
-		for ( uint32_t i = 0; i < CT::blcap; ++i ) L.hbl_n()[i] = 0;
-		apqlo = CT::blcap; apqhi = 0;
+		np = 0; nfpop = 0; fmaxw = 0; ffmask = 0;
+		{ LDSQ uint64_t * Z = reinterpret_cast<LDSQ uint64_t *>(L.hbl_n()); for ( uint32_t i = 0; i < CT::blcap/8; ++i ) Z[i] = 0; }
+		apqm0 = 0; apqm1 = 0;
 		{
 			MIt it; byFirstBegin(it,firstnode);
 			for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
@@ -1265,7 +1264,11 @@ struct FastEngine
 				if ( id < 0 || !apqPush(id) ) return;
 			}
 		}
-		for ( uint32_t zz = apqlo; zz < apqhi; ++zz )
+		// buckets in increasing base length; an extension is strictly longer than its parent, so it lands in a later bucket
+		while ( apqm0 | apqm1 )
+		{
+			uint32_t const zz = apqm0 ? static_cast<uint32_t>(__builtin_ctzll(apqm0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(apqm1));
+			if ( zz < 64 ) apqm0 &= apqm0-1; else apqm1 &= apqm1-1;
 			while ( L.hbl_n()[zz] )
 			{
 				LDSQ uint8_t * H = L.hbl() + 12*zz; uint32_t hn = L.hbl_n()[zz];
@@ -1278,7 +1281,8 @@ struct FastEngine
 					uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path];
 					uint64_t const pw = L.f_w()[path];
 					int32_t const psfo = sfFind(ps,ppos - (L.sslen()[ps]-1));
-					L.fp_front()[nfpop] = L.nv()[L.slast()[ps]]; L.fp_cl()[nfpop] = ppos;
+					uint32_t const pfront = L.nv()[L.slast()[ps]];
+					L.fp_front()[nfpop] = pfront; L.fp_cl()[nfpop] = ppos; ffmask |= 1ull << (pfront & 63);
 					L.fp_adj()[nfpop] = psfo >= 0 ? (pw - wlF(psfo)) : pw;
 					if ( pw > fmaxw ) fmaxw = pw;
 				}
@@ -1306,6 +1310,7 @@ struct FastEngine
 					}
 				}
 			}
+		}
 	}
 	// scans of the forward enumeration look for stretches whose first node equals a target; splitting `par` at `ln`
 	// changes the answer only for targets par.first (parent vs first piece) and ln (second piece)
@@ -1357,13 +1362,14 @@ struct FastEngine
 		}
 		return o;
 	}
-	DEV void combinePair(uint32_t const base, uint32_t const nacc2, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
+	DEV void combinePair(uint32_t const base, uint32_t const nacc2, uint64_t const rfm, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
 	{
 		nsiq = 0;
 		for ( uint32_t pi = 0; pi < nfpop; ++pi )
 		{
-			int64_t const candlen = static_cast<int64_t>(L.fp_cl()[pi]) + k;
 			uint32_t const front = L.fp_front()[pi];
+			if ( !((rfm >> (front & 63)) & 1) ) continue;   // no reverse path starts at this k-mer
+			int64_t const candlen = static_cast<int64_t>(L.fp_cl()[pi]) + k;
 			uint32_t lo = 0, hi = nacc2;
 			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.rc_front()[base+mid] < front ) lo = mid+1; else hi = mid; }
 			uint32_t e = lo;
@@ -1386,6 +1392,7 @@ struct FastEngine
 				fstat(6,nsiq);
 			}
 		}
+		if ( nsiq ) fstatadd(2,1);
 		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
 		uint32_t pn = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
@@ -1476,6 +1483,7 @@ struct FastEngine
 	// the pair loop runs on lane 0; it comes back to the wavefront only for the feasibility of a temporary middle
 	// piece (a stretch split at both its first and its last candidate)
 	uint32_t pl_fi, pl_li, pl_midA, pl_midB, pl_midpar; bool pl_midready; uint64_t ftmask;
+	uint64_t ffmask, rfmcur;   // front k-mer bit sets (value mod 64) of the current forward tree / of the reverse block just enumerated
 
 	// returns 0 = all pairs done, 1 = needs the middle piece [pl_midA,pl_midB] of stretch pl_midpar
 	DEV uint32_t pairLoop(int64_t const lmin, int64_t const lmax)
@@ -1506,7 +1514,7 @@ struct FastEngine
 						reverseEnumerate(lastk,lastnode,lmax);
 						if ( flags ) return 0;
 						L.rbase()[li] = rb; L.rn()[li] = narp; L.rnpool()[li] = nrp; L.rvalid()[li] = 1; RMAX[li] = rmaxw;
-						L.rtmask()[li] = reverseTargetMask(lastnode,lmax);
+						L.rtmask()[li] = reverseTargetMask(lastnode,lmax); L.rfmask()[li] = rfmcur;
 						rctop = rb + nrp;
 						pcount(22,pclock()-tq0); pcount(25,1);
 					}
@@ -1569,8 +1577,11 @@ struct FastEngine
 					if ( !rcached ) { rb = rctop; reverseEnumerate(lastk,lastnode,lmax); if ( flags ) return 0; }
 					if ( !fcached ) { forwardEnumerate(firstnode,lmax); if ( flags ) return 0; fcur_fi = fi; fcur_li = li; }
 				}
-				if ( rcached ) { base = L.rbase()[li]; nacc2 = L.rn()[li]; } else { base = rb; nacc2 = narp; }
-				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,lmin,lmax,16); pcount(24,pclock()-tq0); }
+				uint64_t rfm;
+				if ( rcached ) { base = L.rbase()[li]; nacc2 = L.rn()[li]; rfm = L.rfmask()[li]; } else { base = rb; nacc2 = narp; rfm = rfmcur; }
+				fstatadd(0,1);
+				if ( (rfm & ffmask) == 0 ) { pcount(28,1); fstatadd(1,1); continue; }   // the forward tree and the reverse block share no junction k-mer
+				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,rfm,lmin,lmax,16); pcount(24,pclock()-tq0); }
 				if ( !rcached || !fcached ) pcount(21,1);
 				if ( flags ) return 0;
 			}
@@ -1688,10 +1699,17 @@ struct FastEngine
 			{
 				double const * row = T.dpnorm + static_cast<uint64_t>(i)*T.nsup;
 				vprod = 1.0;
-				for ( uint32_t j = 0; j < mao; ++j )
+				// same multiplication order as the reference; the table loads of four strings are issued together
+				for ( uint32_t j = 0; j < mao; j += 4 )
 				{
-					uint32_t const len = L.slen()[j];
-					if ( len ) vprod *= ((len-1) < static_cast<uint32_t>(T.nsup) ? row[len-1] : 0.0);
+					uint32_t const l0 = L.slen()[j], l1 = j+1 < mao ? L.slen()[j+1] : 0, l2 = j+2 < mao ? L.slen()[j+2] : 0, l3 = j+3 < mao ? L.slen()[j+3] : 0;
+					uint32_t const ns = static_cast<uint32_t>(T.nsup);
+					double const r0 = (l0 && (l0-1) < ns) ? row[l0-1] : 0.0, r1 = (l1 && (l1-1) < ns) ? row[l1-1] : 0.0;
+					double const r2 = (l2 && (l2-1) < ns) ? row[l2-1] : 0.0, r3 = (l3 && (l3-1) < ns) ? row[l3-1] : 0.0;
+					if ( l0 ) vprod *= r0;
+					if ( l1 ) vprod *= r1;
+					if ( l2 ) vprod *= r2;
+					if ( l3 ) vprod *= r3;
 				}
 			}
 			union { double d; uint64_t u; } cv; cv.d = vprod;
@@ -1808,7 +1826,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 #endif
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
 	E.rctop = 0; E.np = E.nfpop = E.nsiq = E.ncdh = E.nacc = 0; E.fcur_fi = E.fcur_li = -1; E.rb = E.nrp = E.narp = E.rlastk = 0; E.rmaxw = E.fmaxw = 0;
-	E.apqlo = E.apqhi = 0; E.cfree = 0; E.pl_fi = E.pl_li = E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false; E.ftmask = 0; E.V.nadd = 0; E.V.r0 = E.V.r1 = 0xFFFF;
+	E.apqm0 = E.apqm1 = 0; E.cfree = 0; E.pl_fi = E.pl_li = E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false; E.ftmask = 0; E.ffmask = 0; E.rfmcur = 0; E.V.nadd = 0; E.V.r0 = E.V.r1 = 0xFFFF;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 	E.L.base = lds;
@@ -1858,21 +1876,44 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 	uint32_t toolong = 0;
 	if ( mao )
 	{
-		uint64_t const aoff = B.boff[pile.aread];
-		for ( uint32_t p = lane; p < B.P.w; p += WSZ ) L.str()[p] = readBase(B.bps,aoff,B.rlen[pile.aread],false,astart+p);
-		if ( lane == 0 ) L.slen()[0] = B.P.w;
-		for ( uint32_t j = 1; j < mao; ++j )
+		// string descriptors, one lane per string (a single round of dependent HBM loads for the whole window):
+		// mfirst[j] = first base | read length << 32, mlast[j] = byte offset of the read | inverse << 63
+		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
-			uint32_t const z = static_cast<uint32_t>(L.pre()[j-1] & 0xFFFFFFFFu);
-			DevOvl const & o = ov[z];
-			uint64_t const row = o.wtoff + (y - o.y0);
-			uint32_t const bs = B.wt_b[row], be = B.wt_e[row];
-			uint32_t const len = be-bs;
-			if ( len > 64 ) { toolong = 1; continue; }
-			uint64_t const off = B.boff[o.bread]; uint32_t const rl = B.rlen[o.bread]; bool const inv = o.flags & 1;
-			for ( uint32_t p = lane; p < len; p += WSZ ) L.str()[j*64+p] = readBase(B.bps,off,rl,inv,bs+p);
-			if ( lane == 0 ) L.slen()[j] = len;
+			uint32_t bs, len, rl; uint64_t off; bool inv;
+			if ( j == 0 ) { bs = astart; len = B.P.w; off = B.boff[pile.aread]; rl = B.rlen[pile.aread]; inv = false; }
+			else
+			{
+				uint32_t const z = static_cast<uint32_t>(L.pre()[j-1] & 0xFFFFFFFFu);
+				DevOvl const & o = ov[z];
+				uint64_t const row = o.wtoff + (y - o.y0);
+				bs = B.wt_b[row]; len = B.wt_e[row]-bs;
+				off = B.boff[o.bread]; rl = B.rlen[o.bread]; inv = o.flags & 1;
+			}
+			if ( len > 64 ) { toolong = 1; len = 0; }
+			L.slen()[j] = len;
+			L.mfirst()[j] = bs | (static_cast<uint64_t>(rl)<<32);
+			L.mlast()[j] = off | (static_cast<uint64_t>(inv ? 1 : 0)<<63);
 		}
+		toolong = wv_any(toolong);
+		wv_sync();
+		// bases: lane p of string j; four strings per round so that their loads are in flight together
+		for ( uint32_t j0 = 0; j0 < mao; j0 += 4 )
+			for ( uint32_t p = lane; p < 64; p += WSZ )
+			{
+				uint8_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+				bool const a0 = p < L.slen()[j0], a1 = j0+1 < mao && p < L.slen()[j0+1], a2 = j0+2 < mao && p < L.slen()[j0+2], a3 = j0+3 < mao && p < L.slen()[j0+3];
+				#define DACC_LB(u) { uint64_t const d0 = L.mfirst()[j0+u], d1 = L.mlast()[j0+u]; v##u = readBase(B.bps,d1 & 0x7FFFFFFFFFFFFFFFull,static_cast<uint32_t>(d0>>32),(d1>>63) != 0,static_cast<uint32_t>(d0)+p); }
+				if ( a0 ) DACC_LB(0)
+				if ( a1 ) DACC_LB(1)
+				if ( a2 ) DACC_LB(2)
+				if ( a3 ) DACC_LB(3)
+				#undef DACC_LB
+				if ( a0 ) L.str()[(j0+0)*64+p] = v0;
+				if ( a1 ) L.str()[(j0+1)*64+p] = v1;
+				if ( a2 ) L.str()[(j0+2)*64+p] = v2;
+				if ( a3 ) L.str()[(j0+3)*64+p] = v3;
+			}
 	}
 	wv_sync();
 	if ( toolong ) { FFAIL(4) }

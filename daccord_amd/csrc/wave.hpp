@@ -148,6 +148,36 @@ DEV void wv_bitonic_sort(PT A, uint32_t const n)
 		}
 }
 
+// ascending sort of n (any n) 64-bit keys: bitonic network in its all-ascending form (first sub-step of every merge is
+// a flip), so that the virtual +infinity padding up to the next power of two never moves and its pairs are skipped
+template<typename PT>
+DEV void wv_bitonic_sort_n(PT A, uint32_t const n)
+{
+	int const lane = wv_lane();
+	uint32_t n2 = 1; while ( n2 < n ) n2 <<= 1;
+	for ( uint32_t k = 2; k <= n2; k <<= 1 )
+	{
+		uint32_t const h = k>>1;
+		for ( uint32_t t = lane; t < (n2>>1); t += WSZ )
+		{
+			uint32_t const blk = t / h, off = t - blk*h;
+			uint32_t const i = blk*k + off, l = blk*k + (k-1-off);
+			if ( l < n ) { uint64_t const a = A[i], b = A[l]; if ( a > b ) { A[i] = b; A[l] = a; } }
+		}
+		wv_sync();
+		for ( uint32_t j = k>>2; j > 0; j >>= 1 )
+		{
+			for ( uint32_t t = lane; t < (n2>>1); t += WSZ )
+			{
+				uint32_t const i = ((t & ~(j-1)) << 1) | (t & (j-1));
+				uint32_t const l = i | j;
+				if ( l < n ) { uint64_t const a = A[i], b = A[l]; if ( a > b ) { A[i] = b; A[l] = a; } }
+			}
+			wv_sync();
+		}
+	}
+}
+
 // ascending bitonic sort of n (power of two) indices by (key[idx], idx); 0xFFFFFFFF pads sort last
 DEV void wv_bitonic_sort_idx(uint32_t * I, uint64_t const * K, uint32_t const n)
 {

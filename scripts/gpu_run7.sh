@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+( timeout 300 python -m pytest tests -m gpu -x -q ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+( timeout 600 python bench.py --reads 1000 --steps 2 --warmup 1 --no-cpu ) > gpurun_out/bench_1000.log 2>&1; echo "rc=$?" >> gpurun_out/bench_1000.log
+tail -n 3 gpurun_out/pytest_gpu.log; tail -n 2 gpurun_out/bench_1000.log
