@@ -1009,27 +1009,21 @@ struct FastEngine
 
 	// ================= reverse enumeration on the current view (lane 0) =================
 	uint32_t rb, nrp, narp, rlastk; uint64_t rmaxw, fmaxw;
-	DEV int32_t extendReversePath(uint32_t const parent, uint32_t const s)
+	// extendReversePath :4058-4105 with the parent's fields and the feasible entry sfo = csfFind(s,ppos) held in registers
+	// (checkReversePathFeasiblePosition :4130-4159 looks the same entry up again: the check position is the parent's)
+	DEV int32_t extendReversePath(uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl, int32_t const sfo, uint64_t const wr)
 	{
 		if ( rb+nrp >= CT::rccap || nrp >= 250 ) { over(512); return -1; }
 		uint32_t const id = nrp++;
-		uint32_t const ppos = L.rc_pos()[rb+parent], plen = L.rc_len()[rb+parent];
-		int32_t const sfo = csfFind(s,ppos);
-		uint64_t weight = L.rc_w()[rb+parent]; uint32_t baselen = L.rc_baselen()[rb+parent];
-		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? wuR(sfo) : 0; }
-		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += wuR(sfo) - w1R(sfo); }
-		uint32_t const npos = ppos + L.sslen()[s]-1;
+		uint32_t const slen = L.sslen()[s];
+		uint64_t weight = pw; uint32_t baselen = pbl;
+		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wr : 0; }
+		else { baselen += slen-1; if ( sfo >= 0 ) weight += wr - w1R(sfo); }
+		uint32_t const npos = ppos + slen-1;
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --nrp; return -1; }
 		L.rc_parent()[rb+id] = parent; L.rc_stretch()[rb+id] = s; L.rc_len()[rb+id] = plen+1; L.rc_pos()[rb+id] = npos;
 		L.rc_w()[rb+id] = weight; L.rc_baselen()[rb+id] = baselen;
 		return id;
-	}
-	DEV bool checkReversePathFeasiblePosition(uint32_t const id) const
-	{
-		uint32_t const s = L.rc_stretch()[rb+id];
-		uint32_t const checkpos = L.rc_pos()[rb+id] - (L.sslen()[s]-1);
-		int32_t const f = csfFind(s,checkpos);
-		return f >= 0 && wuR(f) >= FW_THRES_05;
 	}
 	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len()[rb+id] ? L.nv()[L.sfirst()[L.rc_stretch()[rb+id]]] : rlastk; }
 	DEV bool arpLess(uint8_t const a, uint8_t const b) const
@@ -1114,30 +1108,34 @@ struct FastEngine
 		{
 			uint32_t const rp = L.rpst()[0];
 			ipop<false>(L.rpst(),nrpst,W);
-			uint32_t const bl = L.rc_baselen()[rb+rp];
+			uint32_t const bl = L.rc_baselen()[rb+rp], ppos = L.rc_pos()[rb+rp], plen = L.rc_len()[rb+rp];
+			uint64_t const pw = W[rp];
 			if ( bl >= CT::blcap ) { over(2048); return; }
 			LDSQ uint8_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
 			if ( hn == 12 )
 			{
-				if ( W[rp] <= W[H[0]] ) continue;
+				if ( pw <= W[H[0]] ) continue;
 				else ipop<true>(H,hn,W);
 			}
 			ipush<true>(H,hn,rp,W);
 			L.hbl_n()[bl] = hn;
 			if ( narp >= 250 ) { over(512); return; }
 			L.rc_ord()[rb+narp++] = rp;
-			if ( L.rc_len()[rb+rp] == 0 )
+			if ( plen == 0 )
 			{
 				MIt it; byLastBegin(it,lastnode);
 				for ( int32_t sx = byLastNext(it); sx >= 0; sx = byLastNext(it) )
 				{
-					int32_t const rpe = extendReversePath(rp,sx);
+					int32_t const sfo = csfFind(sx,ppos);
+					uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
+					if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;     // the new path would be dropped right away
+					int32_t const rpe = extendReversePath(rp,sx,ppos,plen,pw,bl,sfo,wr);
 					if ( rpe < 0 ) return;
-					if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst(),nrpst,rpe,W); }
-					else --nrp;
+					if ( nrpst >= 250 ) { over(512); return; }
+					ipush<false>(L.rpst(),nrpst,rpe,W);
 				}
 			}
-			else if ( static_cast<int64_t>(L.rc_baselen()[rb+rp]) < (lmax+1)/2 )
+			else if ( static_cast<int64_t>(bl) < (lmax+1)/2 )
 			{
 				uint32_t const b = L.rc_stretch()[rb+rp];
 				uint32_t const bf = L.sfirst()[b];
@@ -1147,16 +1145,18 @@ struct FastEngine
 					uint32_t const a = ax;
 					if ( linkOk(a,b) )
 					{
-						int32_t const rpe = extendReversePath(rp,a);
+						int32_t const sfo = csfFind(a,ppos);
+						uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
+						if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;
+						int32_t const rpe = extendReversePath(rp,a,ppos,plen,pw,bl,sfo,wr);
 						if ( rpe < 0 ) return;
-						if ( checkReversePathFeasiblePosition(rpe) ) { if ( nrpst >= 250 ) { over(512); return; } ipush<false>(L.rpst(),nrpst,rpe,W); }
-						else --nrp;
+						if ( nrpst >= 250 ) { over(512); return; }
+						ipush<false>(L.rpst(),nrpst,rpe,W);
 					}
 				}
 			}
 		}
 		fstatadd(8,1); fstatadd(9,narp);
-		{ uint32_t nb = 0, mx = 0; for ( uint32_t i = 0; i < CT::blcap; ++i ) if ( L.hbl_n()[i] ) { ++nb; mx = i; } fstat(2,nb); fstat(3,mx); }
 		rmaxw = 0;
 		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[rb+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
 		arpSort(L.rc_ord()+rb,L.rc_ord()+rb+narp);
@@ -1219,31 +1219,30 @@ struct FastEngine
 
 	// ================= forward enumeration on the current view (lane 0) =================
 	uint64_t apqm0, apqm1;   // non empty base length buckets of the forward queue (base length < 128)
-	DEV int32_t extendPath(int32_t const parent, uint32_t const s)
+	// extendPath :3989-4056 with the parent's fields, the feasible entry sfo = sfFind(s,ppos) and its weight in registers;
+	// the new path's position, base length and weight are returned in npos, nbl, nw
+	DEV int32_t extendPath(int32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl,
+		int32_t const sfo, uint64_t const wf, uint32_t & npos, uint32_t & nbl, uint64_t & nw)
 	{
 		if ( np >= CT::fcap || np >= 250 ) { over(512); return -1; }
 		uint32_t const id = np++;
-		uint32_t const ppos = parent >= 0 ? L.f_pos()[parent] : 0;
-		uint32_t const plen = parent >= 0 ? L.f_len()[parent] : 0;
-		uint64_t weight = parent >= 0 ? L.f_w()[parent] : 0;
-		uint32_t baselen = parent >= 0 ? L.f_baselen()[parent] : 0;
-		int32_t const sfo = sfFind(s,ppos);
-		if ( plen == 0 ) { baselen = L.sslen()[s]+k-1; weight = sfo >= 0 ? wuF(sfo) : 0; }
-		else { baselen += L.sslen()[s]-1; if ( sfo >= 0 ) weight += wuF(sfo) - w1F(sfo); }
-		uint32_t const npos = ppos + (L.sslen()[s]-1);
+		uint32_t const slen = L.sslen()[s];
+		uint64_t weight = pw; uint32_t baselen = pbl;
+		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wf : 0; }
+		else { baselen += slen-1; if ( sfo >= 0 ) weight += wf - w1F(sfo); }
+		npos = ppos + (slen-1); nbl = baselen; nw = weight;
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --np; return -1; }
 		L.f_parent()[id] = parent >= 0 ? parent : 0xFF; L.f_stretch()[id] = s; L.f_len()[id] = plen+1; L.f_pos()[id] = npos;
 		L.f_w()[id] = weight; L.f_baselen()[id] = baselen;
 		return id;
 	}
-	DEV bool apqPush(uint32_t const id)
+	DEV bool apqPush(uint32_t const id, uint32_t const bl, uint64_t const w)
 	{
-		uint32_t const bl = L.f_baselen()[id];
 		if ( bl >= CT::blcap ) { over(2048); return false; }
 		LDSQ uint8_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
 		if ( hn == 12 )
 		{
-			if ( L.f_w()[id] > L.f_w()[H[0]] ) { ipop<true>(H,hn,L.f_w()); ipush<true>(H,hn,id,L.f_w()); }
+			if ( w > L.f_w()[H[0]] ) { ipop<true>(H,hn,L.f_w()); ipush<true>(H,hn,id,L.f_w()); }
 		}
 		else ipush<true>(H,hn,id,L.f_w());
 		L.hbl_n()[bl] = hn;
@@ -1260,8 +1259,11 @@ struct FastEngine
 			MIt it; byFirstBegin(it,firstnode);
 			for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
 			{
-				int32_t const id = extendPath(-1,sx);
-				if ( id < 0 || !apqPush(id) ) return;
+				int32_t const sfo = sfFind(sx,0);
+				uint64_t const wf = sfo >= 0 ? wuF(sfo) : 0;
+				uint32_t npos, nbl; uint64_t nw;
+				int32_t const id = extendPath(-1,sx,0,0,0,0,sfo,wf,npos,nbl,nw);
+				if ( id < 0 || !apqPush(id,nbl,nw) ) return;
 			}
 		}
 		// buckets in increasing base length; an extension is strictly longer than its parent, so it lands in a later bucket
@@ -1276,34 +1278,34 @@ struct FastEngine
 				ipop<true>(H,hn,L.f_w());
 				L.hbl_n()[zz] = hn;
 				if ( nfpop >= CT::fcap ) { over(512); return; }
+				uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path], plen = L.f_len()[path], pbl = L.f_baselen()[path];
+				uint64_t const pw = L.f_w()[path];
+				uint32_t const lastn = L.slast()[ps];
 				{
 					// what the score intervals need of this path: junction k-mer, candidate length, weight without the junction node
-					uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path];
-					uint64_t const pw = L.f_w()[path];
 					int32_t const psfo = sfFind(ps,ppos - (L.sslen()[ps]-1));
-					uint32_t const pfront = L.nv()[L.slast()[ps]];
+					uint32_t const pfront = L.nv()[lastn];
 					L.fp_front()[nfpop] = pfront; L.fp_cl()[nfpop] = ppos; ffmask |= 1ull << (pfront & 63);
 					L.fp_adj()[nfpop] = psfo >= 0 ? (pw - wlF(psfo)) : pw;
 					if ( pw > fmaxw ) fmaxw = pw;
 				}
 				L.fpop()[nfpop++] = path;
-				uint32_t const pbl = L.f_baselen()[path];
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 				{
-					uint32_t const lastn = L.slast()[L.f_stretch()[path]];
 					MIt it; byFirstBegin(it,lastn);
 					for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
 					{
 						uint32_t const s = sx;
-						int32_t const sfo = sfFind(s,L.f_pos()[path]);
+						int32_t const sfo = sfFind(s,ppos);
 						uint64_t const eweight = sfo >= 0 ? wuF(sfo) : 0;
 						if ( eweight >= FW_THRES_01 )
 						{
-							int32_t const ep = extendPath(path,s);
+							uint32_t npos, nbl; uint64_t nw;
+							int32_t const ep = extendPath(path,s,ppos,plen,pw,pbl,sfo,eweight,npos,nbl,nw);
 							if ( ep < 0 ) return;
-							if ( L.f_w()[ep] >= FW_THRES_01 && static_cast<int64_t>(L.f_pos()[ep]) + k <= lmax )
+							if ( nw >= FW_THRES_01 && static_cast<int64_t>(npos) + k <= lmax )
 							{
-								if ( !apqPush(ep) ) return;
+								if ( !apqPush(ep,nbl,nw) ) return;
 							}
 							else --np;
 						}

@@ -150,28 +150,57 @@ DEV void wv_bitonic_sort(PT A, uint32_t const n)
 
 // ascending sort of n (any n) 64-bit keys: bitonic network in its all-ascending form (first sub-step of every merge is
 // a flip), so that the virtual +infinity padding up to the next power of two never moves and its pairs are skipped
+// The compare-exchange pairs of one step are disjoint; a lane loads up to four of them before it stores, so that the
+// LDS round trips overlap.
+template<typename PT>
+DEV void wv_cx4(PT A, uint32_t const n, uint32_t const i0, uint32_t const l0, uint32_t const i1, uint32_t const l1,
+	uint32_t const i2, uint32_t const l2, uint32_t const i3, uint32_t const l3)
+{
+	bool const v0 = l0 < n, v1 = l1 < n, v2 = l2 < n, v3 = l3 < n;
+	uint64_t a0 = 0, b0 = 0, a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+	if ( v0 ) { a0 = A[i0]; b0 = A[l0]; }
+	if ( v1 ) { a1 = A[i1]; b1 = A[l1]; }
+	if ( v2 ) { a2 = A[i2]; b2 = A[l2]; }
+	if ( v3 ) { a3 = A[i3]; b3 = A[l3]; }
+	if ( v0 && a0 > b0 ) { A[i0] = b0; A[l0] = a0; }
+	if ( v1 && a1 > b1 ) { A[i1] = b1; A[l1] = a1; }
+	if ( v2 && a2 > b2 ) { A[i2] = b2; A[l2] = a2; }
+	if ( v3 && a3 > b3 ) { A[i3] = b3; A[l3] = a3; }
+}
 template<typename PT>
 DEV void wv_bitonic_sort_n(PT A, uint32_t const n)
 {
 	int const lane = wv_lane();
 	uint32_t n2 = 1; while ( n2 < n ) n2 <<= 1;
+	uint32_t const half = n2>>1;
 	for ( uint32_t k = 2; k <= n2; k <<= 1 )
 	{
 		uint32_t const h = k>>1;
-		for ( uint32_t t = lane; t < (n2>>1); t += WSZ )
+		for ( uint32_t t = lane; t < half; t += 4*WSZ )
 		{
-			uint32_t const blk = t / h, off = t - blk*h;
-			uint32_t const i = blk*k + off, l = blk*k + (k-1-off);
-			if ( l < n ) { uint64_t const a = A[i], b = A[l]; if ( a > b ) { A[i] = b; A[l] = a; } }
+			uint32_t I[4], Lx[4];
+			#pragma unroll
+			for ( uint32_t u = 0; u < 4; ++u )
+			{
+				uint32_t const tt = t + u*WSZ;
+				uint32_t const blk = tt / h, off = tt - blk*h;
+				I[u] = blk*k + off; Lx[u] = (tt < half) ? (blk*k + (k-1-off)) : n;
+			}
+			wv_cx4(A,n,I[0],Lx[0],I[1],Lx[1],I[2],Lx[2],I[3],Lx[3]);
 		}
 		wv_sync();
 		for ( uint32_t j = k>>2; j > 0; j >>= 1 )
 		{
-			for ( uint32_t t = lane; t < (n2>>1); t += WSZ )
+			for ( uint32_t t = lane; t < half; t += 4*WSZ )
 			{
-				uint32_t const i = ((t & ~(j-1)) << 1) | (t & (j-1));
-				uint32_t const l = i | j;
-				if ( l < n ) { uint64_t const a = A[i], b = A[l]; if ( a > b ) { A[i] = b; A[l] = a; } }
+				uint32_t I[4], Lx[4];
+				#pragma unroll
+				for ( uint32_t u = 0; u < 4; ++u )
+				{
+					uint32_t const tt = t + u*WSZ;
+					I[u] = ((tt & ~(j-1)) << 1) | (tt & (j-1)); Lx[u] = (tt < half) ? (I[u] | j) : n;
+				}
+				wv_cx4(A,n,I[0],Lx[0],I[1],Lx[1],I[2],Lx[2],I[3],Lx[3]);
 			}
 			wv_sync();
 		}

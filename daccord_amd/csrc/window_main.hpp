@@ -51,6 +51,9 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 	E.C = B.C; E.T = B.T; E.P = B.P;
 	E.lane = wv_lane();
 	E.flags = 0;
+	// no member may carry a value over from the previous window (early returns on overflow skip assignments)
+	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = 0; E.nmfirst = E.nmlast = 0; E.nstretch = E.nlinks = E.nsf = E.ncsf = E.nrl = 0;
+	E.nrp = E.narp = E.np = E.nsiq = E.ncdh = E.nacc = E.conso = 0; E.maxsiq = E.maxlinks = 0;
 	E.prof = B.prof;
 #if defined(DACC_STATS)
 	for ( int i = 0; i < 16; ++i ) E.st[i] = 0;
@@ -151,18 +154,23 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 				// setup + filterFreq + computeFeasibleKmerPositions (:2211-2228)
 				PROF_T0
 				E.buildInstances();
+				E.flags = wv_or(E.flags); if ( E.flags ) break;
 				PROF(E,2)
 				E.buildNodes(ff > 1 ? ff : 1);
+				E.flags = wv_or(E.flags); if ( E.flags ) break;
 				PROF(E,3)
 				E.buildSuccessors(mao);
 				PROF(E,4)
 				E.computeFeasible();
+				E.flags = wv_or(E.flags); if ( E.flags ) break;
 				PROF(E,5)
 				if ( ff == 0 )
 				{
 					// gap filling (:2233-2268)
 					E.levelSuccessors2();
+					E.flags = wv_or(E.flags); if ( E.flags ) break;
 					E.buildNodes(1);
+					E.flags = wv_or(E.flags); if ( E.flags ) break;
 					E.buildSuccessors(mao);
 					E.computeFeasible();
 				}
