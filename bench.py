@@ -117,6 +117,16 @@ def main():
         dom = max(kern, key=kern.get)
         # algorithmic bytes (every input byte once + corrected bases) of the launch / its duration
         achieved = t.algo_bytes / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
+        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+        # profiles/r01_pmc/): only quoted when it was collected on this very workload and kernel
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            wl = pm["workload"]
+            if (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) == (args.reads, args.readlen, args.coverage, args.k) and pm["kernel"] == dom:
+                traffic = int(pm["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
         res = {
             "metric": "corrected Mbase/s (whole node), synthetic 20x PacBio piles",
             "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -128,7 +138,7 @@ def main():
                        "trace_blocks_per_gpu": int(t.nblocks), "corrected_bases_per_gpu": int(len(bases)),
                        "sharding": "static by A-read, no data-path collective; RCCL gather of corrected bases per step"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": None,
+                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                          "algo_bytes_per_launch": int(t.algo_bytes), "kernel_ms": {k: round(v, 3) for k, v in kern.items()}, "window_ms_all_tiers": round(wsum / args.steps, 3),
                          "windows_handed_on": {"tier1": touts[0], "tier2": touts[1], "tier3_to_generic": touts[2]}},
             "setup_s": {"generate": round(tgen, 2), "first_pass_incl_h2d": round(tfirst, 2), "h2d_ms": round(tm0.h2d_ms, 2)},

@@ -32,6 +32,8 @@
   static inline uint64_t wv_lanemask_lt() { return 0ull; }
   static inline uint32_t wv_bcast(uint32_t v, int) { return v; }
   static inline uint64_t wv_bcast64(uint64_t v, int) { return v; }
+  static inline uint32_t wv_uni(uint32_t v) { return v; }
+  static inline uint64_t wv_uni64(uint64_t v) { return v; }
   static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
   static inline void atomicOrFlag(uint32_t * f) { *f |= 1u; }
   }
