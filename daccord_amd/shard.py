@@ -48,7 +48,12 @@ def gather_fragments(frags, bases, device="cpu", dst=0):
     if bb.size:
         buf[fb.size:fb.size + bb.size] = torch.from_numpy(bb.copy()).to(device)
     out = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, out, dst=dst)
+    try:
+        dist.gather(buf, out, dst=dst)
+    except (RuntimeError, NotImplementedError):
+        # backend without gather: every rank collects (same result on dst, a little more traffic)
+        out = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
+        dist.all_gather(out, buf)
     if rank != dst:
         return None, None
     allf, allb, off = [], [], 0
