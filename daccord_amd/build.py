@@ -6,6 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libdaccord_hip.so")
+IOLIB = os.path.join(_HERE, "libdaccord_io.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value"]
@@ -21,15 +22,26 @@ def build_hip(force=False, verbose=False):
     if force or _newer(LIB, srcs):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "host_tables.cpp"),
-                                       os.path.join(CSRC, "host_piles.cpp")]
+                                       os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_io.cpp")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     return LIB
 
 
+def build_io(force=False):
+    """Host-only library with the .db / .las readers and writers (include/daccord_io.h) and the pile selection;
+    the same objects are also linked into libdaccord_hip.so."""
+    srcs = [os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_piles.cpp"),
+            os.path.join(_HERE, "..", "include", "daccord_io.h"), os.path.join(_HERE, "..", "include", "daccord_hip.h")]
+    if force or _newer(IOLIB, srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", IOLIB, srcs[0], srcs[1]])
+    return IOLIB
+
+
 def build_all(force=False, verbose=False):
     from . import synth
     build_hip(force, verbose)
+    build_io(force)
     synth.build(force)
     return LIB

@@ -115,3 +115,22 @@ def test_accuracy_vs_truth_larger():
     L = pyoracle.lib()
     ed, n = truth_error(d, fx[:40], bx, lambda a, b: L.oracle_edit_distance(a, len(a), b, len(b)))
     assert n > 0 and ed / n < 0.02
+
+
+@pytest.mark.gpu
+def test_cli_from_las_and_db_files(small_data, tmp_path):
+    """daccord-compatible front end: .las + .db on disk -> FASTA identical to the oracle run on the in-memory piles."""
+    import io as _io
+    import pyoracle
+    from daccord_amd import cli, io as dio
+    d, ovl, piles = small_data
+    las, db = str(tmp_path / "reads.las"), str(tmp_path / "reads.db")
+    dio.write_db(db, d.bps, d.boff, d.rlen)
+    dio.write_las(las, 100, d.ovl, d.trace)
+    p_i, p_d, cor = d.error_profile()
+    buf = _io.StringIO()
+    assert cli.main(["-k8", "-I0,6", "--eprof%r,%r,%r" % (p_i, p_d, cor), las, db], out=buf) == 0
+    O = pyoracle.Oracle(default_params(k=8)); O.set_error_profile(p_i, p_d, cor); O.load_db(d.bps, d.boff, d.rlen)
+    sel = piles[piles["aread"] < 6]
+    fo, bo = O.run(sel, ovl, d.trace, nthreads=4)
+    assert buf.getvalue() == pyoracle.fasta(fo, bo)
