@@ -22,6 +22,17 @@ def test_exports_match_header():
     assert set(engine.EXPORTS) <= set(declared)
 
 
+def test_io_exports_match_header():
+    """include/daccord_io.h: every entry point is exported by the host-only library and by the HIP library."""
+    from daccord_amd import io as dio
+    hdr = open(os.path.join(ROOT, "include", "daccord_io.h")).read()
+    declared = sorted(set(re.findall(r"\b(dacc_(?:db|las)_[a-z_]+)\s*\(", hdr)))
+    assert len(declared) >= 10
+    for L in (dio.lib(), engine.lib()):
+        for name in declared:
+            assert hasattr(L, name), name
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
