@@ -95,11 +95,8 @@ struct FastLds
 	FLD(succ0,uint16_t,CT::ncap,e_nfreq)
 	FLD(sinfo,uint16_t,CT::ncap,e_succ0)
 	FLD(npred,uint8_t,CT::ncap,e_sinfo)
-	FLD(pfrom,uint8_t,CT::ncap,e_npred)
-	FLD(pto,uint8_t,CT::ncap,e_pfrom)
-	FLD(cpfrom,uint8_t,CT::ncap,e_pto)
-	FLD(cpto,uint8_t,CT::ncap,e_cpfrom)
-	FLD(mfirst,uint64_t,keycap,e_cpto)
+	FLD(nrange,uint32_t,CT::ncap,e_npred)   // feasible position range of a node: pfrom | pto<<8 | cpfrom<<16 | cpto<<24
+	FLD(mfirst,uint64_t,keycap,e_nrange)
 	FLD(mlast,uint64_t,keycap,e_mfirst)
 	FLD(suplo8,uint8_t,FSUPCAP,e_mlast)
 	FLD(suphi8,uint8_t,FSUPCAP,e_suplo8)
@@ -395,10 +392,9 @@ struct FastEngine
 			uint32_t const lo = L.ipos()[s0], hi = L.ipos()[s0+f2-1];
 			uint32_t rlo = 255, rhi = 0;
 			for ( uint32_t q = 0; q < f2; ++q ) { uint32_t const r = L.irpos()[s0+q]; rlo = r < rlo ? r : rlo; rhi = r > rhi ? r : rhi; }
-			L.pfrom()[z] = lo < nsup ? L.suplo8()[lo] : nrows;
-			L.pto()[z] = hi < nsup ? L.suphi8()[hi] : nrows;
-			L.cpfrom()[z] = rlo < nsup ? L.suplo8()[rlo] : nrows;
-			L.cpto()[z] = rhi < nsup ? L.suphi8()[rhi] : nrows;
+			uint32_t const pf = lo < nsup ? L.suplo8()[lo] : nrows, pt = hi < nsup ? L.suphi8()[hi] : nrows;
+			uint32_t const cf = rlo < nsup ? L.suplo8()[rlo] : nrows, ct = rhi < nsup ? L.suphi8()[rhi] : nrows;
+			L.nrange()[z] = pf | (pt<<8) | (cf<<16) | (ct<<24);
 		}
 		uint32_t const kp2 = next_pow2(CT::maxs < 2 ? 2 : CT::maxs);
 		base = 0;
@@ -540,11 +536,12 @@ struct FastEngine
 				uint32_t const from = REC[r]>>48, to = (REC[r]>>32)&0xFFFF; uint32_t const cv = static_cast<uint32_t>(REC[r]);
 				uint64_t mweight = 0; uint32_t mp = 0;
 				// common position pp: from feasible at pp-s, to feasible at pp; ascending pp, strict > keeps the first maximum
-				for ( uint32_t pp = L.pfrom()[to]; pp < L.pto()[to]; ++pp )
+				uint32_t const rto = L.nrange()[to], rfrom = L.nrange()[from];
+				for ( uint32_t pp = rto & 0xFF; pp < ((rto>>8)&0xFF); ++pp )
 				{
 					if ( pp < s ) continue;
 					uint32_t const pf = pp-s;
-					if ( pf < L.pfrom()[from] || pf >= L.pto()[from] ) continue;
+					if ( pf < (rfrom&0xFF) || pf >= ((rfrom>>8)&0xFF) ) continue;
 					uint64_t const ua = nodeU(from,pf,false), ub = nodeU(to,pp,false);
 					if ( ua < FW_THRES_FEAS || ub < FW_THRES_FEAS ) continue;
 					uint64_t const weight = ua+ub;
@@ -782,21 +779,44 @@ struct FastEngine
 				uint32_t const Pp = c + lane;
 				bool ok = Pp < nrows, okr = ok;
 				uint64_t sum = 0, rsum = 0, f1 = 0, fl = 0, r1 = 0;
-				for ( uint32_t j = 0; j < len; ++j )
+				// two stretch nodes per round and direction: their index, node and first-instance loads are independent and
+				// issued together; a node has at least one instance, further instances (rare for large k) follow in a tail loop
+				#define DACC_NODE(Z,IP,P,U,RNG) \
+					uint32_t const RNG = L.nrange()[Z]; \
+					{ uint32_t const i0_ = L.nps()[Z], f_ = L.nfreq()[Z]; \
+					  uint32_t const pc_ = (P) < nrows ? (P) : nrows; \
+					  U = tabAt<GT>(IP[i0_],pc_,stride); \
+					  for ( uint32_t q_ = 1; q_ < f_; ++q_ ) U += tabAt<GT>(IP[i0_+q_],pc_,stride); }
+				uint32_t j = 0;
+				for ( ; j+1 < len; j += 2 )
 				{
-					uint32_t const p = Pp+j;
-					uint32_t const pc = p < nrows ? p : nrows;       // clamped: row nrows is all zero
-					uint32_t const zf = Lk[j], zr = Lk[len-1-j];
-					uint32_t const i0f = L.nps()[zf], ff = L.nfreq()[zf], i0r = L.nps()[zr], fr = L.nfreq()[zr];
-					uint64_t uf = 0, ur = 0;
-					for ( uint32_t q = 0; q < ff; ++q ) uf += tabAt<GT>(L.ipos()[i0f+q],pc,stride);
-					for ( uint32_t q = 0; q < fr; ++q ) ur += tabAt<GT>(L.irpos()[i0r+q],pc,stride);
-					ok = ok & (p >= L.pfrom()[zf]) & (p < L.pto()[zf]) & (uf >= FW_THRES_FEAS);
-					okr = okr & (p >= L.cpfrom()[zr]) & (p < L.cpto()[zr]) & (ur >= FW_THRES_FEAS);
-					sum += uf; rsum += ur;
-					if ( j == 0 ) { f1 = uf; r1 = ur; }
-					fl = uf;
+					uint32_t const p0 = Pp+j, p1 = p0+1;
+					uint32_t const zf0 = Lk[j], zf1 = Lk[j+1], zr0 = Lk[len-1-j], zr1 = Lk[len-2-j];
+					uint64_t uf0, uf1, ur0, ur1;
+					DACC_NODE(zf0,L.ipos(),p0,uf0,gf0)
+					DACC_NODE(zr0,L.irpos(),p0,ur0,gr0)
+					DACC_NODE(zf1,L.ipos(),p1,uf1,gf1)
+					DACC_NODE(zr1,L.irpos(),p1,ur1,gr1)
+					ok = ok & (p0 >= (gf0&0xFF)) & (p0 < ((gf0>>8)&0xFF)) & (uf0 >= FW_THRES_FEAS) & (p1 >= (gf1&0xFF)) & (p1 < ((gf1>>8)&0xFF)) & (uf1 >= FW_THRES_FEAS);
+					okr = okr & (p0 >= ((gr0>>16)&0xFF)) & (p0 < (gr0>>24)) & (ur0 >= FW_THRES_FEAS) & (p1 >= ((gr1>>16)&0xFF)) & (p1 < (gr1>>24)) & (ur1 >= FW_THRES_FEAS);
+					sum += uf0; sum += uf1; rsum += ur0; rsum += ur1;
+					if ( j == 0 ) { f1 = uf0; r1 = ur0; }
+					fl = uf1;
 				}
+				if ( j < len )
+				{
+					uint32_t const p0 = Pp+j;
+					uint32_t const zf0 = Lk[j], zr0 = Lk[len-1-j];
+					uint64_t uf0, ur0;
+					DACC_NODE(zf0,L.ipos(),p0,uf0,gf0)
+					DACC_NODE(zr0,L.irpos(),p0,ur0,gr0)
+					ok = ok & (p0 >= (gf0&0xFF)) & (p0 < ((gf0>>8)&0xFF)) & (uf0 >= FW_THRES_FEAS);
+					okr = okr & (p0 >= ((gr0>>16)&0xFF)) & (p0 < (gr0>>24)) & (ur0 >= FW_THRES_FEAS);
+					sum += uf0; rsum += ur0;
+					if ( j == 0 ) { f1 = uf0; r1 = ur0; }
+					fl = uf0;
+				}
+				#undef DACC_NODE
 				uint64_t const bf = wv_ballot(ok), br = wv_ballot(okr);
 				uint32_t const pre = dacc_popc64(bf & ltmask), prer = dacc_popc64(br & ltmask);
 				if ( ok && bF+pre < CT::wcap )
