@@ -55,3 +55,28 @@ def test_empty_and_shallow_piles(small_data):
     O, E, (fo, bo), (fe, be) = _both(d, ovl, p, slice(0, 2), k=8)
     assert len(fo) == 0 and frags_equal(fo, bo, fe, be)
     assert windows_equal(O.windows(), E.windows()) == []
+
+
+def test_capacity_tiers_and_generic_engine_agree(small_data):
+    """k=8 on 20x piles overflows the small LDS layouts for some windows: every capacity tier has to be exercised, and
+    the generic engine alone (fast path off) has to give the same bits."""
+    d, ovl, piles = small_data
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 4), k=8)
+    t1, t2, t3, gen = E.counts()
+    assert t1 > 0 and t2 > 0 and t3 > 0, (t1, t2, t3, gen)
+    assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
+    G = emul_lib.Emul(default_params(k=8)); G.set_fast(False)
+    G.set_error_profile(*d.error_profile()); G.load_db(d.bps, d.boff, d.rlen)
+    fg, bg = G.run(piles[0:2], ovl, d.trace)
+    assert G.counts()[3] > 0 and G.counts()[0] == 0
+    fo2, bo2 = O.run(piles[0:2], ovl, d.trace, nthreads=4)
+    assert frags_equal(fo2, bo2, fg, bg)
+
+
+def test_no_state_leaks_between_windows(small_data, monkeypatch):
+    """The harness fills the LDS image and the engine's members with a poison byte before every window: a window must
+    not depend on what an earlier window (or kernel) left behind (such a leak corrupted later windows on the GPU once)."""
+    d, ovl, piles = small_data
+    monkeypatch.setenv("DACC_EMUL_POISON", "171")
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 3), k=8)
+    assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
