@@ -54,14 +54,15 @@ struct FastCaps
 	uint64_t gbytes;
 };
 
-struct FSI { uint64_t w; uint8_t left, right, current, path; uint32_t pad; };   // ScoreInterval
+struct FSI { uint64_t w; uint16_t left, right, current, path; };   // ScoreInterval (left/right/current: sorted reverse entries, path: forward pop index)
 struct FCC { uint64_t w; uint32_t o, l; };                                       // ConsensusCandidate
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { enum : uint32_t { maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 64, blcap = 96, conscap = 16384 + MAXCONS }; };
-template<> struct FastTier<2> { enum : uint32_t { maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
-template<> struct FastTier<3> { enum : uint32_t { maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 250, siqcap = 200, blcap = 128, conscap = 32768 + MAXCONS }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
+// tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128, conscap = 32768 + MAXCONS }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -106,7 +107,7 @@ struct FastLds
 	FLD(vapos,uint8_t,8,e_vadd)
 	FLD(vfn,uint16_t,8,e_vapos)
 	FLD(vln,uint16_t,8,e_vfn)
-	FLD(sstack,uint8_t,3*24,e_vln)
+	FLD(sstack,uint16_t,3*24,e_vln)
 	FLD(chain,uint8_t,64,e_sstack)
 	static constexpr uint32_t ubase = e_chain;
 	// ---- overlay A: build phase ----
@@ -160,37 +161,37 @@ struct FastLds
 	static constexpr uint32_t pbase = e_consL;
 	// reverse cache
 	FLD(rc_w,uint64_t,CT::rccap,pbase)
-	FLD(rc_parent,uint8_t,CT::rccap,e_rc_w)
+	FLD(rc_parent,typename CT::id_t,CT::rccap,e_rc_w)
 	FLD(rc_stretch,uint8_t,CT::rccap,e_rc_parent)
 	FLD(rc_pos,uint8_t,CT::rccap,e_rc_stretch)
 	FLD(rc_len,uint8_t,CT::rccap,e_rc_pos)
 	FLD(rc_baselen,uint8_t,CT::rccap,e_rc_len)
-	FLD(rc_ord,uint8_t,CT::rccap,e_rc_baselen)
-	FLD(rc_arw,uint8_t,CT::rccap,e_rc_ord)
+	FLD(rc_ord,typename CT::id_t,CT::rccap,e_rc_baselen)
+	FLD(rc_arw,typename CT::id_t,CT::rccap,e_rc_ord)
 	FLD(rc_sbl,uint8_t,CT::rccap,e_rc_arw)         // base length of the i-th entry in sorted order
 	FLD(rc_front,uint32_t,CT::rccap,e_rc_sbl)      // front k-mer of the i-th entry in sorted order
 	FLD(rbase,uint16_t,FNC+1,e_rc_front)
-	FLD(rn,uint8_t,FNC+1,e_rbase)
-	FLD(rnpool,uint8_t,FNC+1,e_rn)
+	FLD(rn,uint16_t,FNC+1,e_rbase)
+	FLD(rnpool,uint16_t,FNC+1,e_rn)
 	FLD(rvalid,uint8_t,FNC+1,e_rnpool)
 	FLD(rmaxw,uint64_t,FNC+1,e_rvalid)
 	FLD(rtmask,uint64_t,FNC+1,e_rmaxw)
 	FLD(rfmask,uint64_t,FNC+1,e_rtmask)    // one bit per front k-mer (value mod 64) of the accepted reverse paths
 	// forward pool
 	FLD(f_w,uint64_t,CT::fcap,e_rfmask)
-	FLD(f_parent,uint8_t,CT::fcap,e_f_w)
+	FLD(f_parent,typename CT::id_t,CT::fcap,e_f_w)
 	FLD(f_stretch,uint8_t,CT::fcap,e_f_parent)
 	FLD(f_pos,uint8_t,CT::fcap,e_f_stretch)
 	FLD(f_baselen,uint8_t,CT::fcap,e_f_pos)
 	FLD(f_len,uint8_t,CT::fcap,e_f_baselen)
-	FLD(fpop,uint8_t,CT::fcap,e_f_len)
+	FLD(fpop,typename CT::id_t,CT::fcap,e_f_len)
 	// per popped path (pop order): k-mer of its last node, candidate length, weight minus the junction node
 	FLD(fp_cl,uint8_t,CT::fcap,e_fpop)
 	FLD(fp_front,uint32_t,CT::fcap,e_fp_cl)
 	FLD(fp_adj,uint64_t,CT::fcap,e_fp_front)
 	// heaps
-	FLD(rpst,uint8_t,256,e_fp_adj)
-	FLD(hbl,uint8_t,CT::blcap*12,e_rpst)
+	FLD(rpst,typename CT::id_t,CT::rpstcap,e_fp_adj)
+	FLD(hbl,typename CT::id_t,CT::blcap*12,e_rpst)
 	FLD(hbl_n,uint8_t,CT::blcap,e_hbl)
 	FLD(siq,FSI,CT::siqcap,e_hbl_n)
 	static constexpr uint32_t upool = e_siq;
@@ -260,6 +261,7 @@ DEV void fast_load_tables(FastLds<CT> const & L, uint32_t const nrows, uint32_t 
 template<typename CT>
 struct FastEngine
 {
+	typedef typename CT::id_t id_t;      // path ids inside one enumeration
 	FastLds<CT> L; FastGlobal G; DevTables T; DevParams P;
 	uint32_t nrows, nsup;
 	uint64_t const * vst;        // [nsup][nrows] fixed-point model table in HBM
@@ -977,18 +979,18 @@ struct FastEngine
 	// ---- heaps (same sift algorithm as oracle/o_heap.hpp) ----
 	template<bool MINHEAP> DEV static bool hless(uint64_t a, uint64_t b) { return MINHEAP ? (a < b) : (a > b); }
 	template<bool MINHEAP>
-	DEV void ipush(LDSQ uint8_t * H, uint32_t & f, uint8_t const id, LDSQ uint64_t const * W)
+	DEV void ipush(LDSQ id_t * H, uint32_t & f, id_t const id, LDSQ uint64_t const * W)
 	{
 		uint32_t i = f++; H[i] = id;
 		while ( i )
 		{
 			uint32_t const p = (i-1)>>1;
-			if ( hless<MINHEAP>(W[H[i]],W[H[p]]) ) { uint8_t const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
+			if ( hless<MINHEAP>(W[H[i]],W[H[p]]) ) { id_t const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
 			else break;
 		}
 	}
 	template<bool MINHEAP>
-	DEV void ipop(LDSQ uint8_t * H, uint32_t & f, LDSQ uint64_t const * W)
+	DEV void ipop(LDSQ id_t * H, uint32_t & f, LDSQ uint64_t const * W)
 	{
 		H[0] = H[--f];
 		uint32_t i = 0, r;
@@ -996,10 +998,10 @@ struct FastEngine
 		{
 			uint32_t const m = hless<MINHEAP>(W[H[r-1]],W[H[r]]) ? (r-1) : r;
 			if ( hless<MINHEAP>(W[H[i]],W[H[m]]) ) return;
-			uint8_t const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
+			id_t const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
 		}
 		uint32_t const l = 2*i+1;
-		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { uint8_t const t = H[i]; H[i] = H[l]; H[l] = t; }
+		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { id_t const t = H[i]; H[i] = H[l]; H[l] = t; }
 	}
 	template<typename TT, bool MINHEAP>
 	DEV void spush(LDSQ TT * H, uint32_t & f, TT const & e)
@@ -1033,7 +1035,8 @@ struct FastEngine
 	// (checkReversePathFeasiblePosition :4130-4159 looks the same entry up again: the check position is the parent's)
 	DEV int32_t extendReversePath(uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl, int32_t const sfo, uint64_t const wr)
 	{
-		if ( rb+nrp >= CT::rccap || nrp >= 250 ) { over(512); return -1; }
+		if ( rb+nrp >= CT::rccap ) { over(512|0x4000); return -1; }
+		if ( nrp >= CT::idmax ) { over(512|0x8000); return -1; }
 		uint32_t const id = nrp++;
 		uint32_t const slen = L.sslen()[s];
 		uint64_t weight = pw; uint32_t baselen = pbl;
@@ -1046,58 +1049,58 @@ struct FastEngine
 		return id;
 	}
 	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len()[rb+id] ? L.nv()[L.sfirst()[L.rc_stretch()[rb+id]]] : rlastk; }
-	DEV bool arpLess(uint8_t const a, uint8_t const b) const
+	DEV bool arpLess(id_t const a, id_t const b) const
 	{
 		uint32_t const fa = rpFront(a), fb = rpFront(b);
 		if ( fa != fb ) return fa < fb;
 		return L.rc_baselen()[rb+a] < L.rc_baselen()[rb+b];
 	}
-	DEV void arpULI(LDSQ uint8_t * last) { uint8_t const val = *last; LDSQ uint8_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
-	DEV void arpIns(LDSQ uint8_t * first, LDSQ uint8_t * last)
+	DEV void arpULI(LDSQ id_t * last) { id_t const val = *last; LDSQ id_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
+	DEV void arpIns(LDSQ id_t * first, LDSQ id_t * last)
 	{
 		if ( first == last ) return;
-		for ( LDSQ uint8_t * i = first+1; i != last; ++i )
+		for ( LDSQ id_t * i = first+1; i != last; ++i )
 		{
-			if ( arpLess(*i,*first) ) { uint8_t const val = *i; for ( LDSQ uint8_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
+			if ( arpLess(*i,*first) ) { id_t const val = *i; for ( LDSQ id_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
 			else arpULI(i);
 		}
 	}
 	// libstdc++ std::sort permutation (introsort + final insertion sort), see dbg_window.hpp arpSort
-	DEV void arpSort(LDSQ uint8_t * first, LDSQ uint8_t * last)
+	DEV void arpSort(LDSQ id_t * first, LDSQ id_t * last)
 	{
 		if ( first == last ) return;
 		int32_t const n = last-first;
 		if ( n > 16 )
 		{
 			int depth = 0; { int32_t t = n; while ( t > 1 ) { t >>= 1; ++depth; } depth *= 2; }
-			LDSQ uint8_t * stF = L.sstack(); LDSQ uint8_t * stL = stF+24; LDSQ uint8_t * stD = stF+48; int sp = 0;   // offsets from first
+			LDSQ uint16_t * stF = L.sstack(); LDSQ uint16_t * stL = stF+24; LDSQ uint16_t * stD = stF+48; int sp = 0;   // offsets from first
 			stF[0] = 0; stL[0] = n; stD[0] = depth; sp = 1;
 			while ( sp )
 			{
 				--sp;
-				LDSQ uint8_t * f = first+stF[sp]; LDSQ uint8_t * l = first+stL[sp]; int d = stD[sp];
+				LDSQ id_t * f = first+stF[sp]; LDSQ id_t * l = first+stL[sp]; int d = stD[sp];
 				while ( l-f > 16 )
 				{
 					if ( d == 0 ) { over(1024); return; }
 					--d;
-					LDSQ uint8_t * mid = f + (l-f)/2; LDSQ uint8_t * a = f+1; LDSQ uint8_t * b = mid; LDSQ uint8_t * c = l-1;
+					LDSQ id_t * mid = f + (l-f)/2; LDSQ id_t * a = f+1; LDSQ id_t * b = mid; LDSQ id_t * c = l-1;
 					if ( arpLess(*a,*b) )
 					{
-						if ( arpLess(*b,*c) ) { uint8_t t = *f; *f = *b; *b = t; }
-						else if ( arpLess(*a,*c) ) { uint8_t t = *f; *f = *c; *c = t; }
-						else { uint8_t t = *f; *f = *a; *a = t; }
+						if ( arpLess(*b,*c) ) { id_t t = *f; *f = *b; *b = t; }
+						else if ( arpLess(*a,*c) ) { id_t t = *f; *f = *c; *c = t; }
+						else { id_t t = *f; *f = *a; *a = t; }
 					}
-					else if ( arpLess(*a,*c) ) { uint8_t t = *f; *f = *a; *a = t; }
-					else if ( arpLess(*b,*c) ) { uint8_t t = *f; *f = *c; *c = t; }
-					else { uint8_t t = *f; *f = *b; *b = t; }
-					LDSQ uint8_t * lo = f+1; LDSQ uint8_t * hi = l;
+					else if ( arpLess(*a,*c) ) { id_t t = *f; *f = *a; *a = t; }
+					else if ( arpLess(*b,*c) ) { id_t t = *f; *f = *c; *c = t; }
+					else { id_t t = *f; *f = *b; *b = t; }
+					LDSQ id_t * lo = f+1; LDSQ id_t * hi = l;
 					while ( true )
 					{
 						while ( arpLess(*lo,*f) ) ++lo;
 						--hi;
 						while ( arpLess(*f,*hi) ) --hi;
 						if ( !(lo < hi) ) break;
-						uint8_t t = *lo; *lo = *hi; *hi = t;
+						id_t t = *lo; *lo = *hi; *hi = t;
 						++lo;
 					}
 					if ( sp < 24 ) { stF[sp] = lo-first; stL[sp] = l-first; stD[sp] = d; ++sp; } else { over(1024); return; }
@@ -1105,7 +1108,7 @@ struct FastEngine
 				}
 			}
 			arpIns(first,first+16);
-			for ( LDSQ uint8_t * i = first+16; i != last; ++i ) arpULI(i);
+			for ( LDSQ id_t * i = first+16; i != last; ++i ) arpULI(i);
 		}
 		else arpIns(first,last);
 	}
@@ -1118,7 +1121,7 @@ struct FastEngine
 		uint32_t nrpst = 0;
 		if ( lastnode >= 0 )
 		{
-			if ( rb >= CT::rccap ) { over(512); return; }
+			if ( rb >= CT::rccap ) { over(512|0x4000); return; }
 			uint32_t const id = nrp++;
 			L.rc_parent()[rb+id] = 0xFF; L.rc_stretch()[rb+id] = 0xFF; L.rc_len()[rb+id] = 0; L.rc_pos()[rb+id] = 0; L.rc_w()[rb+id] = 0; L.rc_baselen()[rb+id] = k;
 			L.rpst()[nrpst++] = id;
@@ -1131,7 +1134,7 @@ struct FastEngine
 			uint32_t const bl = L.rc_baselen()[rb+rp], ppos = L.rc_pos()[rb+rp], plen = L.rc_len()[rb+rp];
 			uint64_t const pw = W[rp];
 			if ( bl >= CT::blcap ) { over(2048); return; }
-			LDSQ uint8_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
+			LDSQ id_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
 			if ( hn == 12 )
 			{
 				if ( pw <= W[H[0]] ) continue;
@@ -1139,7 +1142,7 @@ struct FastEngine
 			}
 			ipush<true>(H,hn,rp,W);
 			L.hbl_n()[bl] = hn;
-			if ( narp >= 250 ) { over(512); return; }
+			if ( narp >= CT::idmax ) { over(512|0x8000); return; }
 			L.rc_ord()[rb+narp++] = rp;
 			if ( plen == 0 )
 			{
@@ -1151,7 +1154,7 @@ struct FastEngine
 					if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;     // the new path would be dropped right away
 					int32_t const rpe = extendReversePath(rp,sx,ppos,plen,pw,bl,sfo,wr);
 					if ( rpe < 0 ) return;
-					if ( nrpst >= 250 ) { over(512); return; }
+					if ( nrpst >= CT::rpstcap ) { over(512|0x8000); return; }
 					ipush<false>(L.rpst(),nrpst,rpe,W);
 				}
 			}
@@ -1170,7 +1173,7 @@ struct FastEngine
 						if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;
 						int32_t const rpe = extendReversePath(rp,a,ppos,plen,pw,bl,sfo,wr);
 						if ( rpe < 0 ) return;
-						if ( nrpst >= 250 ) { over(512); return; }
+						if ( nrpst >= CT::rpstcap ) { over(512|0x8000); return; }
 						ipush<false>(L.rpst(),nrpst,rpe,W);
 					}
 				}
@@ -1244,7 +1247,7 @@ struct FastEngine
 	DEV int32_t extendPath(int32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl,
 		int32_t const sfo, uint64_t const wf, uint32_t & npos, uint32_t & nbl, uint64_t & nw)
 	{
-		if ( np >= CT::fcap || np >= 250 ) { over(512); return -1; }
+		if ( np >= CT::fcap || np >= CT::idmax ) { over(512|0x10000); return -1; }
 		uint32_t const id = np++;
 		uint32_t const slen = L.sslen()[s];
 		uint64_t weight = pw; uint32_t baselen = pbl;
@@ -1259,7 +1262,7 @@ struct FastEngine
 	DEV bool apqPush(uint32_t const id, uint32_t const bl, uint64_t const w)
 	{
 		if ( bl >= CT::blcap ) { over(2048); return false; }
-		LDSQ uint8_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
+		LDSQ id_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
 		if ( hn == 12 )
 		{
 			if ( w > L.f_w()[H[0]] ) { ipop<true>(H,hn,L.f_w()); ipush<true>(H,hn,id,L.f_w()); }
@@ -1293,11 +1296,11 @@ struct FastEngine
 			if ( zz < 64 ) apqm0 &= apqm0-1; else apqm1 &= apqm1-1;
 			while ( L.hbl_n()[zz] )
 			{
-				LDSQ uint8_t * H = L.hbl() + 12*zz; uint32_t hn = L.hbl_n()[zz];
+				LDSQ id_t * H = L.hbl() + 12*zz; uint32_t hn = L.hbl_n()[zz];
 				uint32_t const path = H[0];
 				ipop<true>(H,hn,L.f_w());
 				L.hbl_n()[zz] = hn;
-				if ( nfpop >= CT::fcap ) { over(512); return; }
+				if ( nfpop >= CT::fcap ) { over(512|0x20000); return; }
 				uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path], plen = L.f_len()[path], pbl = L.f_baselen()[path];
 				uint64_t const pw = L.f_w()[path];
 				uint32_t const lastn = L.slast()[ps];
@@ -1408,8 +1411,8 @@ struct FastEngine
 			{
 				uint32_t mi = sub, mr = L.rc_arw()[base+sub];
 				for ( uint32_t i = sub+1; i < sup; ++i ) { uint32_t const r = L.rc_arw()[base+i]; if ( r > mr ) { mi = i; mr = r; } }
-				if ( nsiq >= CT::siqcap ) { over(512); return; }
-				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = pi; si.pad = 0; si.w = L.fp_adj()[pi] + L.rc_w()[base+L.rc_ord()[base+mi]];
+				if ( nsiq >= CT::siqcap ) { over(512|0x40000); return; }
+				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = pi; si.w = L.fp_adj()[pi] + L.rc_w()[base+L.rc_ord()[base+mi]];
 				spush<FSI,false>(L.siq(),nsiq,si);
 				fstat(6,nsiq);
 			}
@@ -1437,7 +1440,7 @@ struct FastEngine
 					if ( found )
 					{
 						FSI sic = si; sic.current = bi; sic.w = L.fp_adj()[si.path] + L.rc_w()[base+L.rc_ord()[base+bi]];
-						if ( nsiq >= CT::siqcap ) { over(512); return; }
+						if ( nsiq >= CT::siqcap ) { over(512|0x40000); return; }
 						spush<FSI,false>(L.siq(),nsiq,sic);
 					}
 				}

@@ -1,0 +1,4 @@
+mkdir -p gpurun_out
+( timeout 400 python -m pytest tests -m gpu -x -q ) > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+( DACC_TIERS=7 timeout 60 python scripts/dbg_tiers.py 14; DACC_TIERS=7 timeout 60 python scripts/dbg_tiers.py 8 ) > gpurun_out/dbg_tiers.log 2>&1
+tail -n 3 gpurun_out/pytest_gpu.log; grep -v amdgpu gpurun_out/dbg_tiers.log
