@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 		else { i = it*gridDim.x + blockIdx.x; ++it; }
 		if ( i >= n ) break;
 		uint64_t const w = list ? list[1+i] : i;
-		bool const done = processWindowFast<CT>(FB,w,lds,garena);
+		bool const done = processWindowFast<CT>(FB,w,lds,garena,list != 0);
 		if ( !done && threadIdx.x == 0 ) { uint32_t const q = atomicAdd(FB.retry,1u); FB.retry[1+q] = static_cast<uint32_t>(w); }
 		__syncthreads();
 	}

@@ -1842,7 +1842,7 @@ struct FastEngine
 
 // returns true if the window was completed on the fast path, false if it must be re-run generically
 template<typename CT>
-DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, uint8_t * garena)
+DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, uint8_t * garena, bool const resume = false)
 {
 	WindowBatch const & B = FB.W;
 	FastEngine<CT> E;
@@ -1859,7 +1859,17 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 	FastLds<CT> const & L = E.L;
 	int const lane = E.lane;
 	PROF_T0
-	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); } return false; }
+	// A window that does not fit is handed to the next capacity tier together with the filter frequency of the pass
+	// that overflowed: with a single k the passes before it ended without a consensus and left no state behind
+	// (minrate, best), so the next tier starts at that pass instead of repeating them.
+	int32_t curff = B.P.maxff;
+	if ( resume && B.P.klow == B.P.khigh )
+	{
+		WindowOut const prev = B.wout[widx];
+		if ( prev.status == WS_RETRY && prev.filterfreq <= B.P.maxff && prev.filterfreq >= B.P.minff ) curff = prev.filterfreq;
+	}
+	int32_t const startff = curff;
+	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); B.wout[widx].filterfreq = curff; } return false; }
 
 	uint32_t lo = 0, hi = B.npiles;
 	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
@@ -1963,8 +1973,9 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh; ++k )
 		{
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
-			for ( int32_t ff = B.P.maxff; ff >= B.P.minff; --ff )
+			for ( int32_t ff = startff; ff >= B.P.minff; --ff )
 			{
+				curff = ff;
 				PROF_T0
 				E.buildInstances();
 				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only

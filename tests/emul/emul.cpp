@@ -150,7 +150,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 #if defined(DACC_FSTATS)
 			for ( int i = 0; i < 16; ++i ) dacc::g_fstat[i] = 0;
 #endif
-			bool done = false;
+			bool done = false, tried = false;
 			for ( int t = 0; t < 3 && !done; ++t )
 			{
 				if ( !tierok[t] ) continue;
@@ -162,9 +162,10 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 					else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 					else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 				}
-				if ( t == 0 ) done = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),0);
-				else if ( t == 1 ) done = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),0);
-				else done = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),0);
+				if ( t == 0 ) done = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),0,tried);
+				else if ( t == 1 ) done = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),0,tried);
+				else done = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),0,tried);
+				tried = true;
 				if ( done ) ++c->ntier[t];
 				else { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++; }
 #if defined(DACC_FSTATS)
