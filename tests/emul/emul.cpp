@@ -33,6 +33,7 @@ struct EmulCtx
 	std::vector<dacc_window_result> windows;
 	std::string err;
 	bool usefast; uint64_t ntier[3], nretry;
+	std::vector<uint64_t> glist;   // windows that went to the generic engine: index, flags of the last tier
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
 
@@ -56,6 +57,7 @@ void emul_reasons_tier(void * v, int t, uint64_t * r, uint64_t * fb) { EmulCtx *
 void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,1,r,fb); }
 void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,0,r,fb); }
 void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
+uint64_t emul_generic_list(void * v, uint64_t * out, uint64_t cap) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( uint64_t i = 0; i < c->glist.size() && i < cap; ++i ) out[i] = c->glist[i]; return c->glist.size(); }
 void emul_counts4(void * v, uint64_t * n) { EmulCtx * c = static_cast<EmulCtx *>(v); n[0] = c->ntier[0]; n[1] = c->ntier[1]; n[2] = c->ntier[2]; n[3] = c->nretry; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
@@ -141,7 +143,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= BP.ftier[t].pad;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
-		c->nretry = 0;
+		c->nretry = 0; c->glist.clear();
 		{ FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
 		{ FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 		{ FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
@@ -172,7 +174,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				if ( t == 0 ) for ( int i = 0; i < 16; ++i ) g_all.push_back(dacc::g_fstat[i]);
 #endif
 			}
-			if ( !done ) { ++c->nretry; processWindow(WB,wdx,arena.data()); }
+			if ( !done ) { ++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); processWindow(WB,wdx,arena.data()); }
 		}
 	}
 	c->windows.clear();
