@@ -119,8 +119,12 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 		else { i = it*gridDim.x + blockIdx.x; ++it; }
 		if ( i >= n ) break;
 		uint64_t const w = list ? list[1+i] : i;
-		bool const done = processWindowFast<CT>(FB,w,lds,garena,list != 0);
-		if ( !done && threadIdx.x == 0 ) { uint32_t const q = atomicAdd(FB.retry,1u); FB.retry[1+q] = static_cast<uint32_t>(w); }
+		int const rc = processWindowFast<CT>(FB,w,lds,garena,list != 0);
+		if ( rc != FW_DONE && threadIdx.x == 0 )
+		{
+			uint32_t * const dst = (rc == FW_GENERIC && FB.gearly) ? FB.gearly : FB.retry;
+			uint32_t const q = atomicAdd(dst,1u); dst[1+q] = static_cast<uint32_t>(w);
+		}
 		__syncthreads();
 	}
 #if defined(DACC_PROFILE)
@@ -186,7 +190,7 @@ struct dacc_ctx
 {
 	dacc_params par;
 	int device;
-	hipStream_t stream;
+	hipStream_t stream; hipStream_t stream2; hipEvent_t evFirstTier, evEarlyGeneric;   // stream2: generic engine for the windows no LDS tier can run, concurrent with tiers 2 and 3
 	hipEvent_t ev[6]; hipEvent_t evtier[3];
 	std::string err;
 	bool haveprofile, havedb, havebatch;
@@ -203,8 +207,8 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work;
-	uint32_t tier_grid[3], retry_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly; DevBuf<uint8_t> d_arena2;
+	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_threads, win_grid;
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
@@ -239,6 +243,8 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0;
 	std::memset(&c->timing,0,sizeof(c->timing));
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
+	{ int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo,&hi); if ( hipStreamCreateWithPriority(&c->stream2,hipStreamNonBlocking,hi) != hipSuccess ) { delete c; return DACC_EHIP; } }
+	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming);
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
 	for ( int i = 0; i < 3; ++i ) hipEventCreate(&c->evtier[i]);
 	*out = c;
@@ -254,9 +260,9 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release();
+	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_arena2.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
-	hipStreamDestroy(c->stream);
+	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric);
 	delete c;
 }
 
@@ -351,6 +357,8 @@ static int runDevice(dacc_ctx * c)
 		if ( c->usefast )
 		{
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
+			bool early = false;
 			HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s));
 			// capacity tiers: every tier takes the windows the previous one handed over (list = 0: all windows)
 			uint32_t const * list = 0;
@@ -358,17 +366,29 @@ static int runDevice(dacc_ctx * c)
 			{
 				if ( c->tier_ok[t] )
 				{
-					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.garena = 0; FB.retry = c->d_retry[t].p;
+					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.garena = 0; FB.retry = c->d_retry[t].p; FB.gearly = c->d_gearly.p;
 					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
 					if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					list = c->d_retry[t].p;
+					if ( !early )
+					{
+						// the first tier has seen every window: what only the generic engine can run starts now, on its own
+						// (high priority) stream and arena, while the remaining tiers run
+						early = true;
+						HIPCHK(hipEventRecord(c->evFirstTier,s));
+						HIPCHK(hipStreamWaitEvent(c->stream2,c->evFirstTier,0));
+						WindowBatch WE = WB; WE.arena = c->d_arena2.p; WE.prof = 0;
+						hipLaunchKernelGGL(k_window,dim3(c->early_grid),dim3(64),0,c->stream2,WE,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p),static_cast<uint32_t *>(0));
+						HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
+					}
 				}
 				hipEventRecord(c->evtier[t],s);
 			}
 			// what is left (rare shapes) goes through the generic engine
 			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0));
+			if ( early ) HIPCHK(hipStreamWaitEvent(s,c->evEarlyGeneric,0));
 		}
 		else
 			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0)); }
@@ -492,6 +512,9 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = wg < 512 ? wg : 512;
 		c->win_grid = c->retry_grid;
+		c->early_grid = c->retry_grid < 64 ? c->retry_grid : 64;
+		HIPCHK(c->d_gearly.ensure(BP.nwindows+2));
+		HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
 		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));
 	}

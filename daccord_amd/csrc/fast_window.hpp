@@ -242,7 +242,8 @@ struct FastBatch
 	FastCaps F;
 	uint64_t const * dpsq_vst;  // [nsup][nrows] transposed fixed-point table (HBM); copied to LDS as 32-bit
 	uint8_t * garena;           // [gridDim][F.gbytes]
-	uint32_t * retry;           // [0] = count, [1..] = window indices to re-run generically
+	uint32_t * retry;           // [0] = count, [1..] = window indices for the next capacity tier
+	uint32_t * gearly;          // same layout: windows no LDS tier can run (w > 63, a string > 64): straight to the generic engine
 };
 
 // once per workgroup: the support bounds of the model table
@@ -1840,9 +1841,10 @@ struct FastEngine
 	}
 };
 
-// returns true if the window was completed on the fast path, false if it must be re-run generically
+// returns FW_DONE, FW_NEXT (does not fit this tier's capacities) or FW_GENERIC (shape no LDS tier supports)
+enum { FW_DONE = 0, FW_NEXT = 1, FW_GENERIC = 2 };
 template<typename CT>
-DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, uint8_t * garena, bool const resume = false)
+DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, uint8_t * garena, bool const resume = false)
 {
 	WindowBatch const & B = FB.W;
 	FastEngine<CT> E;
@@ -1869,7 +1871,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 		if ( prev.status == WS_RETRY && prev.filterfreq <= B.P.maxff && prev.filterfreq >= B.P.minff ) curff = prev.filterfreq;
 	}
 	int32_t const startff = curff;
-	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); B.wout[widx].filterfreq = curff; } return false; }
+	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); B.wout[widx].filterfreq = curff; } return ((code) == 1 || (code) == 4) ? FW_GENERIC : FW_NEXT; }
 
 	uint32_t lo = 0, hi = B.npiles;
 	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
@@ -2042,7 +2044,7 @@ DEV bool processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8
 	}
 	if ( lane == 0 ) B.wout[widx] = out;
 	wv_sync();
-	return true;
+	return FW_DONE;
 	#undef FFAIL
 }
 

@@ -138,7 +138,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		bool tierok[3];
 		for ( int t = 0; t < 3; ++t )
 		{
-			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].garena = 0; FB[t].retry = 0;
+			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].garena = 0; FB[t].retry = 0; FB[t].gearly = 0;
 			lds[t].resize(BP.ftier[t].ldsbytes+64);
 			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= BP.ftier[t].pad;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
@@ -164,10 +164,12 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 					else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 					else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 				}
-				if ( t == 0 ) done = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),0,tried);
-				else if ( t == 1 ) done = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),0,tried);
-				else done = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),0,tried);
-				tried = true;
+				int rc;
+				if ( t == 0 ) rc = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),0,tried);
+				else if ( t == 1 ) rc = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),0,tried);
+				else rc = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),0,tried);
+				tried = true; done = (rc == FW_DONE);
+				if ( rc == FW_GENERIC ) { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; break; }   // straight to the generic engine
 				if ( done ) ++c->ntier[t];
 				else { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++; }
 #if defined(DACC_FSTATS)
