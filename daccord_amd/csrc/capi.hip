@@ -105,7 +105,6 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 	if ( FB.W.prof ) FB.W.prof += 32*(blockIdx.x & 4095);
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
 	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
-	uint8_t * garena = 0;
 	{ FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
 #if defined(DACC_PROFILE)
 	uint64_t const t0c = clock64(), t0w = wall_clock64();
@@ -119,7 +118,7 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 		else { i = it*gridDim.x + blockIdx.x; ++it; }
 		if ( i >= n ) break;
 		uint64_t const w = list ? list[1+i] : i;
-		int const rc = processWindowFast<CT>(FB,w,lds,garena,list != 0);
+		int const rc = processWindowFast<CT>(FB,w,lds,list != 0);
 		if ( rc != FW_DONE && threadIdx.x == 0 )
 		{
 			uint32_t * const dst = (rc == FW_GENERIC && FB.gearly) ? FB.gearly : FB.retry;
@@ -366,7 +365,7 @@ static int runDevice(dacc_ctx * c)
 			{
 				if ( c->tier_ok[t] )
 				{
-					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.garena = 0; FB.retry = c->d_retry[t].p; FB.gearly = c->d_gearly.p;
+					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p; FB.gearly = c->d_gearly.p;
 					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
 					if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
@@ -496,7 +495,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		for ( int t = 0; t < 3; ++t )
 		{
 			FastCaps const & F = BP.ftier[t];
-			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= F.pad) && F.ldsbytes <= 160*1024;
+			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= F.tabcap) && F.ldsbytes <= 160*1024;
 			{ char const * tm = getenv("DACC_TIERS"); if ( tm && !((atoi(tm)>>t)&1) ) c->tier_ok[t] = 0; }   // debugging: bit t enables tier t+1
 			uint64_t percu = (160*1024) / (F.ldsbytes ? F.ldsbytes : 1);
 			if ( percu > 8 ) percu = 8;

@@ -27,8 +27,16 @@
  *    target of the enumeration equals a node that identifies the split stretch or its pieces);
  *    otherwise the pair is enumerated on its exact stretch set.
  *
- * Windows that do not fit the LDS capacities (deep piles, strings > 64, gap filling at filter
- * frequency 0, w > 63, rare shapes) return false and are re-run by the generic engine.
+ *  - stretches are looked up by first / last node through small index arrays, the weights of a feasible (stretch,
+ *    position) entry carry the weights of its end nodes, candidates are kept as stretch sequences and decoded once.
+ *
+ * The same code is instantiated for three capacity tiers (FastTier<1..3>: 3, 2 and 1 wavefronts per CU; the layout
+ * FastLds<CT> is a compile time constant, so every LDS access has an immediate offset).  processWindowFast returns
+ * FW_NEXT when a window overflows a tier (flags say what overflowed: 1 instances, 2 nodes, 8 candidates, 16 walk,
+ * 32 stretches, 64 links, 128 weights, 512 pools (0x4000 reverse cache, 0x8000 path ids, 0x10000 forward pool,
+ * 0x20000 popped paths, 0x40000 score intervals), 1024 introsort depth, 2048 base length, 4096 candidate length /
+ * sequence, 8192 gap filling) and FW_GENERIC for shapes no tier supports (w > 63, a string longer than 64 bases);
+ * those go to the generic engine (dbg_window.hpp).
  */
 #ifndef DACC_FAST_WINDOW_HPP
 #define DACC_FAST_WINDOW_HPP
@@ -48,10 +56,10 @@ enum { FSEQCAP = 48 };      // max stretches of one candidate path     // max wi
 // run time description of a capacity tier (host planning, launch parameters)
 struct FastCaps
 {
-	uint32_t maxs, precap, ncap, scap, lcap, wcap, rccap, fcap, siqcap, blcap, conscap, pad;
+	uint32_t maxs, precap, ncap, scap, lcap, wcap, rccap, fcap, siqcap, blcap;
+	uint32_t tabcap;             // 32-bit words the table overlay of this tier can hold
 	uint32_t nrows, nsup;        // dimensions of the fixed-point table copy held in LDS
-	uint32_t ldsbytes, pad2;
-	uint64_t gbytes;
+	uint32_t ldsbytes;
 };
 
 struct FSI { uint64_t w; uint16_t left, right, current, path; };   // ScoreInterval (left/right/current: sorted reverse entries, path: forward pop index)
@@ -59,10 +67,10 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96, conscap = 16384 + MAXCONS }; };
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96, conscap = 16384 + MAXCONS }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128, conscap = 32768 + MAXCONS }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -172,8 +180,7 @@ struct FastLds
 	FLD(rc_front,uint32_t,CT::rccap,e_rc_sbl)      // front k-mer of the i-th entry in sorted order
 	FLD(rbase,uint16_t,FNC+1,e_rc_front)
 	FLD(rn,uint16_t,FNC+1,e_rbase)
-	FLD(rnpool,uint16_t,FNC+1,e_rn)
-	FLD(rvalid,uint8_t,FNC+1,e_rnpool)
+	FLD(rvalid,uint8_t,FNC+1,e_rn)
 	FLD(rmaxw,uint64_t,FNC+1,e_rvalid)
 	FLD(rtmask,uint64_t,FNC+1,e_rmaxw)
 	FLD(rfmask,uint64_t,FNC+1,e_rtmask)    // one bit per front k-mer (value mod 64) of the accepted reverse paths
@@ -221,18 +228,15 @@ struct FastLds
 };
 #undef FLD
 
-struct FastGlobal { GLBQ uint8_t * cons; };
-
 template<typename CT>
 HDEV FastCaps fastCapsOf(uint32_t const nrows, uint32_t const nsup)
 {
 	FastCaps C;
 	C.maxs = CT::maxs; C.precap = CT::precap; C.ncap = CT::ncap; C.scap = CT::scap; C.lcap = CT::lcap; C.wcap = CT::wcap; C.rccap = CT::rccap;
-	C.fcap = CT::fcap; C.siqcap = CT::siqcap; C.blcap = CT::blcap; C.conscap = CT::conscap; C.pad = 0; C.pad2 = 0;
+	C.fcap = CT::fcap; C.siqcap = CT::siqcap; C.blcap = CT::blcap;
 	C.nrows = nrows; C.nsup = nsup;
 	C.ldsbytes = FastLds<CT>::bytes(nrows,nsup);
-	C.gbytes = (static_cast<uint64_t>(CT::conscap)+255)&~255ull;
-	C.pad = FastLds<CT>::tabcap;   // words available for the model table copy
+	C.tabcap = FastLds<CT>::tabcap;
 	return C;
 }
 
@@ -241,7 +245,6 @@ struct FastBatch
 	WindowBatch W;
 	FastCaps F;
 	uint64_t const * dpsq_vst;  // [nsup][nrows] transposed fixed-point table (HBM); copied to LDS as 32-bit
-	uint8_t * garena;           // [gridDim][F.gbytes]
 	uint32_t * retry;           // [0] = count, [1..] = window indices for the next capacity tier
 	uint32_t * gearly;          // same layout: windows no LDS tier can run (w > 63, a string > 64): straight to the generic engine
 };
@@ -263,7 +266,7 @@ template<typename CT>
 struct FastEngine
 {
 	typedef typename CT::id_t id_t;      // path ids inside one enumeration
-	FastLds<CT> L; FastGlobal G; DevTables T; DevParams P;
+	FastLds<CT> L; DevTables T; DevParams P;
 	uint32_t nrows, nsup;
 	uint64_t const * vst;        // [nsup][nrows] fixed-point model table in HBM
 	int lane; uint32_t flags;
@@ -283,13 +286,6 @@ struct FastEngine
 #else
 	DEV void pcount(int, uint64_t) {}
 	DEV uint64_t pclock() { return 0; }
-#endif
-#if defined(DACC_EMUL) && defined(DACC_FSTATS)
-	void fstat(int i, uint32_t v) { extern uint32_t g_fstat[16]; if ( v > g_fstat[i] ) g_fstat[i] = v; }
-	void fstatadd(int i, uint32_t v) { extern uint32_t g_fstat[16]; g_fstat[i] += v; }
-#else
-	DEV void fstat(int, uint32_t) {}
-	DEV void fstatadd(int, uint32_t) {}
 #endif
 
 	DEV int32_t findNode(uint32_t const v) const
@@ -745,7 +741,7 @@ struct FastEngine
 		npool = wv_bcast(npool,0);
 		for ( uint32_t id = n0 + lane; id < npool; id += WSZ ) L.ppos()[id] = basePos(id);
 		wv_sync();
-		fstat(12,nF); fstat(13,nL); fstat(14,npool); fstat(15,n0);
+
 	}
 
 	// copy of the model table in LDS, row stride nrows+1: the extra row is zero so that positions beyond the table can be
@@ -1180,7 +1176,7 @@ struct FastEngine
 				}
 			}
 		}
-		fstatadd(8,1); fstatadd(9,narp);
+
 		rmaxw = 0;
 		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[rb+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
 		arpSort(L.rc_ord()+rb,L.rc_ord()+rb+narp);
@@ -1415,10 +1411,8 @@ struct FastEngine
 				if ( nsiq >= CT::siqcap ) { over(512|0x40000); return; }
 				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = pi; si.w = L.fp_adj()[pi] + L.rc_w()[base+L.rc_ord()[base+mi]];
 				spush<FSI,false>(L.siq(),nsiq,si);
-				fstat(6,nsiq);
 			}
 		}
-		if ( nsiq ) fstatadd(2,1);
 		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
 		uint32_t pn = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
@@ -1539,7 +1533,7 @@ struct FastEngine
 						rb = rctop;
 						reverseEnumerate(lastk,lastnode,lmax);
 						if ( flags ) return 0;
-						L.rbase()[li] = rb; L.rn()[li] = narp; L.rnpool()[li] = nrp; L.rvalid()[li] = 1; RMAX[li] = rmaxw;
+						L.rbase()[li] = rb; L.rn()[li] = narp; L.rvalid()[li] = 1; RMAX[li] = rmaxw;
 						L.rtmask()[li] = reverseTargetMask(lastnode,lmax); L.rfmask()[li] = rfmcur;
 						rctop = rb + nrp;
 						pcount(22,pclock()-tq0); pcount(25,1);
@@ -1605,8 +1599,8 @@ struct FastEngine
 				}
 				uint64_t rfm;
 				if ( rcached ) { base = L.rbase()[li]; nacc2 = L.rn()[li]; rfm = L.rfmask()[li]; } else { base = rb; nacc2 = narp; rfm = rfmcur; }
-				fstatadd(0,1);
-				if ( (rfm & ffmask) == 0 ) { pcount(28,1); fstatadd(1,1); continue; }   // the forward tree and the reverse block share no junction k-mer
+
+				if ( (rfm & ffmask) == 0 ) { pcount(28,1); continue; }   // the forward tree and the reverse block share no junction k-mer
 				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,rfm,lmin,lmax,16); pcount(24,pclock()-tq0); }
 				if ( !rcached || !fcached ) pcount(21,1);
 				if ( flags ) return 0;
@@ -1629,7 +1623,7 @@ struct FastEngine
 		flags = wv_or(flags); if ( flags ) return false;
 		for ( uint32_t i = lane; i < FNC+1; i += WSZ ) L.rvalid()[i] = 0;
 		wv_sync();
-		fstat(4,nwF); fstat(5,nwR); fstat(7,nlinks);
+
 		PROF(*this,9)
 		pl_fi = 0; pl_li = 0; pl_midready = false;
 		while ( true )
@@ -1844,7 +1838,7 @@ struct FastEngine
 // returns FW_DONE, FW_NEXT (does not fit this tier's capacities) or FW_GENERIC (shape no LDS tier supports)
 enum { FW_DONE = 0, FW_NEXT = 1, FW_GENERIC = 2 };
 template<typename CT>
-DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, uint8_t * garena, bool const resume = false)
+DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, bool const resume = false)
 {
 	WindowBatch const & B = FB.W;
 	FastEngine<CT> E;
@@ -1857,7 +1851,6 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 	E.L.base = lds;
-	E.G.cons = (GLBQ uint8_t *)garena;
 	FastLds<CT> const & L = E.L;
 	int const lane = E.lane;
 	PROF_T0

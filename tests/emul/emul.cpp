@@ -9,10 +9,6 @@
 #include <string>
 #include <cstring>
 #include <cstdlib>
-#if defined(DACC_FSTATS)
-namespace dacc { uint32_t g_fstat[16]; }
-static std::vector<uint32_t> g_all;
-#endif
 #include "../../daccord_amd/csrc/batch_plan.hpp"
 #include "../../daccord_amd/csrc/host_tables.hpp"
 #include "../../daccord_amd/csrc/window_main.hpp"
@@ -138,9 +134,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		bool tierok[3];
 		for ( int t = 0; t < 3; ++t )
 		{
-			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].garena = 0; FB[t].retry = 0; FB[t].gearly = 0;
+			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].retry = 0; FB[t].gearly = 0;
 			lds[t].resize(BP.ftier[t].ldsbytes+64);
-			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= BP.ftier[t].pad;
+			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= BP.ftier[t].tabcap;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
 		c->nretry = 0; c->glist.clear();
@@ -149,9 +145,6 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		{ FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
 		{
-#if defined(DACC_FSTATS)
-			for ( int i = 0; i < 16; ++i ) dacc::g_fstat[i] = 0;
-#endif
 			bool done = false, tried = false;
 			for ( int t = 0; t < 3 && !done; ++t )
 			{
@@ -165,16 +158,13 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 					else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 				}
 				int rc;
-				if ( t == 0 ) rc = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),0,tried);
-				else if ( t == 1 ) rc = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),0,tried);
-				else rc = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),0,tried);
+				if ( t == 0 ) rc = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),tried);
+				else if ( t == 1 ) rc = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),tried);
+				else rc = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),tried);
 				tried = true; done = (rc == FW_DONE);
 				if ( rc == FW_GENERIC ) { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; break; }   // straight to the generic engine
 				if ( done ) ++c->ntier[t];
 				else { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++; }
-#if defined(DACC_FSTATS)
-				if ( t == 0 ) for ( int i = 0; i < 16; ++i ) g_all.push_back(dacc::g_fstat[i]);
-#endif
 			}
 			if ( !done ) { ++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); processWindow(WB,wdx,arena.data()); }
 		}
@@ -250,7 +240,3 @@ int emul_windows(void * v, dacc_window_result * out, uint64_t cap, uint64_t * n)
 
 }
 
-#if defined(DACC_FSTATS)
-extern "C" uint64_t emul_fstats(uint32_t * out, uint64_t cap) { uint64_t n = g_all.size(); for ( uint64_t i = 0; i < n && i < cap; ++i ) out[i] = g_all[i]; return n; }
-extern "C" void emul_fstats_reset() { g_all.clear(); }
-#endif
