@@ -58,3 +58,43 @@ def test_two_rank_sharding_and_gather():
         pr.join(timeout=120)
         assert pr.exitcode == 0
     assert same and n == nref and 0 < nmine < 10
+
+
+def _worker_edge(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from daccord_amd import shard
+    from daccord_amd._structs import DaccFragment
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dt = np.dtype(DaccFragment)
+    # rank 1 has nothing to contribute; the others have r+1 fragments of different lengths
+    nf = 0 if rank == 1 else rank + 1
+    f = np.zeros(nf, dtype=dt); bases = b""
+    for i in range(nf):
+        s = bytes([65 + rank]) * (10 + i)
+        f[i]["aread"] = 100 * rank + i; f[i]["first"] = i; f[i]["last"] = i + len(s); f[i]["len"] = len(s); f[i]["seq_off"] = len(bases)
+        bases += s
+    F, B = shard.gather_fragments(f, bases, device="cpu")
+    if rank == 0:
+        ok = len(F) == 1 + 0 + 3 and [int(x) for x in F["aread"]] == [0, 200, 201, 202]
+        ok = ok and all(B[int(x["seq_off"]):int(x["seq_off"]) + int(x["len"])] == bytes([65 + int(x["aread"]) // 100]) * int(x["len"]) for x in F)
+        q.put(ok)
+    else:
+        assert F is None and B is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_with_an_empty_rank_and_uneven_sizes():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, 3, port, q)) for r in range(3)]
+    for pr in procs:
+        pr.start()
+    ok = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert ok
