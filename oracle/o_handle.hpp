@@ -6,6 +6,10 @@
  * schedule Windows (HandleContext.hpp:382-447), of PileElement ordering (:232-240) and of
  * libmaus2's OverlapDataInterface::computeTrace / getErrorRate as recalled (SURVEY.md 8c:
  * trace points -> one global alignment per tspace block of A, concatenated).
+ *
+ * PARITY UNPINNED: the reference cannot be built here (libmaus2 is not in /root/reference) and ships no tests or
+ * golden vectors, so this restatement is checked against itself, the committed fixture it generated and
+ * implementation-independent properties only.
  */
 #ifndef ORACLE_HANDLE_HPP
 #define ORACLE_HANDLE_HPP
