@@ -601,7 +601,8 @@ struct FastEngine
 		}
 		wv_sync();
 	}
-	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, LDSQ uint16_t * out, uint32_t & lastnode)
+	// out (if given) receives the first `cap` nodes
+	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, LDSQ uint16_t * out, uint32_t & lastnode, uint32_t const cap = 0xFFFFFFFFu)
 	{
 		int32_t cur = succNode(z,i);
 		uint32_t len = 2;
@@ -610,7 +611,7 @@ struct FastEngine
 		while ( !loop && nsuccact(cur) == 1 && L.npred()[cur] == 1 )
 		{
 			cur = succNode(cur,0);
-			if ( out ) out[len] = cur;
+			if ( out && len < cap ) out[len] = cur;
 			++len;
 			if ( cur == static_cast<int32_t>(z) ) loop = true;
 			if ( len > nn+1 ) { over(16); break; }
@@ -643,7 +644,18 @@ struct FastEngine
 		uint32_t const ns = base;
 		if ( ns + 2 > CT::scap || ns > 250 || nn >= 0x3FFF ) { over(32); n0 = 0; return; }
 		wv_sync();
-		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; L.tslen()[q] = walkStretch(L.tfirst()[q],L.tlast()[q],0,ln); }
+		// walk every stretch once: the nodes go to a scratch slot of WSLOT entries per stretch in the (not yet used) weight
+		// arrays and are compacted into `links` below; a stretch without a slot or longer than it is walked a second time
+		enum { WSLOT = 64 };
+		LDSQ uint16_t * const wtmp = reinterpret_cast<LDSQ uint16_t *>(L.wF_lo());
+		uint32_t const nslot = (FastLds<CT>::e_wR1_hi - FastLds<CT>::o_wF_lo) / (2*WSLOT);
+		for ( uint32_t q = lane; q < ns; q += WSZ )
+		{
+			uint32_t ln;
+			uint32_t const sub = L.tlast()[q];
+			L.tslen()[q] = walkStretch(L.tfirst()[q],sub,q < nslot ? wtmp + q*WSLOT : static_cast<LDSQ uint16_t *>(0),ln,WSLOT);
+			L.skey()[q] = (static_cast<uint64_t>(sub)<<32) | ln;     // successor index (for a second walk) and last node
+		}
 		wv_sync();
 		base = 0;
 		for ( uint32_t c = 0; c < ns; c += WSZ )
@@ -657,7 +669,14 @@ struct FastEngine
 		nlinks = base;
 		if ( nlinks > CT::lcap ) { over(64); n0 = 0; return; }
 		wv_sync();
-		for ( uint32_t q = lane; q < ns; q += WSZ ) { uint32_t ln; walkStretch(L.tfirst()[q],L.tlast()[q],L.links()+L.tlink()[q],ln); L.tlast()[q] = ln; }
+		for ( uint32_t q = lane; q < ns; q += WSZ )
+		{
+			uint32_t const len = L.tslen()[q]; uint64_t const sk = L.skey()[q];
+			LDSQ uint16_t * const dst = L.links() + L.tlink()[q];
+			if ( q < nslot && len <= WSLOT ) { LDSQ uint16_t const * src = wtmp + q*WSLOT; for ( uint32_t t = 0; t < len; ++t ) dst[t] = src[t]; }
+			else { uint32_t ln; walkStretch(L.tfirst()[q],static_cast<uint32_t>(sk>>32),dst,ln); }
+			L.tlast()[q] = static_cast<uint32_t>(sk);
+		}
 		wv_sync();
 		uint32_t const p2 = next_pow2(ns < 2 ? 2 : ns);
 		for ( uint32_t q = lane; q < p2; q += WSZ )
@@ -1180,13 +1199,18 @@ struct FastEngine
 		rmaxw = 0;
 		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[rb+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
 		arpSort(L.rc_ord()+rb,L.rc_ord()+rb+narp);
+		// rank of every entry by (weight, sorted position); the weights in sorted order are staged in the (idle) score
+		// interval heap so that the quadratic loop reads one word per step
+		LDSQ uint64_t * const sw = reinterpret_cast<LDSQ uint64_t *>(L.siq());
+		bool const staged = narp <= 2*CT::siqcap;
+		if ( staged ) for ( uint32_t i = 0; i < narp; ++i ) sw[i] = W[L.rc_ord()[rb+i]];
 		for ( uint32_t i = 0; i < narp; ++i )
 		{
-			uint64_t const wi = W[L.rc_ord()[rb+i]];
+			uint64_t const wi = staged ? sw[i] : W[L.rc_ord()[rb+i]];
 			uint32_t r = 0;
 			for ( uint32_t j = 0; j < narp; ++j )
 			{
-				uint64_t const wj = W[L.rc_ord()[rb+j]];
+				uint64_t const wj = staged ? sw[j] : W[L.rc_ord()[rb+j]];
 				if ( wj < wi || (wj == wi && j < i) ) ++r;
 			}
 			L.rc_arw()[rb+i] = r;
@@ -1514,6 +1538,7 @@ struct FastEngine
 			uint32_t const fi = pl_fi;
 			int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
 			uint32_t const sf = L.parF()[fi];
+			uint32_t const fnodeFi = L.fnode()[fi], sfLast = sf != FNOPAR ? L.slast()[sf] : 0u;
 			for ( ; pl_li < nL; ++pl_li )
 			{
 				uint32_t const li = pl_li;
@@ -1542,8 +1567,8 @@ struct FastEngine
 					else
 					{
 						uint64_t const tm = L.rtmask()[li];
-						rcached = !((tm >> (L.slast()[sf]&63))&1) && !((tm >> (L.fnode()[fi]&63))&1);
-						if ( !rcached ) rcached = reverseUnaffected(L.rbase()[li],L.rn()[li],lastnode,sf,L.fnode()[fi],lmax);
+						rcached = !((tm >> (sfLast&63))&1) && !((tm >> (fnodeFi&63))&1);
+						if ( !rcached ) rcached = reverseUnaffected(L.rbase()[li],L.rn()[li],lastnode,sf,fnodeFi,lmax);
 					}
 					// forward tree, cached for the current first k-mer (computed on the view split at `first` only)
 					if ( fcur_fi != static_cast<int32_t>(fi) || fcur_li != -1 )
