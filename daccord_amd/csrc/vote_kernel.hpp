@@ -94,7 +94,8 @@ DEV void votePass1(VoteBatch const & B, DevPile const & pile, uint32_t const p)
 		T = nins > T ? nins : T;
 	}
 	bool has = (l0 || T);
-	if ( !has && B.P.producefull && p < pile.rl ) { has = true; l0 = 1; }
+	// -f fills uncovered positions with the lower-case A base, but only for a pile that has overlaps (ita != ite, HandleContext.hpp:2543)
+	if ( !has && B.P.producefull && pile.novl && p < pile.rl ) { has = true; l0 = 1; }
 	B.has[pile.posbase+p] = has;
 	B.ld0[pile.posbase+p] = l0;
 }

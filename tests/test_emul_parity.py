@@ -55,6 +55,10 @@ def test_empty_and_shallow_piles(small_data):
     O, E, (fo, bo), (fe, be) = _both(d, ovl, p, slice(0, 2), k=8)
     assert len(fo) == 0 and frags_equal(fo, bo, fe, be)
     assert windows_equal(O.windows(), E.windows()) == []
+    # -f copies the uncorrected read for a pile WITH overlaps only (ita != ite, HandleContext.hpp:2543): the empty pile
+    # stays silent, the shallow one comes back in lower case
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, p, slice(0, 2), k=8, producefull=1)
+    assert len(fo) == 1 and fo[0]["aread"] == p[1]["aread"] and bo == bo.lower() and frags_equal(fo, bo, fe, be)
 
 
 def test_capacity_tiers_and_generic_engine_agree(small_data):

@@ -92,6 +92,11 @@ def test_empty_shallow_and_rerun(small_data):
     E.rerun()                                             # idempotence on the resident batch
     fy, by = E.collect()
     assert frags_equal(fx, bx, fy, by)
+    # -f: the uncorrected read is copied for piles that have overlaps only (HandleContext.hpp:2543)
+    O, E = _pair(d, k=8, producefull=1)
+    fo, bo = O.run(p, ovl, d.trace, nthreads=4)
+    fx, bx = E(p, ovl, d.trace)
+    assert frags_equal(fo, bo, fx, bx) and all(f["aread"] != p[0]["aread"] for f in fx)
 
 
 def test_perfect_piles_full_size_property():
