@@ -32,6 +32,13 @@ static inline void windowIv(uint64_t const l, uint64_t const a, uint64_t const w
 	if ( y*a+w <= l ) { s = y*a; e = s+w; } else { s = l-w; e = l; }
 }
 
+// larger scratch capacities for the generic engine after a window reported WS_OVERFLOW (dense graphs at small k)
+static inline void growArenaCaps(ArenaCaps & c)
+{
+	c.precap *= 2; c.nodecap *= 2;        // stays a power of two (bitonic sorts)
+	c.fcap *= 4; c.strcap *= 2; c.linkcap *= 4; c.sfcap *= 4; c.rlcap *= 4; c.poolcap *= 4; c.conscap = 4*(c.conscap-MAXCONS) + MAXCONS;
+}
+
 struct BatchPlan
 {
 	std::vector<DevPile> piles;

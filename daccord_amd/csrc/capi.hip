@@ -96,6 +96,13 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 	}
 }
 
+// windows the generic engine left as WS_OVERFLOW -> list (count in list[0])
+__global__ void k_collect_overflow(WindowOut const * wout, uint64_t n, uint32_t * list)
+{
+	uint64_t const i = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+	if ( i < n && wout[i].status == WS_OVERFLOW ) { uint32_t const q = atomicAdd(list,1u); list[1+q] = static_cast<uint32_t>(i); }
+}
+
 // LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice.
 // list == 0: all windows; else the windows a smaller capacity tier handed over.  Windows that do not fit go to FB.retry.
 template<int TIER>
@@ -393,31 +400,56 @@ static int runDevice(dacc_ctx * c)
 			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0)); }
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
-	if ( BP.piles.size() )
-	{
-		VoteBatch VB;
-		VB.P = c->P; VB.bps = c->d_bps.p; VB.boff = c->d_boff.p; VB.rlen = c->d_rlen.p; VB.piles = c->d_piles.p; VB.npiles = BP.piles.size();
-		VB.wrec = c->d_wrec.p; VB.has = c->d_has.p; VB.ld0 = c->d_ld0.p; VB.oc = c->d_oc.p; VB.ocs = c->d_ocs.p; VB.outsym = c->d_outsym.p;
-		VB.frags = c->d_frags.p; VB.fragbase = c->d_fragbase.p; VB.nfrag = c->d_nfrag.p; VB.errflag = c->d_err.p + 1;
-		hipLaunchKernelGGL(k_vote,dim3(BP.piles.size()),dim3(256),0,s,VB);
-	}
-	HIPCHK(hipEventRecord(c->ev[3],s));
-	HIPCHK(hipGetLastError());
-	// results
 	uint32_t herr[4] = {0,0,0,0};
 	size_t const symbytes = 2*BP.npos + 64*BP.piles.size() + 64;
 	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
-	HIPCHK(hipMemcpyAsync(herr,c->d_err.p,sizeof(herr),hipMemcpyDeviceToHost,s));
-	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
-	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpyAsync(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost,s));
-	if ( BP.piles.size() )
+	auto voteAndFetch = [&]() -> int
 	{
-		HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
-		HIPCHK(hipMemcpyAsync(c->h_frags.data(),c->d_frags.p,BP.nfragslots*sizeof(VoteFragment),hipMemcpyDeviceToHost,s));
-		HIPCHK(hipMemcpyAsync(c->h_outsym.data(),c->d_outsym.p,symbytes,hipMemcpyDeviceToHost,s));
+		if ( BP.piles.size() )
+		{
+			VoteBatch VB;
+			VB.P = c->P; VB.bps = c->d_bps.p; VB.boff = c->d_boff.p; VB.rlen = c->d_rlen.p; VB.piles = c->d_piles.p; VB.npiles = BP.piles.size();
+			VB.wrec = c->d_wrec.p; VB.has = c->d_has.p; VB.ld0 = c->d_ld0.p; VB.oc = c->d_oc.p; VB.ocs = c->d_ocs.p; VB.outsym = c->d_outsym.p;
+			VB.frags = c->d_frags.p; VB.fragbase = c->d_fragbase.p; VB.nfrag = c->d_nfrag.p; VB.errflag = c->d_err.p + 1;
+			hipLaunchKernelGGL(k_vote,dim3(BP.piles.size()),dim3(256),0,s,VB);
+		}
+		HIPCHK(hipEventRecord(c->ev[3],s));
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(herr,c->d_err.p,sizeof(herr),hipMemcpyDeviceToHost,s));
+		if ( BP.piles.size() )
+		{
+			HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
+			HIPCHK(hipMemcpyAsync(c->h_frags.data(),c->d_frags.p,BP.nfragslots*sizeof(VoteFragment),hipMemcpyDeviceToHost,s));
+			HIPCHK(hipMemcpyAsync(c->h_outsym.data(),c->d_outsym.p,symbytes,hipMemcpyDeviceToHost,s));
+		}
+		HIPCHK(hipEventRecord(c->ev[4],s));
+		HIPCHK(hipStreamSynchronize(s));
+		return DACC_OK;
+	};
+	{ int const rc = voteAndFetch(); if ( rc ) return rc; }
+	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
+	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpy(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+	// a window the generic engine could not hold (dense graph at small k): grow its scratch capacities and run those
+	// windows again, then the vote (rare; the capacities stay grown for the rest of the batch geometry)
+	for ( int attempt = 0; herr[0] && !herr[1] && !herr[2] && attempt < 3; ++attempt )
+	{
+		growArenaCaps(BP.caps);
+		Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
+		uint32_t const g = c->retry_grid < 64 ? c->retry_grid : 64;
+		c->retry_grid = g; c->win_grid = g; if ( c->early_grid > g ) c->early_grid = g;     // later launches of this batch use the grown arenas
+		HIPCHK(c->d_arena.ensure(static_cast<size_t>(g)*BP.caps.bytes));
+		if ( c->usefast ) HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
+		HIPCHK(c->d_gearly.ensure(BP.nwindows+2));
+		HIPCHK(hipMemsetAsync(c->d_err.p,0,4*sizeof(uint32_t),s));
+		HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
+		hipLaunchKernelGGL(k_collect_overflow,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_gearly.p);
+		WindowBatch WB;
+		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
+		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
+		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = 0;
+		hipLaunchKernelGGL(k_window,dim3(g),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p),static_cast<uint32_t *>(0));
+		int const rc = voteAndFetch(); if ( rc ) return rc;
 	}
-	HIPCHK(hipEventRecord(c->ev[4],s));
-	HIPCHK(hipStreamSynchronize(s));
 	if ( herr[0] ) { c->err = "window kernel scratch capacity exceeded (depth / graph size); lower -d or use smaller piles"; return DACC_ENOTSUP; }
 	if ( herr[1] ) { c->err = "vote kernel capacity exceeded"; return DACC_ENOTSUP; }
 	if ( herr[2] ) { c->err = "trace kernel capacity exceeded (tspace block longer than 128 or B span > 255)"; return DACC_ENOTSUP; }

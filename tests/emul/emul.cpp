@@ -6,6 +6,7 @@
  */
 #define DACC_EMUL 1
 #include <vector>
+#include <cstdio>
 #include <string>
 #include <cstring>
 #include <cstdlib>
@@ -168,6 +169,17 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			}
 			if ( !done ) { ++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); processWindow(WB,wdx,arena.data()); }
 		}
+		// mirrors the library: windows the generic engine could not hold are run again with grown scratch capacities
+		for ( int attempt = 0; attempt < 3; ++attempt )
+		{
+			bool any = false;
+			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) any = true;
+			if ( !any ) break;
+			growArenaCaps(caps); caps.bytes = arena_carve(A,0,caps);
+			arena.assign(caps.bytes+64,0);
+			WB.C = caps; WB.arena = arena.data();
+			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) processWindow(WB,wdx,arena.data());
+		}
 	}
 	c->windows.clear();
 	bool overflow = false;
@@ -190,7 +202,12 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			else r.filterfreq = (o.status == WS_FAILED) ? 0 : 0;
 			c->windows.push_back(r);
 		}
-	if ( overflow ) { c->err = "window kernel scratch capacity exceeded"; return DACC_ENOTSUP; }
+	if ( overflow )
+	{
+		uint32_t fl = 0; for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) fl |= wout[wdx].flags;
+		char buf[96]; std::snprintf(buf,sizeof(buf),"window kernel scratch capacity exceeded (flags 0x%x)",fl);
+		c->err = buf; return DACC_ENOTSUP;
+	}
 
 	// vote
 	std::vector<uint8_t> has(BP.npos+1), oc(BP.npos+1); std::vector<uint16_t> ld0(BP.npos+1); std::vector<uint32_t> ocs(BP.npos+1);

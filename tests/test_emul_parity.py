@@ -84,3 +84,13 @@ def test_no_state_leaks_between_windows(small_data, monkeypatch):
     monkeypatch.setenv("DACC_EMUL_POISON", "171")
     O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 3), k=8)
     assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
+
+
+def test_dense_graph_overflows_the_generic_scratch_and_is_rerun():
+    """k=6 with -d3 and gap filling: the generic engine's first scratch sizes are too small for some windows; the
+    windows are run again with grown capacities (same in the library) and must still equal the oracle."""
+    d = SynthData(60000, 300, 3000, erate=0.28, seed=481075, ins_frac=0.2, del_frac=0.7, sub_frac=0.1)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 2), k=6, w=63, a=20, maxalign=3)
+    assert E.counts()[3] > 0                               # windows with strings > 64 bases: generic engine
+    assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
