@@ -96,6 +96,13 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 	}
 }
 
+// safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
+__global__ void k_check_done(WindowOut const * wout, uint64_t n, uint32_t * errflag)
+{
+	uint64_t const i = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+	if ( i < n && wout[i].status == WS_RETRY ) atomicOr(errflag,1u);
+}
+
 // windows the generic engine left as WS_OVERFLOW -> list (count in list[0])
 __global__ void k_collect_overflow(WindowOut const * wout, uint64_t n, uint32_t * list)
 {
@@ -372,7 +379,11 @@ static int runDevice(dacc_ctx * c)
 			{
 				if ( c->tier_ok[t] )
 				{
-					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p; FB.gearly = c->d_gearly.p;
+					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p;
+					// only the first tier feeds the early generic list (its kernel reads the list once, right after that tier): a
+					// window that reaches a later tier first (mao beyond the earlier tier) and turns out to be generic-only takes
+					// the ordinary hand-over chain to the generic kernel at the end
+					FB.gearly = early ? static_cast<uint32_t *>(0) : c->d_gearly.p;
 					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
 					if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
@@ -405,6 +416,7 @@ static int runDevice(dacc_ctx * c)
 	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
 	auto voteAndFetch = [&]() -> int
 	{
+		if ( BP.nwindows ) hipLaunchKernelGGL(k_check_done,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_err.p+3);
 		if ( BP.piles.size() )
 		{
 			VoteBatch VB;
@@ -451,6 +463,7 @@ static int runDevice(dacc_ctx * c)
 		int const rc = voteAndFetch(); if ( rc ) return rc;
 	}
 	if ( herr[0] ) { c->err = "window kernel scratch capacity exceeded (depth / graph size); lower -d or use smaller piles"; return DACC_ENOTSUP; }
+	if ( herr[3] ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
 	if ( herr[1] ) { c->err = "vote kernel capacity exceeded"; return DACC_ENOTSUP; }
 	if ( herr[2] ) { c->err = "trace kernel capacity exceeded (tspace block longer than 128 or B span > 255)"; return DACC_ENOTSUP; }
 	c->frags.clear(); c->bases.clear();

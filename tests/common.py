@@ -41,3 +41,29 @@ def truth_error(d, frags, bases, edit_distance):
         tot_ed += edit_distance(s, g)
         tot_len += len(g)
     return tot_ed, tot_len
+
+
+def random_run_config(rng):
+    """One random parameter set of the parity fuzzing (scripts/fuzz_emul_vs_oracle.py, test_gpu_parity.py):
+    returns (params kw, synthetic data kw, maxinput, number of piles)."""
+    w = rng.choice([24, 32, 40, 40, 40, 48, 56, 63]); a = min(rng.choice([5, 8, 10, 10, 16, 20]), w)
+    klow = rng.choice([6, 7, 8, 8, 9, 10, 12, 14, 14, 16]); khigh = min(klow + rng.choice([0, 0, 0, 1, 2]), 16)
+    if klow >= w - 4:
+        klow = khigh = 8
+    erate = rng.choice([0.02, 0.08, 0.12, 0.15, 0.15, 0.2, 0.28])
+    mix = rng.choice([(0.8, 0.1333, 0.0667), (1 / 3, 1 / 3, 1 / 3), (0.5, 0.4, 0.1), (0.2, 0.7, 0.1)])
+    nreads = rng.choice([60, 120, 200, 300]); rlen = rng.choice([1500, 3000, 5000]); glen = rng.choice([30000, 60000, 100000])
+    kw = dict(w=w, a=a, klow=klow, khigh=khigh)
+    if rng.random() < 0.3: kw["maxalign"] = rng.choice([3, 5, 8, 15])
+    if rng.random() < 0.2: kw["minwindowcov"] = rng.choice([2, 4, 5])
+    if rng.random() < 0.2: kw["producefull"] = 1
+    if rng.random() < 0.2: kw["minlen"] = rng.choice([200, 1000])
+    if rng.random() < 0.2: kw["maxfilterfreq"] = rng.choice([1, 3])
+    if rng.random() < 0.15: kw["minfilterfreq"] = 1
+    if rng.random() < 0.1: kw["eminrate"] = rng.choice([5, 15, 40])
+    seed = rng.randrange(1, 10 ** 6)
+    tspace = rng.choice([100, 100, 100, 50, 64, 125]); minovl = rng.choice([1000, 1000, 500, 200])
+    kw["tspace"] = tspace
+    data = dict(genome_len=glen, nreads=nreads, read_len=rlen, erate=erate, seed=seed, ins_frac=mix[0], del_frac=mix[1], sub_frac=mix[2],
+                tspace=tspace, min_overlap=minovl)
+    return kw, data, rng.choice([5000, 5000, 10]), rng.choice([2, 3, 4])

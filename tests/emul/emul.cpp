@@ -175,6 +175,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			bool any = false;
 			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) any = true;
 			if ( !any ) break;
+			if ( getenv("DACC_EMUL_VERBOSE") ) { uint64_t n = 0; for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) n += (wout[wdx].status == WS_OVERFLOW); std::fprintf(stderr,"[emul] scratch retry %d: %llu windows\n",attempt,static_cast<unsigned long long>(n)); }
 			growArenaCaps(caps); caps.bytes = arena_carve(A,0,caps);
 			arena.assign(caps.bytes+64,0);
 			WB.C = caps; WB.arena = arena.data();
