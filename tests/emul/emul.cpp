@@ -144,31 +144,52 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		{ FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
 		{ FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 		{ FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
-		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
+		// Same orchestration as the library (capi.hip): every tier is one "kernel" over the list the previous tier
+		// handed over; windows only the generic engine can run go to an early list that is read ONCE, right after the
+		// first tier (later tiers hand such windows on through their ordinary list); the generic engine runs the early
+		// list and, at the end, what the last tier handed over.
+		auto runTier = [&](int const t, uint64_t const wdx, bool const resume) -> int
 		{
-			bool done = false, tried = false;
-			for ( int t = 0; t < 3 && !done; ++t )
+			if ( getenv("DACC_EMUL_POISON") )
 			{
-				if ( !tierok[t] ) continue;
-				if ( getenv("DACC_EMUL_POISON") )
-				{
-					// debugging aid: no window may depend on what an earlier window (or kernel) left in LDS
-					std::memset(lds[t].data(),atoi(getenv("DACC_EMUL_POISON")),lds[t].size());
-					if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
-					else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
-					else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
-				}
-				int rc;
-				if ( t == 0 ) rc = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),tried);
-				else if ( t == 1 ) rc = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),tried);
-				else rc = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),tried);
-				tried = true; done = (rc == FW_DONE);
-				if ( rc == FW_GENERIC ) { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; break; }   // straight to the generic engine
-				if ( done ) ++c->ntier[t];
-				else { uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++; }
+				// debugging aid: no window may depend on what an earlier window (or kernel) left in LDS
+				std::memset(lds[t].data(),atoi(getenv("DACC_EMUL_POISON")),lds[t].size());
+				if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
+				else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+				else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 			}
-			if ( !done ) { ++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); processWindow(WB,wdx,arena.data()); }
+			if ( t == 0 ) return processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),resume);
+			if ( t == 1 ) return processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),resume);
+			return processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),resume);
+		};
+		std::vector<uint64_t> cur, next, gearly, earlysnap;
+		bool haveList = false, early = false;
+		for ( int t = 0; t < 3; ++t )
+		{
+			if ( !tierok[t] ) continue;
+			next.clear();
+			uint64_t const n = haveList ? cur.size() : BP.nwindows;
+			for ( uint64_t i = 0; i < n; ++i )
+			{
+				uint64_t const wdx = haveList ? cur[i] : i;
+				int const rc = runTier(t,wdx,haveList);
+				if ( rc == FW_DONE ) { ++c->ntier[t]; continue; }
+				uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++;
+				if ( rc == FW_GENERIC && !early ) gearly.push_back(wdx); else next.push_back(wdx);
+			}
+			cur.swap(next); haveList = true;
+			if ( !early ) { early = true; earlysnap = gearly; }       // the early generic kernel reads its list here
 		}
+		for ( size_t i = 0; i < earlysnap.size(); ++i ) { ++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); processWindow(WB,earlysnap[i],arena.data()); }
+		{
+			uint64_t const n = haveList ? cur.size() : BP.nwindows;
+			for ( uint64_t i = 0; i < n; ++i )
+			{
+				uint64_t const wdx = haveList ? cur[i] : i;
+				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); processWindow(WB,wdx,arena.data());
+			}
+		}
+		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_RETRY ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
 		// mirrors the library: windows the generic engine could not hold are run again with grown scratch capacities
 		for ( int attempt = 0; attempt < 3; ++attempt )
 		{

@@ -94,3 +94,16 @@ def test_dense_graph_overflows_the_generic_scratch_and_is_rerun():
     O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 2), k=6, w=63, a=20, maxalign=3)
     assert E.counts()[3] > 0                               # windows with strings > 64 bases: generic engine
     assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
+
+
+def test_deep_piles_reach_later_tiers_first_and_then_need_the_generic_engine():
+    """50x piles, w=56: windows with more strings than tier 1 holds reach tier 2/3 first and many of them then turn out
+    to have a string > 64 bases.  The harness mirrors the library's list orchestration (early generic list read once
+    after the first tier): every window must be processed by exactly one engine and equal the oracle (a hand-over
+    into the early list after it had been read lost such windows on the GPU once)."""
+    d = SynthData(30000, 300, 5000, erate=0.08, seed=699273, ins_frac=0.2, del_frac=0.7, sub_frac=0.1, tspace=64, min_overlap=200)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 1), w=56, a=16, klow=7, khigh=9, minfilterfreq=1, tspace=64)
+    t1, t2, t3, gen = E.counts()
+    assert t3 > 0 and gen > 0 and t1 == 0
+    assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
