@@ -262,6 +262,23 @@ DEV void fast_load_tables(FastLds<CT> const & L, uint32_t const nrows, uint32_t 
 #define FW_THRES_01   429496730ull      /* weight > 0.1 and weight >= 0.1 (no integer lies between) */
 #define FW_THRES_05   2147483648ull     /* weight >= 0.5 */
 
+#if defined(DACC_EMUL)
+// emulation only: per-window maxima of the variable-size structures (design aid, DACC_EMUL_STATS=<file>)
+struct FastStats { uint32_t v[24]; void clear() { for ( int i = 0; i < 24; ++i ) v[i] = 0; } void mx(int i, uint32_t x) { if ( x > v[i] ) v[i] = x; } void add(int i, uint32_t x) { v[i] += x; } };
+static FastStats g_fstats;
+static inline void fstats_dump(int const tier)
+{
+	static FILE * sf = 0; static bool tried = false;
+	if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_STATS"); if ( fn ) sf = fopen(fn,"w"); }
+	if ( sf ) { fprintf(sf,"%d",tier); for ( int i = 0; i < 24; ++i ) fprintf(sf," %u",g_fstats.v[i]); fprintf(sf,"\n"); fflush(sf); }
+}
+#define FSTAT_MX(i,x) g_fstats.mx(i,x)
+#define FSTAT_ADD(i,x) g_fstats.add(i,x)
+#else
+#define FSTAT_MX(i,x)
+#define FSTAT_ADD(i,x)
+#endif
+
 template<typename CT>
 struct FastEngine
 {
@@ -1358,6 +1375,9 @@ struct FastEngine
 			}
 		}
 	}
+	// (stats hook)
+	DEV void statF() { FSTAT_MX(13,np); FSTAT_MX(14,nfpop); FSTAT_ADD(15,np); FSTAT_ADD(16,1); }
+	DEV void statR() { FSTAT_MX(17,nrp); FSTAT_MX(18,narp); FSTAT_ADD(19,nrp); FSTAT_ADD(20,1); }
 	// scans of the forward enumeration look for stretches whose first node equals a target; splitting `par` at `ln`
 	// changes the answer only for targets par.first (parent vs first piece) and ln (second piece)
 	DEV bool forwardUnaffected(int32_t const firstnode, uint32_t const par, uint32_t const ln, int64_t const lmax) const
@@ -1437,6 +1457,7 @@ struct FastEngine
 				spush<FSI,false>(L.siq(),nsiq,si);
 			}
 		}
+		FSTAT_MX(21,nsiq); FSTAT_ADD(22,1);
 		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
 		uint32_t pn = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
@@ -1557,6 +1578,7 @@ struct FastEngine
 						if ( sl != FNOPAR ) { viewRemove(sl); viewAdd(L.pieL()[li]); viewAdd(L.pieL()[li]+1); }
 						rb = rctop;
 						reverseEnumerate(lastk,lastnode,lmax);
+						statR();
 						if ( flags ) return 0;
 						L.rbase()[li] = rb; L.rn()[li] = narp; L.rvalid()[li] = 1; RMAX[li] = rmaxw;
 						L.rtmask()[li] = reverseTargetMask(lastnode,lmax); L.rfmask()[li] = rfmcur;
@@ -1577,6 +1599,7 @@ struct FastEngine
 						viewClear();
 						if ( sf != FNOPAR ) { viewRemove(sf); viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
 						forwardEnumerate(firstnode,lmax);
+						statF();
 						if ( flags ) return 0;
 						fcur_fi = fi; fcur_li = -1;
 						ftmask = forwardTargetMask(firstnode,lmax);
@@ -1719,6 +1742,8 @@ struct FastEngine
 		}
 		wv_sync();
 		PROF(*this,13)
+		FSTAT_MX(0,mao); FSTAT_MX(1,npre); FSTAT_MX(2,nn); FSTAT_MX(3,n0); FSTAT_MX(4,npool); FSTAT_MX(5,nlinks); FSTAT_MX(6,nwF); FSTAT_MX(7,nwR);
+		FSTAT_MX(8,rctop); FSTAT_MX(9,nF); FSTAT_MX(10,nL); FSTAT_ADD(11,1); FSTAT_MX(12,nc);
 		return nc != 0;
 	}
 
@@ -1875,6 +1900,9 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	E.apqm0 = E.apqm1 = 0; E.cfree = 0; E.pl_fi = E.pl_li = E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false; E.ftmask = 0; E.ffmask = 0; E.rfmcur = 0; E.V.nadd = 0; E.V.r0 = E.V.r1 = 0xFFFF;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
+#if defined(DACC_EMUL)
+	g_fstats.clear();
+#endif
 	E.L.base = lds;
 	FastLds<CT> const & L = E.L;
 	int const lane = E.lane;
@@ -2062,6 +2090,9 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	}
 	if ( lane == 0 ) B.wout[widx] = out;
 	wv_sync();
+#if defined(DACC_EMUL)
+	fstats_dump(static_cast<int>(CT::maxs));
+#endif
 	return FW_DONE;
 	#undef FFAIL
 }

@@ -12,7 +12,13 @@
 #define DACC_WAVE_HPP
 #include <stdint.h>
 
-#if defined(DACC_EMUL)
+#if defined(DACC_EMUL) && defined(DACC_EMUL_LANES) && DACC_EMUL_LANES == 64
+  // 64-lane host wavefront (coroutine per lane), see wave_emul64.hpp
+  #define DEV inline
+  #define HDEV inline
+  #define WSZ 64
+  #include "wave_emul64.hpp"
+#elif defined(DACC_EMUL)
   #define DEV inline
   #define HDEV inline
   #define WSZ 1
@@ -34,8 +40,12 @@
   static inline uint64_t wv_bcast64(uint64_t v, int) { return v; }
   static inline uint32_t wv_uni(uint32_t v) { return v; }
   static inline uint64_t wv_uni64(uint64_t v) { return v; }
+  static inline uint32_t wv_shfl(uint32_t v, int) { return v; }
+  static inline uint64_t wv_shfl64(uint64_t v, int) { return v; }
   static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
   static inline void atomicOrFlag(uint32_t * f) { *f |= 1u; }
+  template<typename T> static inline T wv_atomic_add(T * p, T const v) { T const o = *p; *p = o + v; return o; }
+  template<typename F> static inline void wave_run(F const & f) { f(); }
   }
 #else
   #include <hip/hip_runtime.h>
@@ -113,6 +123,8 @@
   DEV uint64_t wv_lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
   DEV uint32_t wv_bcast(uint32_t v, int src) { return wv_uni(__shfl(v,src,64)); }
   DEV uint64_t wv_bcast64(uint64_t v, int src) { return wv_uni64(__shfl(v,src,64)); }
+  DEV uint32_t wv_shfl(uint32_t v, int src) { return __shfl(v,src,64); }
+  DEV uint64_t wv_shfl64(uint64_t v, int src) { return __shfl(v,src,64); }
   DEV int dacc_popc64(uint64_t v) { return __popcll(v); }
   DEV void atomicOrFlag(uint32_t * f) { atomicOr(f,1u); }
   }

@@ -141,9 +141,15 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
 		c->nretry = 0; c->glist.clear();
-		{ FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
-		{ FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
-		{ FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
+		auto loadTables = [&](int const t)
+		{
+			wave_run([&]() {
+				if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
+				else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+				else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
+			});
+		};
+		for ( int t = 0; t < 3; ++t ) loadTables(t);
 		// Same orchestration as the library (capi.hip): every tier is one "kernel" over the list the previous tier
 		// handed over; windows only the generic engine can run go to an early list that is read ONCE, right after the
 		// first tier (later tiers hand such windows on through their ordinary list); the generic engine runs the early
@@ -154,13 +160,17 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			{
 				// debugging aid: no window may depend on what an earlier window (or kernel) left in LDS
 				std::memset(lds[t].data(),atoi(getenv("DACC_EMUL_POISON")),lds[t].size());
-				if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
-				else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
-				else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
+				loadTables(t);
 			}
-			if ( t == 0 ) return processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),resume);
-			if ( t == 1 ) return processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),resume);
-			return processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),resume);
+			int rc = -1;
+			wave_run([&]() {
+				int r;
+				if ( t == 0 ) r = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),resume);
+				else if ( t == 1 ) r = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),resume);
+				else r = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),resume);
+				if ( wv_lane() == 0 ) rc = r;
+			});
+			return rc;
 		};
 		std::vector<uint64_t> cur, next, gearly, earlysnap;
 		bool haveList = false, early = false;
@@ -180,13 +190,13 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			cur.swap(next); haveList = true;
 			if ( !early ) { early = true; earlysnap = gearly; }       // the early generic kernel reads its list here
 		}
-		for ( size_t i = 0; i < earlysnap.size(); ++i ) { ++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); processWindow(WB,earlysnap[i],arena.data()); }
+		for ( size_t i = 0; i < earlysnap.size(); ++i ) { ++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); wave_run([&]() { processWindow(WB,earlysnap[i],arena.data()); }); }
 		{
 			uint64_t const n = haveList ? cur.size() : BP.nwindows;
 			for ( uint64_t i = 0; i < n; ++i )
 			{
 				uint64_t const wdx = haveList ? cur[i] : i;
-				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); processWindow(WB,wdx,arena.data());
+				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); wave_run([&]() { processWindow(WB,wdx,arena.data()); });
 			}
 		}
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_RETRY ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
@@ -200,7 +210,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			growArenaCaps(caps); caps.bytes = arena_carve(A,0,caps);
 			arena.assign(caps.bytes+64,0);
 			WB.C = caps; WB.arena = arena.data();
-			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) processWindow(WB,wdx,arena.data());
+			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) wave_run([&]() { processWindow(WB,wdx,arena.data()); });
 		}
 	}
 	c->windows.clear();

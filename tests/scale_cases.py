@@ -1,0 +1,50 @@
+"""BASELINE-scale parity cases shared by the golden generator (tests/golden/make_golden_scale.py, runs
+the oracle in the build container) and the GPU test / bench (which only hash what the HIP path returns)."""
+import hashlib
+import numpy as np
+
+THIRD = 1.0 / 3.0
+
+CASES = {
+    # config 2 of BASELINE.json = bench.py's default data set (seed 3); the first 1000 of its 10 000 piles
+    "cfg2": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=1000,
+                 params=[dict(k=14)]),
+    # config 1 stand-in at the reference's default k (the E. coli files are not in the container)
+    "cfg1k8": dict(genome_len=500000, nreads=1000, read_len=10000, seed=2, synth={}, first=0, npiles=100,
+                   params=[dict(k=8)]),
+    # config 5: ONT-like 1/3-1/3-1/3 error mix, 15 % total, k sweep (k = 17 is outside the reference's semantics)
+    "cfg5": dict(genome_len=500000, nreads=1000, read_len=10000, seed=5, synth=dict(ins_frac=THIRD, del_frac=THIRD, sub_frac=THIRD),
+                 first=0, npiles=100, params=[dict(k=k) for k in (10, 11, 12, 13, 14, 15, 16)]),
+    # config 4 shape: 54x depth slice
+    "cfg4": dict(genome_len=111111, nreads=600, read_len=10000, seed=4, synth={}, first=0, npiles=50,
+                 params=[dict(k=14)]),
+}
+
+
+def make_case(case, pile_select):
+    from daccord_amd.synth import SynthData
+    d = SynthData(case["genome_len"], case["nreads"], case["read_len"], seed=case["seed"], **case["synth"])
+    ovl, piles = pile_select(d.ovl, d.piles)
+    sel = piles[case["first"]:case["first"] + case["npiles"]]
+    return d, ovl, piles, sel
+
+
+def window_digest(w):
+    h = hashlib.sha256()
+    for x in w:
+        ok = x["status"] == 1
+        h.update(np.array([x["pile"], x["y"], x["status"], x["mao"], x["elength"], x["k"] if ok else 0,
+                           x["filterfreq"] if ok else 0], dtype=np.int64).tobytes())
+        h.update(np.uint64(x["minrate"] if ok else 0).tobytes())
+        h.update(bytes(x["cons"]).rstrip(b"\0") if ok else b"")
+        h.update(b"|")
+    return h.hexdigest()
+
+
+def pile_digests(frags, bases, sel, fasta):
+    out = []
+    ar = frags["aread"] if len(frags) else np.zeros(0, np.int32)
+    for p in sel:
+        f = frags[ar == p["aread"]]
+        out.append(hashlib.sha256(fasta(f, bases).encode()).hexdigest()[:12])
+    return out
