@@ -67,10 +67,10 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 8, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 8, idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -158,50 +158,68 @@ struct FastLds
 	FLD(posL,uint8_t,FNC,e_parL)
 	FLD(pieF,uint8_t,FNC,e_posL)      // first piece id of candidate i (second = +1), FNOPAR if none
 	FLD(pieL,uint8_t,FNC,e_pieF)
-	FLD(cdh,FCC,16,e_pieL)
-	FLD(ch,FCC,16,e_cdh)
+	FLD(bestL,uint8_t,MAXCONS,e_pieL)      // best consensus so far (survives the tries)
+	FLD(cdh,FCC,16,e_bestL)
+	FLD(cseq,uint8_t,18*FSEQCAP,e_cdh)      // stretch sequences of the kept candidates (16 slots) + current + previous
+	// dead until the kept candidates are decoded: shared with the lane scratch of the enumerations (lscr: per lane a
+	// heap of 32 path ids / of 12 path ids / of PSIQ score intervals; all of it for an enumeration on lane 0 alone)
+	FLD(ch,FCC,16,e_cseq)
 	FLD(acc,FCC,16,e_ch)
 	FLD(accerr,uint32_t,16,e_acc)
-	FLD(bestL,uint8_t,MAXCONS,e_accerr)    // best consensus so far (survives the tries)
-	FLD(canderr,uint8_t,16*CT::maxs,e_bestL)
-	FLD(cseq,uint8_t,18*FSEQCAP,e_canderr)      // stretch sequences of the kept candidates (16 slots) + current + previous
-	FLD(consL,uint8_t,16*MAXCONS,e_cseq)   // decoded candidates
-	static constexpr uint32_t pbase = e_consL;
-	// reverse cache
+	FLD(canderr,uint8_t,16*CT::maxs,e_accerr)
+	FLD(consL,uint8_t,16*MAXCONS,e_canderr)   // decoded candidates
+	static constexpr uint32_t lscrbytes = 2560u*static_cast<uint32_t>(sizeof(typename CT::id_t));
+	FLD(lscr,uint8_t,lscrbytes,e_cseq)
+	FLD(siq,FSI,CT::siqcap,e_cseq)          // score intervals of a pair combined on lane 0
+	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
+	static constexpr uint32_t pbase = fcmax(e_consL,e_lscr);
+	// reverse pool: paths by pool id
 	FLD(rc_w,uint64_t,CT::rccap,pbase)
 	FLD(rc_parent,typename CT::id_t,CT::rccap,e_rc_w)
 	FLD(rc_stretch,uint8_t,CT::rccap,e_rc_parent)
 	FLD(rc_pos,uint8_t,CT::rccap,e_rc_stretch)
 	FLD(rc_len,uint8_t,CT::rccap,e_rc_pos)
 	FLD(rc_baselen,uint8_t,CT::rccap,e_rc_len)
-	FLD(rc_ord,typename CT::id_t,CT::rccap,e_rc_baselen)
+	FLD(rc_acc,typename CT::id_t,CT::rccap,e_rc_baselen)     // accepted paths of an enumeration, in its own slots
+	// sorted blocks of the reverse enumerations
+	FLD(rc_ord,typename CT::id_t,CT::rccap,e_rc_acc)
 	FLD(rc_arw,typename CT::id_t,CT::rccap,e_rc_ord)
 	FLD(rc_sbl,uint8_t,CT::rccap,e_rc_arw)         // base length of the i-th entry in sorted order
 	FLD(rc_front,uint32_t,CT::rccap,e_rc_sbl)      // front k-mer of the i-th entry in sorted order
 	FLD(rbase,uint16_t,FNC+1,e_rc_front)
 	FLD(rn,uint16_t,FNC+1,e_rbase)
-	FLD(rvalid,uint8_t,FNC+1,e_rn)
-	FLD(rmaxw,uint64_t,FNC+1,e_rvalid)
+	FLD(rmaxw,uint64_t,FNC+1,e_rn)
 	FLD(rtmask,uint64_t,FNC+1,e_rmaxw)
 	FLD(rfmask,uint64_t,FNC+1,e_rtmask)    // one bit per front k-mer (value mod 64) of the accepted reverse paths
-	// forward pool
+	// forward pool: paths by pool id
 	FLD(f_w,uint64_t,CT::fcap,e_rfmask)
 	FLD(f_parent,typename CT::id_t,CT::fcap,e_f_w)
 	FLD(f_stretch,uint8_t,CT::fcap,e_f_parent)
 	FLD(f_pos,uint8_t,CT::fcap,e_f_stretch)
 	FLD(f_baselen,uint8_t,CT::fcap,e_f_pos)
 	FLD(f_len,uint8_t,CT::fcap,e_f_baselen)
-	FLD(fpop,typename CT::id_t,CT::fcap,e_f_len)
-	// per popped path (pop order): k-mer of its last node, candidate length, weight minus the junction node
-	FLD(fp_cl,uint8_t,CT::fcap,e_fpop)
+	// popped paths of a tree (pop order, in the tree's own slots): path, candidate length, k-mer of its last node, weight
+	// minus the junction node
+	FLD(fp_id,typename CT::id_t,CT::fcap,e_f_len)
+	FLD(fp_cl,uint8_t,CT::fcap,e_fp_id)
 	FLD(fp_front,uint32_t,CT::fcap,e_fp_cl)
 	FLD(fp_adj,uint64_t,CT::fcap,e_fp_front)
-	// heaps
-	FLD(rpst,typename CT::id_t,CT::rpstcap,e_fp_adj)
-	FLD(hbl,typename CT::id_t,CT::blcap*12,e_rpst)
-	FLD(hbl_n,uint8_t,CT::blcap,e_hbl)
-	FLD(siq,FSI,CT::siqcap,e_hbl_n)
-	static constexpr uint32_t upool = e_siq;
+	// per first k-mer candidate: chunk list of its tree, popped paths, junction k-mer bits, scan target bits, heaviest path
+	FLD(fchb,uint8_t,16*(FNC+1),e_fp_adj)
+	FLD(fnp,uint16_t,FNC+1,e_fchb)
+	FLD(ffm,uint64_t,FNC+1,e_fnp)
+	FLD(ftm,uint64_t,FNC+1,e_ffm)
+	FLD(fmx,uint64_t,FNC+1,e_ftm)
+	// recorded (path, entry) sequences of the pairs of a round
+	FLD(pout,typename CT::id_t,32*32,e_fmx)
+	FLD(poutn,uint8_t,32,e_pout)
+	FLD(ctr,uint32_t,4,e_poutn)
+	FLD(rchx,uint8_t,32,e_ctr)              // chunk ids of a reverse enumeration on lane 0 alone
+	static constexpr uint32_t upool = e_rchx;
+	// chunk ids of the reverse enumerations of all last k-mers (32 per lane): over the per first k-mer tables, which are
+	// written after those enumerations have been copied to their blocks
+	FLD(rchb,uint8_t,64*32,o_fchb)
+	static_assert(e_rchb <= o_pout,"reverse chunk lists must fit the per first k-mer tables");
 	// raw stretches (overlay of the caches)
 	FLD(tfirst,uint16_t,CT::scap,pbase)
 	FLD(tlast,uint16_t,CT::scap,e_tfirst)
@@ -222,8 +240,8 @@ struct FastLds
 	// fixed-point model table [pos][row], row stride nrows+1.  It shares the bytes of the enumeration pools: it is
 	// (re)loaded from HBM/L2 for gap filling and for the stretch feasibility of a traverse call, both of which are over
 	// before the pools are used.
-	FLD(tab,uint32_t,(upool-o_canderr)/4,o_canderr)   // also over the candidate buffers, which are dead at that time
-	static constexpr uint32_t tabcap = (upool-o_canderr)/4;
+	FLD(tab,uint32_t,(upool-o_cdh)/4,o_cdh)   // also over the candidate buffers, which are dead at that time
+	static constexpr uint32_t tabcap = (upool-o_cdh)/4;
 	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
 };
 #undef FLD
@@ -292,9 +310,6 @@ struct FastEngine
 	uint32_t npre, nlast, nn, nmfirst, nmlast;
 	uint32_t n0, npool, nlinks, nwF, nwR;
 	uint32_t nF, nL;
-	uint32_t rctop;                      // used entries of the reverse cache
-	uint32_t np, nfpop, nsiq, ncdh, nacc;
-	int32_t fcur_fi; int32_t fcur_li;    // what the forward pool holds: F(fi) on view(fi) (li = -1) or an exact pair view
 
 	DEV void over(uint32_t b) { flags |= b; }
 #if defined(DACC_PROFILE) && !defined(DACC_EMUL)
@@ -876,6 +891,149 @@ struct FastEngine
 		}
 		wv_sync();
 	}
+
+	// ---- stretch feasibility, one LANE per (stretch, direction) (the wavefront-per-stretch form above walks the
+	// stretches one after the other and leaves most lanes idle for the short position ranges that survive the node
+	// supports).  A lane first intersects the support ranges of its nodes (start positions that every node allows),
+	// reserves that many weight slots by a wave scan and then evaluates FNP start positions at a time: node and instance
+	// loads are shared by the FNP positions and run three nodes ahead of the table reads (the chain link -> node ->
+	// instance -> table would otherwise be paid per node).  Same sums in the same order as computeStretchFeas, entries in
+	// ascending start position.  If the reservations (upper bounds) of all stretches do not fit, the feasible positions
+	// are counted first and evaluated again at their exact offsets.
+	enum { FNP = 8 };
+	DEV uint64_t evalStretchLane(bool const rev, bool const maskonly, uint32_t const len, LDSQ uint16_t const * Lk, int32_t const lo, int32_t const hi, uint32_t const wbase)
+	{
+		uint32_t const stride = nrows+1;
+		LDSQ uint8_t const * IP = rev ? L.irpos() : L.ipos();
+		uint64_t mask = 0; uint32_t cnt = 0;
+		#define DACC_LKN(J) static_cast<uint32_t>(Lk[rev ? (len-1-(J)) : (J)])
+		for ( int32_t P0 = lo; P0 < hi; P0 += FNP )
+		{
+			uint64_t sum[FNP], f1[FNP], fl[FNP]; uint32_t okm = 0;
+			#pragma unroll
+			for ( int u = 0; u < FNP; ++u ) { sum[u] = 0; f1[u] = 0; fl[u] = 0; if ( P0+u < hi ) okm |= 1u<<u; }
+			// software pipeline over the nodes: a = node j (instances known), b = node j+1 (index known), c = node j+2
+			uint32_t z_b = len > 1 ? DACC_LKN(1) : 0u, z_c = len > 2 ? DACC_LKN(2) : 0u;
+			uint32_t i0_a, f_a, ip_a, i0_b, f_b;
+			{ uint32_t const z_a = DACC_LKN(0); i0_a = L.nps()[z_a]; f_a = L.nfreq()[z_a]; ip_a = IP[i0_a]; i0_b = L.nps()[z_b]; f_b = L.nfreq()[z_b]; }
+			for ( uint32_t j = 0; j < len && okm; ++j )
+			{
+				uint32_t const z_d = j+3 < len ? DACC_LKN(j+3) : 0u;
+				uint32_t const i0_c = L.nps()[z_c], f_c = L.nfreq()[z_c];
+				uint32_t const ip_b = IP[i0_b];
+				uint64_t U[FNP];
+				{
+					uint32_t const row = ip_a*stride;
+					#pragma unroll
+					for ( int u = 0; u < FNP; ++u )
+					{
+						uint32_t const pp = static_cast<uint32_t>(P0+u)+j;
+						U[u] = L.tab()[row + (pp < nrows ? pp : nrows)];
+					}
+				}
+				for ( uint32_t q = 1; q < f_a; ++q )
+				{
+					uint32_t const row = static_cast<uint32_t>(IP[i0_a+q])*stride;
+					#pragma unroll
+					for ( int u = 0; u < FNP; ++u )
+					{
+						uint32_t const pp = static_cast<uint32_t>(P0+u)+j;
+						U[u] += L.tab()[row + (pp < nrows ? pp : nrows)];
+					}
+				}
+				#pragma unroll
+				for ( int u = 0; u < FNP; ++u )
+				{
+					if ( U[u] < FW_THRES_FEAS ) okm &= ~(1u<<u);
+					sum[u] += U[u];
+					if ( j == 0 ) f1[u] = U[u];
+					fl[u] = U[u];
+				}
+				i0_a = i0_b; f_a = f_b; ip_a = ip_b; i0_b = i0_c; f_b = f_c; z_c = z_d;
+			}
+			#pragma unroll
+			for ( int u = 0; u < FNP; ++u )
+				if ( (okm>>u)&1 )
+				{
+					uint32_t const o = wbase + cnt; ++cnt;
+					mask |= 1ull << (P0+u);
+					if ( maskonly ) continue;
+					if ( rev )
+					{
+						L.wR_lo()[o] = static_cast<uint32_t>(sum[u]); L.wR_hi()[o] = static_cast<uint16_t>(sum[u]>>32);
+						L.wR1_lo()[o] = static_cast<uint32_t>(f1[u]); L.wR1_hi()[o] = static_cast<uint8_t>(f1[u]>>32);
+					}
+					else
+					{
+						L.wF_lo()[o] = static_cast<uint32_t>(sum[u]); L.wF_hi()[o] = static_cast<uint16_t>(sum[u]>>32);
+						L.wF1_lo()[o] = static_cast<uint32_t>(f1[u]); L.wF1_hi()[o] = static_cast<uint8_t>(f1[u]>>32);
+						L.wFl_lo()[o] = static_cast<uint32_t>(fl[u]); L.wFl_hi()[o] = static_cast<uint8_t>(fl[u]>>32);
+					}
+				}
+		}
+		#undef DACC_LKN
+		return mask;
+	}
+	// start positions [lo,hi) that the supports of all nodes of stretch s allow in direction rev
+	DEV void stretchRange(uint32_t const s, bool const rev, uint32_t & len, LDSQ uint16_t const * & Lk, int32_t & lo, int32_t & hi) const
+	{
+		len = L.sslen()[s]; Lk = L.links() + L.slink()[s];
+		lo = 0; hi = static_cast<int32_t>(nrows);
+		uint32_t const sh = rev ? 16 : 0;
+		for ( uint32_t j = 0; j < len; ++j )
+		{
+			uint32_t const g = L.nrange()[Lk[rev ? (len-1-j) : j]] >> sh;
+			int32_t const jj = static_cast<int32_t>(j);
+			int32_t const a = static_cast<int32_t>(g&0xFF)-jj, b = static_cast<int32_t>((g>>8)&0xFF)-jj;
+			lo = a > lo ? a : lo; hi = b < hi ? b : hi;
+		}
+		if ( hi < lo ) hi = lo;
+	}
+	DEV void computeStretchFeasLanes(uint32_t const sfrom, uint32_t const sto)
+	{
+		// do the reservations of all stretches fit?
+		bool exact = false;
+		{
+			uint32_t tF = 0, tR = 0;
+			for ( uint32_t c = 2*sfrom; c < 2*sto; c += WSZ )
+			{
+				uint32_t const u = c + lane;
+				uint32_t w = 0; bool const rev = u & 1;
+				if ( u < 2*sto ) { uint32_t len; LDSQ uint16_t const * Lk; int32_t lo, hi; stretchRange(u>>1,rev,len,Lk,lo,hi); w = static_cast<uint32_t>(hi-lo); }
+				tF += wv_sum(rev ? 0u : w); tR += wv_sum(rev ? w : 0u);
+			}
+			exact = (nwF + tF > CT::wcap) || (nwR + tR > CT::wcap);
+		}
+		for ( uint32_t c = 2*sfrom; c < 2*sto; c += WSZ )
+		{
+			uint32_t const u = c + lane;
+			bool const act = u < 2*sto;
+			bool const rev = u & 1;
+			uint32_t const s = u>>1;
+			uint32_t len = 0; int32_t lo = 0, hi = 0;
+			LDSQ uint16_t const * Lk = L.links();
+			if ( act ) stretchRange(s,rev,len,Lk,lo,hi);
+			uint64_t m = 0;
+			uint32_t wF, wR;
+			if ( exact )
+			{
+				if ( act ) m = evalStretchLane(rev,true,len,Lk,lo,hi,0);
+				wF = act && !rev ? dacc_popc64(m) : 0u; wR = act && rev ? dacc_popc64(m) : 0u;
+			}
+			else { wF = act && !rev ? static_cast<uint32_t>(hi-lo) : 0u; wR = act && rev ? static_cast<uint32_t>(hi-lo) : 0u; }
+			uint32_t totF, totR;
+			uint32_t const preF = wv_scan_excl(wF,totF), preR = wv_scan_excl(wR,totR);
+			if ( nwF + totF > CT::wcap || nwR + totR > CT::wcap ) { over(128); return; }
+			if ( act )
+			{
+				uint32_t const wb = rev ? (nwR+preR) : (nwF+preF);
+				uint64_t const mm = evalStretchLane(rev,false,len,Lk,lo,hi,wb);
+				if ( rev ) { L.maskR()[s] = mm; L.woffR()[s] = wb; } else { L.maskF()[s] = mm; L.woffF()[s] = wb; }
+			}
+			nwF += totF; nwR += totR;
+		}
+		wv_sync();
+	}
 	// weights of feasible (stretch, position) entry i.  A node weight is a sum of at most 255 table words (< 2^40), a
 	// feasible stretch has at most nrows <= 64 nodes (< 2^46)
 	DEV uint64_t wuF(uint32_t const i) const { return L.wF_lo()[i] | (static_cast<uint64_t>(L.wF_hi()[i])<<32); }
@@ -930,10 +1088,10 @@ struct FastEngine
 	// ================= views: the stretch set of a pair in sorted order =================
 	// view = base stretches (pool ids 0..n0-1, already in Stretch::operator< order) minus the split parents plus the
 	// pieces.  It is never materialised: the enumerations look stretches up by first / last node (fhead = npred region,
-	// lhead/lord) and merge the <= 6 inserted pieces by their position ppos among the base stretches.
-	struct View { uint32_t nadd; uint32_t r0, r1; };
+	// lhead/lord) and merge the <= 4 inserted pieces by their position ppos among the base stretches.  A view lives in
+	// registers (every lane has its own): e[i] = piece | position << 8 | first node << 16 | last node << 32.
+	struct View { uint32_t nadd; uint32_t r0, r1; uint64_t e0, e1, e2, e3; };
 	struct MIt { uint32_t i, a, target; };
-	View V;
 	// number of base stretches whose key is smaller than the key of pool stretch s
 	DEV uint32_t basePos(uint32_t const s) const
 	{
@@ -942,49 +1100,63 @@ struct FastEngine
 		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( poolKey(mid) < key ) lo = mid+1; else hi = mid; }
 		return lo;
 	}
-	DEV void viewClear() { V.nadd = 0; V.r0 = 0xFFFF; V.r1 = 0xFFFF; }
-	DEV void viewRemove(uint32_t const s) { if ( V.r0 == 0xFFFF ) V.r0 = s; else V.r1 = s; }
-	DEV void viewAdd(uint32_t const s)
+	DEV static void viewClear(View & V) { V.nadd = 0; V.r0 = 0xFFFF; V.r1 = 0xFFFF; V.e0 = V.e1 = V.e2 = V.e3 = 0; }
+	DEV static void viewRemove(View & V, uint32_t const s) { if ( V.r0 == 0xFFFF ) V.r0 = s; else V.r1 = s; }
+	// (masks instead of selects: a select chain over four registers is turned into an indexed access of a scratch array)
+	DEV static uint64_t viewE(View const & V, uint32_t const i)
+	{
+		uint64_t const m0 = 0ull - static_cast<uint64_t>(i == 0), m1 = 0ull - static_cast<uint64_t>(i == 1), m2 = 0ull - static_cast<uint64_t>(i == 2), m3 = 0ull - static_cast<uint64_t>(i == 3);
+		return (V.e0 & m0) | (V.e1 & m1) | (V.e2 & m2) | (V.e3 & m3);
+	}
+	DEV static uint32_t vAdd(uint64_t const e) { return static_cast<uint32_t>(e) & 0xFF; }
+	DEV static uint32_t vPos(uint64_t const e) { return static_cast<uint32_t>(e>>8) & 0xFF; }
+	DEV static uint32_t vFn(uint64_t const e) { return static_cast<uint32_t>(e>>16) & 0xFFFF; }
+	DEV static uint32_t vLn(uint64_t const e) { return static_cast<uint32_t>(e>>32) & 0xFFFF; }
+	DEV void viewAdd(View & V, uint32_t const s) const
 	{
 		uint32_t const pos = L.ppos()[s];
-		uint32_t i = V.nadd++;
+		uint64_t const key = poolKey(s);
+		uint64_t const ne = s | (static_cast<uint64_t>(pos)<<8) | (static_cast<uint64_t>(L.sfirst()[s])<<16) | (static_cast<uint64_t>(L.slast()[s])<<32);
 		// keep the insertions sorted by (position, key)
-		while ( i > 0 && ( L.vapos()[i-1] > pos || (L.vapos()[i-1] == pos && poolKey(L.vadd()[i-1]) > poolKey(s)) ) )
+		uint32_t i = V.nadd;
+		#define DACC_VSHIFT(Q,PE,DST) if ( i == Q ) { uint64_t const pe = PE; if ( vPos(pe) > pos || (vPos(pe) == pos && poolKey(vAdd(pe)) > key) ) { DST = pe; i = Q-1; } }
+		DACC_VSHIFT(3,V.e2,V.e3) DACC_VSHIFT(2,V.e1,V.e2) DACC_VSHIFT(1,V.e0,V.e1)
+		#undef DACC_VSHIFT
 		{
-			L.vadd()[i] = L.vadd()[i-1]; L.vapos()[i] = L.vapos()[i-1]; L.vfn()[i] = L.vfn()[i-1]; L.vln()[i] = L.vln()[i-1];
-			--i;
+			uint64_t const m0 = 0ull - static_cast<uint64_t>(i == 0), m1 = 0ull - static_cast<uint64_t>(i == 1), m2 = 0ull - static_cast<uint64_t>(i == 2), m3 = 0ull - static_cast<uint64_t>(i == 3);
+			V.e0 = (V.e0 & ~m0) | (ne & m0); V.e1 = (V.e1 & ~m1) | (ne & m1); V.e2 = (V.e2 & ~m2) | (ne & m2); V.e3 = (V.e3 & ~m3) | (ne & m3);
 		}
-		L.vadd()[i] = s; L.vapos()[i] = pos; L.vfn()[i] = L.sfirst()[s]; L.vln()[i] = L.slast()[s];
+		++V.nadd;
 	}
-	DEV bool viewRemoved(uint32_t const s) const { return s == V.r0 || s == V.r1; }
+	DEV static bool viewRemoved(View const & V, uint32_t const s) { return s == V.r0 || s == V.r1; }
 	// view stretches whose first node is `node`, in view order
-	DEV void byFirstBegin(MIt & it, uint32_t const node) const { it.i = fheadOf(node); it.a = 0; it.target = node; }
-	DEV int32_t byFirstNext(MIt & it) const
+	DEV void byFirstBegin(View const &, MIt & it, uint32_t const node) const { it.i = fheadOf(node); it.a = 0; it.target = node; }
+	DEV int32_t byFirstNext(View const & V, MIt & it) const
 	{
 		while ( true )
 		{
-			while ( it.a < V.nadd && L.vfn()[it.a] != it.target ) ++it.a;
+			while ( it.a < V.nadd && vFn(viewE(V,it.a)) != it.target ) ++it.a;
 			bool const haveb = it.i < n0 && L.sfirst()[it.i] == it.target;
-			if ( it.a < V.nadd && ( !haveb || L.vapos()[it.a] <= it.i ) ) return L.vadd()[it.a++];
+			if ( it.a < V.nadd && ( !haveb || vPos(viewE(V,it.a)) <= it.i ) ) return vAdd(viewE(V,it.a++));
 			if ( !haveb ) return -1;
 			uint32_t const sx = it.i++;
-			if ( !viewRemoved(sx) ) return sx;
+			if ( !viewRemoved(V,sx) ) return sx;
 		}
 	}
 	// view stretches whose last node is `node`, in view order
-	DEV void byLastBegin(MIt & it, uint32_t const node) const { it.i = L.lhead()[node]; it.a = 0; it.target = node; }
-	DEV int32_t byLastNext(MIt & it) const
+	DEV void byLastBegin(View const &, MIt & it, uint32_t const node) const { it.i = L.lhead()[node]; it.a = 0; it.target = node; }
+	DEV int32_t byLastNext(View const & V, MIt & it) const
 	{
 		while ( true )
 		{
-			while ( it.a < V.nadd && L.vln()[it.a] != it.target ) ++it.a;
+			while ( it.a < V.nadd && vLn(viewE(V,it.a)) != it.target ) ++it.a;
 			uint32_t const e = it.i < n0 ? L.lord()[it.i] : 0xFFFFFFFFu;
 			bool const haveb = (e>>8) == it.target;
 			uint32_t const sx = e & 0xFF;
-			if ( it.a < V.nadd && ( !haveb || L.vapos()[it.a] <= sx ) ) return L.vadd()[it.a++];
+			if ( it.a < V.nadd && ( !haveb || vPos(viewE(V,it.a)) <= sx ) ) return vAdd(viewE(V,it.a++));
 			if ( !haveb ) return -1;
 			++it.i;
-			if ( !viewRemoved(sx) ) return sx;
+			if ( !viewRemoved(V,sx) ) return sx;
 		}
 	}
 	DEV uint32_t fheadOf(uint32_t const node) const { return L.npred()[node]; }   // npred is free once the stretches are walked
@@ -1062,44 +1234,143 @@ struct FastEngine
 		if ( l < f && !hless<MINHEAP>(H[i].w,H[l].w) ) ldswap(H+i,H+l);
 	}
 
-	// ================= reverse enumeration on the current view (lane 0) =================
-	uint32_t rb, nrp, narp, rlastk; uint64_t rmaxw, fmaxw;
-	// extendReversePath :4058-4105 with the parent's fields and the feasible entry sfo = csfFind(s,ppos) held in registers
-	// (checkReversePathFeasiblePosition :4130-4159 looks the same entry up again: the check position is the parent's)
-	DEV int32_t extendReversePath(uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl, int32_t const sfo, uint64_t const wr)
+	// ================= per-lane path enumerations =================
+	// The reverse enumeration of every last k-mer candidate and the forward enumeration of every first k-mer candidate
+	// are independent of each other, so they run on one lane each (lane = candidate), all candidates of a window at once;
+	// the same routines run on lane 0 alone for the rare pair that needs its exact stretch set.  Paths live in shared
+	// pools (rc_* / f_*, indexed by a pool-wide id); a lane takes pool entries in chunks of RCH / FCH through an LDS
+	// counter and keeps its chunk list in registers (entry i of an enumeration -> clSlot).
+	enum { RCH = CT::rch, RNW = 4, FCH = CT::fch, FNW = 2 };         // entries per chunk, 64 bit words of chunk ids (8 per word)
+	// The chunk ids of an enumeration are a row of bytes in LDS (a register array indexed at run time would end up in
+	// scratch memory): NW*8 chunks per enumeration.
+	template<int NW> struct ChunkList { LDSQ uint8_t * ids; uint32_t n; };
+	template<int NW> DEV static void clInit(ChunkList<NW> & C, LDSQ uint8_t * row) { C.ids = row; C.n = 0; }
+	template<int PCH, int NW> DEV static uint32_t clSlot(ChunkList<NW> const & C, uint32_t const i) { return static_cast<uint32_t>(C.ids[i/PCH])*PCH + (i%PCH); }
+	// slot of entry i, taking a new chunk from the pool when i starts one; ~0u: pool or chunk list exhausted
+	template<int PCH, int NW> DEV uint32_t clEnsure(ChunkList<NW> & C, uint32_t const i, LDSQ uint32_t * ctr, uint32_t const nchunks)
 	{
-		if ( rb+nrp >= CT::rccap ) { over(512|0x4000); return -1; }
-		if ( nrp >= CT::idmax ) { over(512|0x8000); return -1; }
-		uint32_t const id = nrp++;
+		uint32_t const ch = i/PCH;
+		if ( ch >= C.n )
+		{
+			if ( ch >= 8*NW ) return ~0u;
+			uint32_t const id = wv_atomic_add(ctr,1u);
+			if ( id >= nchunks || id > 255 ) return ~0u;
+			C.ids[ch] = id;
+			C.n = ch+1;
+			return id*PCH + (i%PCH);
+		}
+		return clSlot<PCH>(C,i);
+	}
+
+	// ---- reverse enumeration (prepareTraverse :3582-3765) of one last k-mer on view V ----
+	struct REnum { ChunkList<RNW> C; uint32_t nrp, narp, lastk; };
+	// extendReversePath :4058-4105 with the parent's fields and the feasible entry sfo = csfFind(s,ppos) in registers
+	// (checkReversePathFeasiblePosition :4130-4159 looks the same entry up again: the check position is the parent's)
+	DEV int32_t extendReversePath(REnum & R, uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl, int32_t const sfo, uint64_t const wr)
+	{
+		uint32_t const slot = clEnsure<RCH>(R.C,R.nrp,L.ctr()+0,CT::rccap/RCH);
+		if ( slot == ~0u ) { over(512|0x4000); return -1; }
 		uint32_t const slen = L.sslen()[s];
 		uint64_t weight = pw; uint32_t baselen = pbl;
 		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wr : 0; }
 		else { baselen += slen-1; if ( sfo >= 0 ) weight += wr - w1R(sfo); }
 		uint32_t const npos = ppos + slen-1;
-		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --nrp; return -1; }
-		L.rc_parent()[rb+id] = parent; L.rc_stretch()[rb+id] = s; L.rc_len()[rb+id] = plen+1; L.rc_pos()[rb+id] = npos;
-		L.rc_w()[rb+id] = weight; L.rc_baselen()[rb+id] = baselen;
-		return id;
+		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); return -1; }
+		++R.nrp;
+		L.rc_parent()[slot] = parent; L.rc_stretch()[slot] = s; L.rc_len()[slot] = plen+1; L.rc_pos()[slot] = npos;
+		L.rc_w()[slot] = weight; L.rc_baselen()[slot] = baselen;
+		return slot;
 	}
-	DEV uint32_t rpFront(uint32_t const id) const { return L.rc_len()[rb+id] ? L.nv()[L.sfirst()[L.rc_stretch()[rb+id]]] : rlastk; }
-	DEV bool arpLess(id_t const a, id_t const b) const
+	DEV uint32_t rpFront(uint32_t const id, uint32_t const lastk) const { return L.rc_len()[id] ? L.nv()[L.sfirst()[L.rc_stretch()[id]]] : lastk; }
+	// accepted paths are listed in acceptance order in the enumeration's own slots (rc_acc); rpst = the lane's heap
+	DEV void reverseEnumerateLane(REnum & R, LDSQ uint8_t * chunkrow, View const & V, uint32_t const lastkmer, int32_t const lastnode, int64_t const lmax, LDSQ id_t * rpst, uint32_t const rpstcap)
 	{
-		uint32_t const fa = rpFront(a), fb = rpFront(b);
-		if ( fa != fb ) return fa < fb;
-		return L.rc_baselen()[rb+a] < L.rc_baselen()[rb+b];
+		clInit(R.C,chunkrow); R.nrp = 0; R.narp = 0; R.lastk = lastkmer;
+		uint32_t nrpst = 0;
+		if ( lastnode >= 0 )
+		{
+			uint32_t const slot = clEnsure<RCH>(R.C,0,L.ctr()+0,CT::rccap/RCH);
+			if ( slot == ~0u ) { over(512|0x4000); return; }
+			R.nrp = 1;
+			L.rc_parent()[slot] = 0; L.rc_stretch()[slot] = 0xFF; L.rc_len()[slot] = 0; L.rc_pos()[slot] = 0; L.rc_w()[slot] = 0; L.rc_baselen()[slot] = k;
+			rpst[nrpst++] = slot;
+		}
+		LDSQ uint64_t const * W = L.rc_w();
+		while ( nrpst )
+		{
+			uint32_t const rp = rpst[0];
+			ipop<false>(rpst,nrpst,W);
+			uint32_t const bl = L.rc_baselen()[rp], ppos = L.rc_pos()[rp], plen = L.rc_len()[rp];
+			uint64_t const pw = W[rp];
+			// ARPH[bl] (:3626-3665) keeps the 12 heaviest accepted paths of a base length and admits a path only if it is
+			// heavier than the lightest of them: a path is dropped iff 12 accepted paths of its length weigh at least as much
+			if ( R.narp >= 12 )
+			{
+				uint32_t cnt = 0;
+				for ( uint32_t i = 0; i < R.narp; ++i )
+				{
+					uint32_t const a = L.rc_acc()[clSlot<RCH>(R.C,i)];
+					cnt += (L.rc_baselen()[a] == bl && W[a] >= pw) ? 1 : 0;
+				}
+				if ( cnt >= 12 ) continue;
+			}
+			L.rc_acc()[clSlot<RCH>(R.C,R.narp)] = rp; ++R.narp;
+			if ( plen == 0 )
+			{
+				MIt it; byLastBegin(V,it,lastnode);
+				for ( int32_t sx = byLastNext(V,it); sx >= 0; sx = byLastNext(V,it) )
+				{
+					int32_t const sfo = csfFind(sx,ppos);
+					uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
+					if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;     // the new path would be dropped right away
+					int32_t const rpe = extendReversePath(R,rp,sx,ppos,plen,pw,bl,sfo,wr);
+					if ( rpe < 0 ) return;
+					if ( nrpst >= rpstcap ) { over(512|0x8000); return; }
+					ipush<false>(rpst,nrpst,static_cast<id_t>(rpe),W);
+				}
+			}
+			else if ( static_cast<int64_t>(bl) < (lmax+1)/2 )
+			{
+				uint32_t const b = L.rc_stretch()[rp];
+				uint32_t const bf = L.sfirst()[b];
+				MIt it; byLastBegin(V,it,bf);
+				for ( int32_t ax = byLastNext(V,it); ax >= 0; ax = byLastNext(V,it) )
+				{
+					uint32_t const a = ax;
+					if ( linkOk(a,b) )
+					{
+						int32_t const sfo = csfFind(a,ppos);
+						uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
+						if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;
+						int32_t const rpe = extendReversePath(R,rp,a,ppos,plen,pw,bl,sfo,wr);
+						if ( rpe < 0 ) return;
+						if ( nrpst >= rpstcap ) { over(512|0x8000); return; }
+						ipush<false>(rpst,nrpst,static_cast<id_t>(rpe),W);
+					}
+				}
+			}
+		}
 	}
-	DEV void arpULI(LDSQ id_t * last) { id_t const val = *last; LDSQ id_t * next = last-1; while ( arpLess(val,*next) ) { *last = *next; last = next; --next; } *last = val; }
-	DEV void arpIns(LDSQ id_t * first, LDSQ id_t * last)
+	// ---- block of a finished reverse enumeration in sorted order at rc_ord/rc_arw/rc_sbl/rc_front[sbase..sbase+narp) ----
+	DEV bool arpLess(uint32_t const a, uint32_t const b, uint32_t const lastk) const
+	{
+		uint32_t const fa = rpFront(a,lastk), fb = rpFront(b,lastk);
+		if ( fa != fb ) return fa < fb;
+		return L.rc_baselen()[a] < L.rc_baselen()[b];
+	}
+	DEV void arpULI(LDSQ id_t * last, uint32_t const lk) { id_t const val = *last; LDSQ id_t * next = last-1; while ( arpLess(val,*next,lk) ) { *last = *next; last = next; --next; } *last = val; }
+	DEV void arpIns(LDSQ id_t * first, LDSQ id_t * last, uint32_t const lk)
 	{
 		if ( first == last ) return;
 		for ( LDSQ id_t * i = first+1; i != last; ++i )
 		{
-			if ( arpLess(*i,*first) ) { id_t const val = *i; for ( LDSQ id_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
-			else arpULI(i);
+			if ( arpLess(*i,*first,lk) ) { id_t const val = *i; for ( LDSQ id_t * q = i; q != first; --q ) *q = *(q-1); *first = val; }
+			else arpULI(i,lk);
 		}
 	}
-	// libstdc++ std::sort permutation (introsort + final insertion sort), see dbg_window.hpp arpSort
-	DEV void arpSort(LDSQ id_t * first, LDSQ id_t * last)
+	// libstdc++ std::sort permutation (introsort + final insertion sort), see dbg_window.hpp arpSort; more than 16
+	// elements need the (single) explicit stack L.sstack, so only one lane at a time may sort such a block
+	DEV void arpSort(LDSQ id_t * first, LDSQ id_t * last, uint32_t const lk)
 	{
 		if ( first == last ) return;
 		int32_t const n = last-first;
@@ -1117,21 +1388,21 @@ struct FastEngine
 					if ( d == 0 ) { over(1024); return; }
 					--d;
 					LDSQ id_t * mid = f + (l-f)/2; LDSQ id_t * a = f+1; LDSQ id_t * b = mid; LDSQ id_t * c = l-1;
-					if ( arpLess(*a,*b) )
+					if ( arpLess(*a,*b,lk) )
 					{
-						if ( arpLess(*b,*c) ) { id_t t = *f; *f = *b; *b = t; }
-						else if ( arpLess(*a,*c) ) { id_t t = *f; *f = *c; *c = t; }
+						if ( arpLess(*b,*c,lk) ) { id_t t = *f; *f = *b; *b = t; }
+						else if ( arpLess(*a,*c,lk) ) { id_t t = *f; *f = *c; *c = t; }
 						else { id_t t = *f; *f = *a; *a = t; }
 					}
-					else if ( arpLess(*a,*c) ) { id_t t = *f; *f = *a; *a = t; }
-					else if ( arpLess(*b,*c) ) { id_t t = *f; *f = *c; *c = t; }
+					else if ( arpLess(*a,*c,lk) ) { id_t t = *f; *f = *a; *a = t; }
+					else if ( arpLess(*b,*c,lk) ) { id_t t = *f; *f = *c; *c = t; }
 					else { id_t t = *f; *f = *b; *b = t; }
 					LDSQ id_t * lo = f+1; LDSQ id_t * hi = l;
 					while ( true )
 					{
-						while ( arpLess(*lo,*f) ) ++lo;
+						while ( arpLess(*lo,*f,lk) ) ++lo;
 						--hi;
-						while ( arpLess(*f,*hi) ) --hi;
+						while ( arpLess(*f,*hi,lk) ) --hi;
 						if ( !(lo < hi) ) break;
 						id_t t = *lo; *lo = *hi; *hi = t;
 						++lo;
@@ -1140,221 +1411,145 @@ struct FastEngine
 					l = lo;
 				}
 			}
-			arpIns(first,first+16);
-			for ( LDSQ id_t * i = first+16; i != last; ++i ) arpULI(i);
+			arpIns(first,first+16,lk);
+			for ( LDSQ id_t * i = first+16; i != last; ++i ) arpULI(i,lk);
 		}
-		else arpIns(first,last);
+		else arpIns(first,last,lk);
 	}
-
-	// prepareTraverse :3582-3765 on the current view; result block at rc_*[rb ..rb+nrp), sorted order rc_ord, ranks rc_arw
-	DEV void reverseEnumerate(uint32_t const lastkmer, int32_t const lastnode, int64_t const lmax)
+	// copy the accepted list to its block (acceptance order)
+	DEV void reverseBlockCopy(REnum const & R, uint32_t const sbase)
 	{
-		nrp = 0; narp = 0; rlastk = lastkmer; rfmcur = 0;
-		{ LDSQ uint64_t * Z = reinterpret_cast<LDSQ uint64_t *>(L.hbl_n()); for ( uint32_t i = 0; i < CT::blcap/8; ++i ) Z[i] = 0; }
-		uint32_t nrpst = 0;
-		if ( lastnode >= 0 )
-		{
-			if ( rb >= CT::rccap ) { over(512|0x4000); return; }
-			uint32_t const id = nrp++;
-			L.rc_parent()[rb+id] = 0xFF; L.rc_stretch()[rb+id] = 0xFF; L.rc_len()[rb+id] = 0; L.rc_pos()[rb+id] = 0; L.rc_w()[rb+id] = 0; L.rc_baselen()[rb+id] = k;
-			L.rpst()[nrpst++] = id;
-		}
-		LDSQ uint64_t const * W = L.rc_w() + rb;
-		while ( nrpst )
-		{
-			uint32_t const rp = L.rpst()[0];
-			ipop<false>(L.rpst(),nrpst,W);
-			uint32_t const bl = L.rc_baselen()[rb+rp], ppos = L.rc_pos()[rb+rp], plen = L.rc_len()[rb+rp];
-			uint64_t const pw = W[rp];
-			if ( bl >= CT::blcap ) { over(2048); return; }
-			LDSQ id_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
-			if ( hn == 12 )
-			{
-				if ( pw <= W[H[0]] ) continue;
-				else ipop<true>(H,hn,W);
-			}
-			ipush<true>(H,hn,rp,W);
-			L.hbl_n()[bl] = hn;
-			if ( narp >= CT::idmax ) { over(512|0x8000); return; }
-			L.rc_ord()[rb+narp++] = rp;
-			if ( plen == 0 )
-			{
-				MIt it; byLastBegin(it,lastnode);
-				for ( int32_t sx = byLastNext(it); sx >= 0; sx = byLastNext(it) )
-				{
-					int32_t const sfo = csfFind(sx,ppos);
-					uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
-					if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;     // the new path would be dropped right away
-					int32_t const rpe = extendReversePath(rp,sx,ppos,plen,pw,bl,sfo,wr);
-					if ( rpe < 0 ) return;
-					if ( nrpst >= CT::rpstcap ) { over(512|0x8000); return; }
-					ipush<false>(L.rpst(),nrpst,rpe,W);
-				}
-			}
-			else if ( static_cast<int64_t>(bl) < (lmax+1)/2 )
-			{
-				uint32_t const b = L.rc_stretch()[rb+rp];
-				uint32_t const bf = L.sfirst()[b];
-				MIt it; byLastBegin(it,bf);
-				for ( int32_t ax = byLastNext(it); ax >= 0; ax = byLastNext(it) )
-				{
-					uint32_t const a = ax;
-					if ( linkOk(a,b) )
-					{
-						int32_t const sfo = csfFind(a,ppos);
-						uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
-						if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;
-						int32_t const rpe = extendReversePath(rp,a,ppos,plen,pw,bl,sfo,wr);
-						if ( rpe < 0 ) return;
-						if ( nrpst >= CT::rpstcap ) { over(512|0x8000); return; }
-						ipush<false>(L.rpst(),nrpst,rpe,W);
-					}
-				}
-			}
-		}
-
-		rmaxw = 0;
-		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[rb+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
-		arpSort(L.rc_ord()+rb,L.rc_ord()+rb+narp);
-		// rank of every entry by (weight, sorted position); the weights in sorted order are staged in the (idle) score
-		// interval heap so that the quadratic loop reads one word per step
-		LDSQ uint64_t * const sw = reinterpret_cast<LDSQ uint64_t *>(L.siq());
-		bool const staged = narp <= 2*CT::siqcap;
-		if ( staged ) for ( uint32_t i = 0; i < narp; ++i ) sw[i] = W[L.rc_ord()[rb+i]];
+		for ( uint32_t i = 0; i < R.narp; ++i ) L.rc_ord()[sbase+i] = L.rc_acc()[clSlot<RCH>(R.C,i)];
+	}
+	// sort the block and derive what the score intervals need; slot li of the per-candidate tables gets the summary
+	DEV void reverseBlockFinish(REnum const & R, uint32_t const sbase, uint32_t const li, int32_t const lastnode, int64_t const lmax)
+	{
+		uint32_t const narp = R.narp;
+		LDSQ uint64_t const * W = L.rc_w();
+		uint64_t rmaxw = 0, rfm = 0;
+		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[sbase+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
+		arpSort(L.rc_ord()+sbase,L.rc_ord()+sbase+narp,R.lastk);
+		// rank of every entry by (weight, sorted position); one bit per scan target (node id mod 64) of the enumeration
+		uint64_t tm = lastnode >= 0 ? (1ull << (lastnode & 63)) : 0ull;
 		for ( uint32_t i = 0; i < narp; ++i )
 		{
-			uint64_t const wi = staged ? sw[i] : W[L.rc_ord()[rb+i]];
+			uint32_t const rp = L.rc_ord()[sbase+i];
+			uint64_t const wi = W[rp];
 			uint32_t r = 0;
 			for ( uint32_t j = 0; j < narp; ++j )
 			{
-				uint64_t const wj = staged ? sw[j] : W[L.rc_ord()[rb+j]];
+				uint64_t const wj = W[L.rc_ord()[sbase+j]];
 				if ( wj < wi || (wj == wi && j < i) ) ++r;
 			}
-			L.rc_arw()[rb+i] = r;
-			uint32_t const rp = L.rc_ord()[rb+i];
-			uint32_t const fr = rpFront(rp);
-			L.rc_front()[rb+i] = fr; L.rc_sbl()[rb+i] = L.rc_baselen()[rb+rp];
-			rfmcur |= 1ull << (fr & 63);
+			L.rc_arw()[sbase+i] = r;
+			uint32_t const fr = rpFront(rp,R.lastk);
+			L.rc_front()[sbase+i] = fr; L.rc_sbl()[sbase+i] = L.rc_baselen()[rp];
+			rfm |= 1ull << (fr & 63);
+			if ( L.rc_len()[rp] && static_cast<int64_t>(L.rc_baselen()[rp]) < (lmax+1)/2 ) tm |= 1ull << (L.sfirst()[L.rc_stretch()[rp]] & 63);
 		}
-	}
-	// one bit per scan target of the enumeration just finished (node id mod 64): a clear bit proves that a node was not a target
-	DEV uint64_t reverseTargetMask(int32_t const lastnode, int64_t const lmax) const
-	{
-		uint64_t m = lastnode >= 0 ? (1ull << (lastnode & 63)) : 0ull;
-		for ( uint32_t i = 0; i < narp; ++i )
-		{
-			uint32_t const rp = L.rc_ord()[rb+i];
-			if ( L.rc_len()[rb+rp] && static_cast<int64_t>(L.rc_baselen()[rb+rp]) < (lmax+1)/2 ) m |= 1ull << (L.sfirst()[L.rc_stretch()[rb+rp]] & 63);
-		}
-		return m;
-	}
-	DEV uint64_t forwardTargetMask(int32_t const firstnode, int64_t const lmax) const
-	{
-		uint64_t m = 1ull << (firstnode & 63);
-		for ( uint32_t i = 0; i < nfpop; ++i )
-		{
-			uint32_t const path = L.fpop()[i];
-			uint32_t const pbl = L.f_baselen()[path];
-			if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) ) m |= 1ull << (L.slast()[L.f_stretch()[path]] & 63);
-		}
-		return m;
+		L.rbase()[li] = sbase; L.rn()[li] = narp; L.rmaxw()[li] = rmaxw; L.rtmask()[li] = tm; L.rfmask()[li] = rfm;
 	}
 	// can the cached reverse block (computed on the view of `last` alone) be used when stretch `par` is split at node `fn`?
 	// the scans of the enumeration look for stretches whose last node equals a target; the split changes the answer
 	// only for targets par.last (parent vs second piece) and fn (first piece)
-	DEV bool reverseUnaffected(uint32_t const base, uint32_t const nacc2, int32_t const lastnode, uint32_t const par, uint32_t const fn, int64_t const lmax) const
+	DEV bool reverseUnaffected(uint32_t const sbase, uint32_t const nacc2, int32_t const lastnode, uint32_t const par, uint32_t const fn, int64_t const lmax) const
 	{
 		uint32_t const plast = L.slast()[par];
 		if ( lastnode >= 0 && (static_cast<uint32_t>(lastnode) == plast || static_cast<uint32_t>(lastnode) == fn) ) return false;
 		for ( uint32_t i = 0; i < nacc2; ++i )
 		{
-			uint32_t const rp = L.rc_ord()[base+i];
-			if ( L.rc_len()[base+rp] && static_cast<int64_t>(L.rc_baselen()[base+rp]) < (lmax+1)/2 )
+			uint32_t const rp = L.rc_ord()[sbase+i];
+			if ( L.rc_len()[rp] && static_cast<int64_t>(L.rc_baselen()[rp]) < (lmax+1)/2 )
 			{
-				uint32_t const target = L.sfirst()[L.rc_stretch()[base+rp]];
+				uint32_t const target = L.sfirst()[L.rc_stretch()[rp]];
 				if ( target == plast || target == fn ) return false;
 			}
 		}
 		return true;
 	}
 
-	// ================= forward enumeration on the current view (lane 0) =================
-	uint64_t apqm0, apqm1;   // non empty base length buckets of the forward queue (base length < 128)
-	// extendPath :3989-4056 with the parent's fields, the feasible entry sfo = sfFind(s,ppos) and its weight in registers;
-	// the new path's position, base length and weight are returned in npos, nbl, nw
-	DEV int32_t extendPath(int32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl,
+	// ---- forward enumeration (path tree of traverse :4838-5041) of one first k-mer on view V ----
+	// APQ[baselen] (:4851-4862, 5003-5017) are bounded heaps of 12 that are filled completely before they are drained
+	// (an extension is strictly longer than its parent and the buckets are drained in increasing base length), so a
+	// bucket's heap is rebuilt right before it is drained by pushing its paths in creation order: one 12 entry heap per
+	// enumeration instead of one per base length, same heap arrays, same pop order among equal weights.
+	struct FEnum { ChunkList<FNW> C; uint32_t np, nfpop; uint64_t fmaxw, ffm, m0, m1; };
+	DEV int32_t extendPath(FEnum & F, uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl,
 		int32_t const sfo, uint64_t const wf, uint32_t & npos, uint32_t & nbl, uint64_t & nw)
 	{
-		if ( np >= CT::fcap || np >= CT::idmax ) { over(512|0x10000); return -1; }
-		uint32_t const id = np++;
+		uint32_t const slot = clEnsure<FCH>(F.C,F.np,L.ctr()+1,CT::fcap/FCH);
+		if ( slot == ~0u ) { over(512|0x10000); return -1; }
 		uint32_t const slen = L.sslen()[s];
 		uint64_t weight = pw; uint32_t baselen = pbl;
 		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wf : 0; }
 		else { baselen += slen-1; if ( sfo >= 0 ) weight += wf - w1F(sfo); }
 		npos = ppos + (slen-1); nbl = baselen; nw = weight;
-		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); --np; return -1; }
-		L.f_parent()[id] = parent >= 0 ? parent : 0xFF; L.f_stretch()[id] = s; L.f_len()[id] = plen+1; L.f_pos()[id] = npos;
-		L.f_w()[id] = weight; L.f_baselen()[id] = baselen;
-		return id;
+		if ( baselen > 127 || npos > 255 || plen+1 > 255 ) { over(2048); return -1; }
+		++F.np;
+		L.f_parent()[slot] = parent; L.f_stretch()[slot] = s; L.f_len()[slot] = plen+1; L.f_pos()[slot] = npos;
+		L.f_w()[slot] = weight; L.f_baselen()[slot] = baselen;
+		return slot;
 	}
-	DEV bool apqPush(uint32_t const id, uint32_t const bl, uint64_t const w)
+	DEV void forwardEnumerateLane(FEnum & F, LDSQ uint8_t * chunkrow, View const & V, int32_t const firstnode, int64_t const lmax, LDSQ id_t * hp)
 	{
-		if ( bl >= CT::blcap ) { over(2048); return false; }
-		LDSQ id_t * H = L.hbl() + 12*bl; uint32_t hn = L.hbl_n()[bl];
-		if ( hn == 12 )
+		clInit(F.C,chunkrow); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
+		if ( firstnode < 0 ) return;
 		{
-			if ( w > L.f_w()[H[0]] ) { ipop<true>(H,hn,L.f_w()); ipush<true>(H,hn,id,L.f_w()); }
-		}
-		else ipush<true>(H,hn,id,L.f_w());
-		L.hbl_n()[bl] = hn;
-		if ( bl < 64 ) apqm0 |= 1ull << bl; else apqm1 |= 1ull << (bl-64);
-		return true;
-	}
-	// path tree of traverse :4838-5041 without the score-interval part (that one depends on the reverse block)
-	DEV void forwardEnumerate(int32_t const firstnode, int64_t const lmax)
-	{
-		np = 0; nfpop = 0; fmaxw = 0; ffmask = 0;
-		{ LDSQ uint64_t * Z = reinterpret_cast<LDSQ uint64_t *>(L.hbl_n()); for ( uint32_t i = 0; i < CT::blcap/8; ++i ) Z[i] = 0; }
-		apqm0 = 0; apqm1 = 0;
-		{
-			MIt it; byFirstBegin(it,firstnode);
-			for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
+			MIt it; byFirstBegin(V,it,firstnode);
+			for ( int32_t sx = byFirstNext(V,it); sx >= 0; sx = byFirstNext(V,it) )
 			{
 				int32_t const sfo = sfFind(sx,0);
 				uint64_t const wf = sfo >= 0 ? wuF(sfo) : 0;
 				uint32_t npos, nbl; uint64_t nw;
-				int32_t const id = extendPath(-1,sx,0,0,0,0,sfo,wf,npos,nbl,nw);
-				if ( id < 0 || !apqPush(id,nbl,nw) ) return;
+				int32_t const id = extendPath(F,0,sx,0,0,0,0,sfo,wf,npos,nbl,nw);
+				if ( id < 0 ) return;
+				if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64);
 			}
 		}
-		// buckets in increasing base length; an extension is strictly longer than its parent, so it lands in a later bucket
-		while ( apqm0 | apqm1 )
+		LDSQ uint64_t const * W = L.f_w();
+		while ( F.m0 | F.m1 )
 		{
-			uint32_t const zz = apqm0 ? static_cast<uint32_t>(__builtin_ctzll(apqm0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(apqm1));
-			if ( zz < 64 ) apqm0 &= apqm0-1; else apqm1 &= apqm1-1;
-			while ( L.hbl_n()[zz] )
+			uint32_t const zz = F.m0 ? static_cast<uint32_t>(__builtin_ctzll(F.m0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(F.m1));
+			if ( zz < 64 ) F.m0 &= F.m0-1; else F.m1 &= F.m1-1;
+			uint32_t hn = 0;
+			for ( uint32_t i0 = 0; i0 < F.np; i0 += 64 )
 			{
-				LDSQ id_t * H = L.hbl() + 12*zz; uint32_t hn = L.hbl_n()[zz];
-				uint32_t const path = H[0];
-				ipop<true>(H,hn,L.f_w());
-				L.hbl_n()[zz] = hn;
-				if ( nfpop >= CT::fcap ) { over(512|0x20000); return; }
-				uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path], plen = L.f_len()[path], pbl = L.f_baselen()[path];
-				uint64_t const pw = L.f_w()[path];
+				// members of the bucket among entries i0..i0+63 (loads only, so that they overlap), then the pushes in order
+				uint64_t mem = 0;
+				uint32_t const ie = (F.np-i0 < 64) ? (F.np-i0) : 64u;
+				for ( uint32_t i = 0; i < ie; ++i ) mem |= static_cast<uint64_t>(L.f_baselen()[clSlot<FCH>(F.C,i0+i)] == zz) << i;
+				while ( mem )
+				{
+					uint32_t const i = __builtin_ctzll(mem); mem &= mem-1;
+					uint32_t const e = clSlot<FCH>(F.C,i0+i);
+					if ( hn == 12 )
+					{
+						if ( W[e] > W[hp[0]] ) { ipop<true>(hp,hn,W); ipush<true>(hp,hn,static_cast<id_t>(e),W); }
+					}
+					else ipush<true>(hp,hn,static_cast<id_t>(e),W);
+				}
+			}
+			while ( hn )
+			{
+				uint32_t const path = hp[0];
+				ipop<true>(hp,hn,W);
+				uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path], plen = L.f_len()[path], pbl = zz;
+				uint64_t const pw = W[path];
 				uint32_t const lastn = L.slast()[ps];
 				{
 					// what the score intervals need of this path: junction k-mer, candidate length, weight without the junction node
 					int32_t const psfo = sfFind(ps,ppos - (L.sslen()[ps]-1));
 					uint32_t const pfront = L.nv()[lastn];
-					L.fp_front()[nfpop] = pfront; L.fp_cl()[nfpop] = ppos; ffmask |= 1ull << (pfront & 63);
-					L.fp_adj()[nfpop] = psfo >= 0 ? (pw - wlF(psfo)) : pw;
-					if ( pw > fmaxw ) fmaxw = pw;
+					uint32_t const o = clSlot<FCH>(F.C,F.nfpop);
+					L.fp_id()[o] = path; L.fp_front()[o] = pfront; L.fp_cl()[o] = ppos; F.ffm |= 1ull << (pfront & 63);
+					L.fp_adj()[o] = psfo >= 0 ? (pw - wlF(psfo)) : pw;
+					if ( pw > F.fmaxw ) F.fmaxw = pw;
+					++F.nfpop;
 				}
-				L.fpop()[nfpop++] = path;
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 				{
-					MIt it; byFirstBegin(it,lastn);
-					for ( int32_t sx = byFirstNext(it); sx >= 0; sx = byFirstNext(it) )
+					MIt it; byFirstBegin(V,it,lastn);
+					for ( int32_t sx = byFirstNext(V,it); sx >= 0; sx = byFirstNext(V,it) )
 					{
 						uint32_t const s = sx;
 						int32_t const sfo = sfFind(s,ppos);
@@ -1362,31 +1557,41 @@ struct FastEngine
 						if ( eweight >= FW_THRES_01 )
 						{
 							uint32_t npos, nbl; uint64_t nw;
-							int32_t const ep = extendPath(path,s,ppos,plen,pw,pbl,sfo,eweight,npos,nbl,nw);
+							int32_t const ep = extendPath(F,path,s,ppos,plen,pw,pbl,sfo,eweight,npos,nbl,nw);
 							if ( ep < 0 ) return;
 							if ( nw >= FW_THRES_01 && static_cast<int64_t>(npos) + k <= lmax )
 							{
-								if ( !apqPush(ep,nbl,nw) ) return;
+								if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64);
 							}
-							else --np;
+							else --F.np;
 						}
 					}
 				}
 			}
 		}
 	}
-	// (stats hook)
-	DEV void statF() { FSTAT_MX(13,np); FSTAT_MX(14,nfpop); FSTAT_ADD(15,np); FSTAT_ADD(16,1); }
-	DEV void statR() { FSTAT_MX(17,nrp); FSTAT_MX(18,narp); FSTAT_ADD(19,nrp); FSTAT_ADD(20,1); }
+	// summary of a finished forward tree in slot fi of the per-candidate tables; one bit per scan target
+	DEV void forwardTreeFinish(FEnum const & F, uint32_t const fi, int32_t const firstnode, int64_t const lmax)
+	{
+		uint64_t m = firstnode >= 0 ? (1ull << (firstnode & 63)) : 0ull;
+		for ( uint32_t i = 0; i < F.nfpop; ++i )
+		{
+			uint32_t const path = L.fp_id()[clSlot<FCH>(F.C,i)];
+			uint32_t const pbl = L.f_baselen()[path];
+			if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) ) m |= 1ull << (L.slast()[L.f_stretch()[path]] & 63);
+		}
+		L.fnp()[fi] = F.nfpop; L.ffm()[fi] = F.ffm; L.ftm()[fi] = m; L.fmx()[fi] = F.fmaxw;
+	}
+	DEV void forwardTreeLoad(ChunkList<FNW> & C, uint32_t const fi) const { C.ids = L.fchb() + 8*FNW*fi; C.n = 8*FNW; }
 	// scans of the forward enumeration look for stretches whose first node equals a target; splitting `par` at `ln`
 	// changes the answer only for targets par.first (parent vs first piece) and ln (second piece)
-	DEV bool forwardUnaffected(int32_t const firstnode, uint32_t const par, uint32_t const ln, int64_t const lmax) const
+	DEV bool forwardUnaffected(ChunkList<FNW> const & C, uint32_t const nfpop, int32_t const firstnode, uint32_t const par, uint32_t const ln, int64_t const lmax) const
 	{
 		uint32_t const pfirst = L.sfirst()[par];
 		if ( static_cast<uint32_t>(firstnode) == pfirst || static_cast<uint32_t>(firstnode) == ln ) return false;
 		for ( uint32_t i = 0; i < nfpop; ++i )
 		{
-			uint32_t const path = L.fpop()[i];
+			uint32_t const path = L.fp_id()[clSlot<FCH>(C,i)];
 			uint32_t const pbl = L.f_baselen()[path];
 			if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 			{
@@ -1397,22 +1602,22 @@ struct FastEngine
 		return true;
 	}
 
-	// ================= combining a forward tree with a reverse block (score intervals + pair loop) =================
+	// ================= combining a forward tree with a reverse block (score intervals) =================
 	uint32_t cfree;   // free candidate sequence slots
 	// A candidate is kept as its sequence of view stretches (forward chain, then reverse chain).  Within one view two
 	// candidates spell the same string iff their sequences are equal (nodes are distinct k-mers and every edge lies on
 	// exactly one stretch of the view), so the duplicate test of traverse (:5098-5110) compares sequences; strings are
 	// decoded once, for the final candidates (decodePathPair :4267-4300).
-	DEV uint32_t buildSeq(uint32_t const path, uint32_t const base, uint32_t const rp, LDSQ uint8_t * dst, uint32_t & conslen)
+	DEV uint32_t buildSeq(uint32_t const path, uint32_t const rp, LDSQ uint8_t * dst, uint32_t & conslen)
 	{
-		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[base+rp];
+		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[rp];
 		if ( nf + nr > FSEQCAP ) { over(4096); return ~0u; }
-		conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[base+rp];
+		conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[rp];
 		if ( conslen > MAXCONS ) { over(4096); return ~0u; }
 		uint32_t i = nf;
 		for ( uint32_t q = path; i; q = L.f_parent()[q] ) dst[--i] = L.f_stretch()[q];
 		i = nf;
-		for ( uint32_t q = rp; L.rc_len()[base+q]; q = L.rc_parent()[base+q] ) dst[i++] = L.rc_stretch()[base+q];
+		for ( uint32_t q = rp; L.rc_len()[q]; q = L.rc_parent()[q] ) dst[i++] = L.rc_stretch()[q];
 		return nf+nr;
 	}
 	DEV uint32_t decodeSeq(LDSQ uint8_t const * seq, uint32_t const n, LDSQ uint8_t * dst) const
@@ -1428,81 +1633,190 @@ struct FastEngine
 		}
 		return o;
 	}
-	DEV void combinePair(uint32_t const base, uint32_t const nacc2, uint64_t const rfm, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath)
+	// matching interval [sub,sup) of popped path pi (junction k-mer `front`, candidate length candlen) in the sorted
+	// reverse block and its heaviest entry (:4864-4950)
+	DEV bool scoreInterval(uint32_t const sbase, uint32_t const nacc2, uint32_t const front, int64_t const candlen, int64_t const lmin, int64_t const lmax,
+		uint32_t & sub, uint32_t & sup, uint32_t & mi) const
+	{
+		uint32_t lo = 0, hi = nacc2;
+		while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.rc_front()[sbase+mid] < front ) lo = mid+1; else hi = mid; }
+		uint32_t e = lo;
+		while ( e < nacc2 && L.rc_front()[sbase+e] == front ) ++e;
+		if ( e == lo ) return false;
+		int64_t bllo = lmin + static_cast<int64_t>(k) - candlen; if ( bllo < 0 ) bllo = 0;
+		int64_t blhi = lmax + static_cast<int64_t>(k) - candlen; if ( blhi < 0 ) blhi = 0;
+		uint32_t const bllo16 = static_cast<uint16_t>(bllo), blhi16 = static_cast<uint16_t>(blhi);
+		sub = lo;
+		while ( sub < e && L.rc_sbl()[sbase+sub] < bllo16 ) ++sub;
+		sup = sub;
+		while ( sup < e && !(blhi16 < L.rc_sbl()[sbase+sup]) ) ++sup;
+		if ( sub == sup ) return false;
+		mi = sub; uint32_t mr = L.rc_arw()[sbase+sub];
+		for ( uint32_t i = sub+1; i < sup; ++i ) { uint32_t const r = L.rc_arw()[sbase+i]; if ( r > mr ) { mi = i; mr = r; } }
+		return true;
+	}
+	// next lighter entry of a score interval (nextScoreInterval :3513-3534)
+	DEV bool scoreNext(uint32_t const sbase, uint32_t const left, uint32_t const right, uint32_t const current, uint32_t & bi) const
+	{
+		uint32_t const v = L.rc_arw()[sbase+current];
+		if ( !v ) return false;
+		bool found = false; uint32_t bu = 0;
+		for ( uint32_t i = left; i < right; ++i )
+		{
+			uint32_t const r = L.rc_arw()[sbase+i];
+			if ( r <= v-1 && (!found || r > bu) ) { found = true; bu = r; bi = i; }
+		}
+		return found;
+	}
+	// one candidate offered to the candidate heap CDH (:5049-5092, including the shrink quirk); false: stop (error)
+	DEV bool offerCandidate(uint64_t const weight, uint32_t const path, uint32_t const rp, uint32_t & pn)
+	{
+		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
+		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
+		uint32_t conslen = 0;
+		uint32_t const n = buildSeq(path,rp,cur,conslen);
+		if ( n == ~0u ) return false;
+		if ( n == pn )
+		{
+			bool eq = true;
+			for ( uint32_t i = 0; i < n; ++i ) if ( prev[i] != cur[i] ) { eq = false; break; }
+			if ( eq ) return true;
+		}
+		uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
+		LDSQ uint8_t * dst = L.cseq() + FSEQCAP*slot;
+		for ( uint32_t i = 0; i < n; ++i ) { uint8_t const c = cur[i]; prev[i] = c; dst[i] = c; }
+		pn = n;
+		FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
+		spush<FCC,true>(L.cdh(),ncdh,cc);
+		return true;
+	}
+	// serial form (lane 0): score intervals in the shared heap L.siq, candidates offered as they are popped
+	// skip: that many pops have been offered already (recorded sequence of the lane form), pn: sequence length of the last
+	// candidate kept from them
+	DEV void combinePair(ChunkList<FNW> const & FC, uint32_t const nfpop, uint32_t const sbase, uint32_t const nacc2, uint64_t const rfm, int64_t const lmin, int64_t const lmax, uint32_t const maxfullpath,
+		uint32_t const skip = 0, uint32_t pn = ~0u)
 	{
 		nsiq = 0;
 		for ( uint32_t pi = 0; pi < nfpop; ++pi )
 		{
-			uint32_t const front = L.fp_front()[pi];
+			uint32_t const o = clSlot<FCH>(FC,pi);
+			uint32_t const front = L.fp_front()[o];
 			if ( !((rfm >> (front & 63)) & 1) ) continue;   // no reverse path starts at this k-mer
-			int64_t const candlen = static_cast<int64_t>(L.fp_cl()[pi]) + k;
-			uint32_t lo = 0, hi = nacc2;
-			while ( lo < hi ) { uint32_t const mid = (lo+hi)>>1; if ( L.rc_front()[base+mid] < front ) lo = mid+1; else hi = mid; }
-			uint32_t e = lo;
-			while ( e < nacc2 && L.rc_front()[base+e] == front ) ++e;
-			if ( e == lo ) continue;
-			int64_t bllo = lmin + static_cast<int64_t>(k) - candlen; if ( bllo < 0 ) bllo = 0;
-			int64_t blhi = lmax + static_cast<int64_t>(k) - candlen; if ( blhi < 0 ) blhi = 0;
-			uint32_t const bllo16 = static_cast<uint16_t>(bllo), blhi16 = static_cast<uint16_t>(blhi);
-			uint32_t sub = lo;
-			while ( sub < e && L.rc_sbl()[base+sub] < bllo16 ) ++sub;
-			uint32_t sup = sub;
-			while ( sup < e && !(blhi16 < L.rc_sbl()[base+sup]) ) ++sup;
-			if ( sub != sup )
+			uint32_t sub, sup, mi;
+			if ( scoreInterval(sbase,nacc2,front,static_cast<int64_t>(L.fp_cl()[o]) + k,lmin,lmax,sub,sup,mi) )
 			{
-				uint32_t mi = sub, mr = L.rc_arw()[base+sub];
-				for ( uint32_t i = sub+1; i < sup; ++i ) { uint32_t const r = L.rc_arw()[base+i]; if ( r > mr ) { mi = i; mr = r; } }
 				if ( nsiq >= CT::siqcap ) { over(512|0x40000); return; }
-				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = pi; si.w = L.fp_adj()[pi] + L.rc_w()[base+L.rc_ord()[base+mi]];
+				FSI si; si.left = sub; si.right = sup; si.current = mi; si.path = pi; si.w = L.fp_adj()[o] + L.rc_w()[L.rc_ord()[sbase+mi]];
 				spush<FSI,false>(L.siq(),nsiq,si);
 			}
 		}
-		FSTAT_MX(21,nsiq); FSTAT_ADD(22,1);
-		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
-		uint32_t pn = ~0u;
 		for ( uint32_t numfullpath = 0; nsiq && numfullpath < maxfullpath; ++numfullpath )
 		{
 			FSI const si = ldget(L.siq());
 			// the score intervals leave the heap in non increasing weight order and everything still inside is not
 			// heavier, so once the candidate heap is full and its top cannot be beaten, nothing of this pair can enter
-			if ( ncdh == 16 && si.w <= L.cdh()[0].w ) break;
+			if ( numfullpath >= skip && ncdh == 16 && si.w <= L.cdh()[0].w ) break;
 			spop<FSI,false>(L.siq(),nsiq);
+			uint32_t bi;
+			if ( scoreNext(sbase,si.left,si.right,si.current,bi) )
 			{
-				uint32_t const v = L.rc_arw()[base+si.current];
-				if ( v )
+				FSI sic = si; sic.current = bi; sic.w = L.fp_adj()[clSlot<FCH>(FC,si.path)] + L.rc_w()[L.rc_ord()[sbase+bi]];
+				if ( nsiq >= CT::siqcap ) { over(512|0x40000); return; }
+				spush<FSI,false>(L.siq(),nsiq,sic);
+			}
+			if ( numfullpath < skip ) continue;
+			if ( !offerCandidate(si.w,L.fp_id()[clSlot<FCH>(FC,si.path)],L.rc_ord()[sbase+si.current],pn) ) return;
+		}
+	}
+	// lane form: the same pops without the candidate heap; the (path, entry) sequence goes to `out` (at most 16 pairs of
+	// ids) and is offered to the candidate heap later, in pair order (replayPair).  The lane's heap holds the intervals
+	// as (path, current, left, right); weights are recomputed from the tables.  Returns the count or 0xFF if the heap
+	// is too small (the pair is then combined serially).
+	struct PSI { id_t path, current, left, right; };
+	enum { PSIQ = 20 };
+	DEV uint64_t psiW(PSI const & e, ChunkList<FNW> const & FC, uint32_t const sbase) const { return L.fp_adj()[clSlot<FCH>(FC,e.path)] + L.rc_w()[L.rc_ord()[sbase+e.current]]; }
+	DEV uint32_t combineLane(ChunkList<FNW> const & FC, uint32_t const nfpop, uint32_t const sbase, uint32_t const nacc2, uint64_t const rfm, int64_t const lmin, int64_t const lmax,
+		uint32_t const maxfullpath, LDSQ PSI * H, LDSQ id_t * out, bool const prune, uint64_t const T0)
+	{
+		uint32_t n = 0;
+		for ( uint32_t pi = 0; pi < nfpop; ++pi )
+		{
+			uint32_t const o = clSlot<FCH>(FC,pi);
+			uint32_t const front = L.fp_front()[o];
+			if ( !((rfm >> (front & 63)) & 1) ) continue;
+			uint32_t sub, sup, mi;
+			if ( scoreInterval(sbase,nacc2,front,static_cast<int64_t>(L.fp_cl()[o]) + k,lmin,lmax,sub,sup,mi) )
+			{
+				if ( n >= PSIQ || sup > 255 && sizeof(id_t) == 1 ) return 0xFF;
+				PSI e; e.path = pi; e.current = mi; e.left = sub; e.right = sup;
+				// FiniteSizeHeap push (max heap on the weight)
+				uint32_t i = n++; H[i] = e;
+				uint64_t const we = psiW(e,FC,sbase);
+				while ( i )
 				{
-					bool found = false; uint32_t bu = 0, bi = 0;
-					for ( uint32_t i = si.left; i < si.right; ++i )
-					{
-						uint32_t const r = L.rc_arw()[base+i];
-						if ( r <= v-1 && (!found || r > bu) ) { found = true; bu = r; bi = i; }
-					}
-					if ( found )
-					{
-						FSI sic = si; sic.current = bi; sic.w = L.fp_adj()[si.path] + L.rc_w()[base+L.rc_ord()[base+bi]];
-						if ( nsiq >= CT::siqcap ) { over(512|0x40000); return; }
-						spush<FSI,false>(L.siq(),nsiq,sic);
-					}
+					uint32_t const p = (i-1)>>1;
+					PSI const ep = H[p];
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
+					else break;
 				}
 			}
-			uint64_t const weight = si.w;
-			if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
-			uint32_t conslen = 0;
-			uint32_t const n = buildSeq(L.fpop()[si.path],base,L.rc_ord()[base+si.current],cur,conslen);
-			if ( n == ~0u ) return;
-			if ( n == pn )
-			{
-				bool eq = true;
-				for ( uint32_t i = 0; i < n; ++i ) if ( prev[i] != cur[i] ) { eq = false; break; }
-				if ( eq ) continue;
-			}
-			uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
-			LDSQ uint8_t * dst = L.cseq() + FSEQCAP*slot;
-			for ( uint32_t i = 0; i < n; ++i ) { uint8_t const c = cur[i]; prev[i] = c; dst[i] = c; }
-			pn = n;
-			FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
-			spush<FCC,true>(L.cdh(),ncdh,cc);
 		}
+		uint32_t cnt = 0;
+		for ( uint32_t numfullpath = 0; n && numfullpath < maxfullpath; ++numfullpath )
+		{
+			PSI const top = H[0];
+			// the candidate heap was full with lightest weight T0 when the round began: as long as that still holds when
+			// the pair is offered, nothing from here on can enter (replayRound checks it and continues serially otherwise)
+			if ( prune && psiW(top,FC,sbase) <= T0 ) return cnt | 0x20;
+			// pop
+			{
+				--n; PSI const last = H[n]; H[0] = last;
+				uint32_t i = 0, r;
+				while ( (r = 2*i+2) < n )
+				{
+					uint32_t const m = psiW(H[r-1],FC,sbase) > psiW(H[r],FC,sbase) ? (r-1) : r;
+					PSI const em = H[m], ei = H[i];
+					if ( psiW(ei,FC,sbase) > psiW(em,FC,sbase) ) break;
+					H[i] = em; H[m] = ei; i = m;
+				}
+				if ( r >= n )
+				{
+					uint32_t const l = 2*i+1;
+					if ( l < n ) { PSI const el = H[l], ei = H[i]; if ( !(psiW(ei,FC,sbase) > psiW(el,FC,sbase)) ) { H[i] = el; H[l] = ei; } }
+				}
+			}
+			uint32_t bi;
+			if ( scoreNext(sbase,top.left,top.right,top.current,bi) )
+			{
+				PSI e = top; e.current = bi;
+				uint32_t i = n++; H[i] = e;
+				uint64_t const we = psiW(e,FC,sbase);
+				while ( i )
+				{
+					uint32_t const p = (i-1)>>1;
+					PSI const ep = H[p];
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
+					else break;
+				}
+			}
+			out[2*cnt] = top.path; out[2*cnt+1] = top.current; ++cnt;
+		}
+		return cnt;
+	}
+	// offers the recorded sequence of a pair to the candidate heap, exactly as combinePair would have
+	// returns true if the sequence was used up (false: ended at an entry that cannot enter the full heap, or error)
+	DEV bool replayPair(ChunkList<FNW> const & FC, uint32_t const sbase, LDSQ id_t const * out, uint32_t const cnt, uint32_t & pn)
+	{
+		pn = ~0u;
+		for ( uint32_t e = 0; e < cnt; ++e )
+		{
+			uint32_t const o = clSlot<FCH>(FC,out[2*e]);
+			uint32_t const rp = L.rc_ord()[sbase+out[2*e+1]];
+			uint64_t const w = L.fp_adj()[o] + L.rc_w()[rp];
+			if ( ncdh == 16 && w <= L.cdh()[0].w ) return false;
+			if ( !offerCandidate(w,L.fp_id()[o],rp,pn) ) return false;
+		}
+		return true;
 	}
 
 	DEV uint32_t myersDistance(uint32_t const j, LDSQ uint8_t const * text, uint32_t const n) const
@@ -1545,114 +1859,148 @@ struct FastEngine
 	}
 
 	// ================= traverse (:4496-5170) for one activation state =================
-	// the pair loop runs on lane 0; it comes back to the wavefront only for the feasibility of a temporary middle
-	// piece (a stretch split at both its first and its last candidate)
-	uint32_t pl_fi, pl_li, pl_midA, pl_midB, pl_midpar; bool pl_midready; uint64_t ftmask;
-	uint64_t ffmask, rfmcur;   // front k-mer bit sets (value mod 64) of the current forward tree / of the reverse block just enumerated
+	// (first, last) candidate pairs: the reverse blocks of all last k-mers and the forward trees of a batch of first
+	// k-mers are enumerated with one lane each, the score intervals of NPL pairs at a time are popped with one lane per
+	// pair into recorded (path, entry) sequences, and lane 0 offers those to the candidate heap in the reference's pair
+	// order.  A pair whose cached enumerations may be touched by the other k-mer's split (rare) is enumerated on its
+	// exact stretch set by lane 0 at its place in that order.
+	enum { NPL = 32, RPSTL = 32, PM_SKIP = 0xF0, PM_SERIAL = 0xF1, PM_EXACT = 0xE0 };
+	uint32_t pl_midA, pl_midB, pl_midpar; bool pl_midready;
+	uint32_t rstop;                      // sorted reverse entries used by the cached blocks
+	uint64_t roundT0;                    // lightest weight of the (full) candidate heap when the current round of pairs began
+	uint32_t nsiq, ncdh, nacc;
 
-	// returns 0 = all pairs done, 1 = needs the middle piece [pl_midA,pl_midB] of stretch pl_midpar
-	DEV uint32_t pairLoop(int64_t const lmin, int64_t const lmax)
+	DEV void viewOfLast(View & V, uint32_t const li) const
 	{
-		LDSQ uint64_t * RMAX = L.rmaxw();   // per last k-mer: heaviest accepted weight of its cached reverse block
-		for ( ; pl_fi < nF; ++pl_fi, pl_li = 0 )
+		viewClear(V);
+		uint32_t const sl = L.parL()[li];
+		if ( sl != FNOPAR ) { viewRemove(V,sl); viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieL()[li]+1); }
+	}
+	DEV void viewOfFirst(View & V, uint32_t const fi) const
+	{
+		viewClear(V);
+		uint32_t const sf = L.parF()[fi];
+		if ( sf != FNOPAR ) { viewRemove(V,sf); viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
+	}
+	// are the cached enumerations of (fi, li) valid for the pair?  bit 0: reverse block, bit 1: forward tree, bit 2: both
+	// candidates split the same stretch
+	DEV uint32_t classifyPair(uint32_t const fi, uint32_t const li, int64_t const lmax) const
+	{
+		uint32_t const sf = L.parF()[fi], sl = L.parL()[li];
+		if ( sf != FNOPAR && sf == sl ) return 4;
+		int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
+		int32_t const lastnode = L.lnode()[li] == 0xFFFF ? -1 : L.lnode()[li];
+		bool rcached, fcached;
+		if ( sf == FNOPAR ) rcached = true;
+		else
 		{
-			uint32_t const fi = pl_fi;
-			int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
-			uint32_t const sf = L.parF()[fi];
-			uint32_t const fnodeFi = L.fnode()[fi], sfLast = sf != FNOPAR ? L.slast()[sf] : 0u;
-			for ( ; pl_li < nL; ++pl_li )
+			uint64_t const tm = L.rtmask()[li];
+			uint32_t const fn = L.fnode()[fi];
+			rcached = !((tm >> (L.slast()[sf]&63))&1) && !((tm >> (fn&63))&1);
+			if ( !rcached ) rcached = reverseUnaffected(L.rbase()[li],L.rn()[li],lastnode,sf,fn,lmax);
+		}
+		if ( sl == FNOPAR ) fcached = true;
+		else
+		{
+			uint64_t const tm = L.ftm()[fi];
+			fcached = !((tm >> (L.sfirst()[sl]&63))&1) && !((tm >> (L.lnode()[li]&63))&1);
+			if ( !fcached ) { ChunkList<FNW> FC; forwardTreeLoad(FC,fi); fcached = forwardUnaffected(FC,L.fnp()[fi],firstnode,sl,L.lnode()[li],lmax); }
+		}
+		return (rcached ? 1u : 0u) | (fcached ? 2u : 0u);
+	}
+	// lane 0: pairs [q, n) of the round starting at pair p0 of the batch that starts at candidate fstart, in order.
+	// returns 0 when the round is done, 1 when pair q needs the middle piece [pl_midA,pl_midB] of stretch pl_midpar,
+	// 2 when the forward tree of the exact pair q found no pool space next to the trees of the batch (alone: the batch
+	// holds the tree of this first k-mer only)
+	DEV uint32_t replayRound(uint32_t & q, uint32_t const n, uint32_t const p0, uint32_t const fstart, int64_t const lmin, int64_t const lmax, bool const alone)
+	{
+		for ( ; q < n; ++q )
+		{
+			uint32_t const mode = L.poutn()[q];
+			if ( mode == PM_SKIP ) continue;
+			uint32_t const p = p0+q;
+			uint32_t const fi = fstart + p/nL, li = p%nL;
+			if ( mode < 0x40 || mode == PM_SERIAL )
 			{
-				uint32_t const li = pl_li;
-				uint32_t const lastk = L.lkmer()[li];
-				int32_t const lastnode = L.lnode()[li] == 0xFFFF ? -1 : L.lnode()[li];
-				uint32_t const sl = L.parL()[li];
-				bool const same = (sf != FNOPAR && sf == sl);
-				bool rcached = false, fcached = false;
-				if ( !same )
+				// no candidate of this pair can beat the lightest kept candidate: score <= path weight + reverse weight
+				if ( ncdh == 16 && L.fmx()[fi] + L.rmaxw()[li] <= L.cdh()[0].w ) continue;
+				ChunkList<FNW> FC; forwardTreeLoad(FC,fi);
+				if ( mode < 0x40 )
 				{
-					// reverse block, cached per last k-mer (computed on the view split at `last` only)
-					if ( ! L.rvalid()[li] )
-					{
-						uint64_t const tq0 = pclock();
-						viewClear();
-						if ( sl != FNOPAR ) { viewRemove(sl); viewAdd(L.pieL()[li]); viewAdd(L.pieL()[li]+1); }
-						rb = rctop;
-						reverseEnumerate(lastk,lastnode,lmax);
-						statR();
-						if ( flags ) return 0;
-						L.rbase()[li] = rb; L.rn()[li] = narp; L.rvalid()[li] = 1; RMAX[li] = rmaxw;
-						L.rtmask()[li] = reverseTargetMask(lastnode,lmax); L.rfmask()[li] = rfmcur;
-						rctop = rb + nrp;
-						pcount(22,pclock()-tq0); pcount(25,1);
-					}
-					if ( sf == FNOPAR ) rcached = true;
-					else
-					{
-						uint64_t const tm = L.rtmask()[li];
-						rcached = !((tm >> (sfLast&63))&1) && !((tm >> (fnodeFi&63))&1);
-						if ( !rcached ) rcached = reverseUnaffected(L.rbase()[li],L.rn()[li],lastnode,sf,fnodeFi,lmax);
-					}
-					// forward tree, cached for the current first k-mer (computed on the view split at `first` only)
-					if ( fcur_fi != static_cast<int32_t>(fi) || fcur_li != -1 )
-					{
-						uint64_t const tq0 = pclock();
-						viewClear();
-						if ( sf != FNOPAR ) { viewRemove(sf); viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
-						forwardEnumerate(firstnode,lmax);
-						statF();
-						if ( flags ) return 0;
-						fcur_fi = fi; fcur_li = -1;
-						ftmask = forwardTargetMask(firstnode,lmax);
-						pcount(23,pclock()-tq0); pcount(26,1);
-					}
-					if ( sl == FNOPAR ) fcached = true;
-					else
-					{
-						fcached = !((ftmask >> (L.sfirst()[sl]&63))&1) && !((ftmask >> (L.lnode()[li]&63))&1);
-						if ( !fcached ) fcached = forwardUnaffected(firstnode,sl,L.lnode()[li],lmax);
-					}
-					pcount(27,1);
-					// no candidate of this pair can beat the lightest kept candidate: score <= path weight + reverse weight
-					if ( rcached && fcached && ncdh == 16 && fmaxw + RMAX[li] <= L.cdh()[0].w ) { pcount(28,1); continue; }
+					uint32_t const cnt = mode & 0x1F; uint32_t pn;
+					bool const used = replayPair(FC,L.rbase()[li],L.pout() + 32*q,cnt,pn);
+					if ( flags ) return 0;
+					// a sequence cut at weight T0 is complete only while the candidate heap is full with a top of at least T0
+					if ( used && (mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0) )
+						pcount(21,1);
+					if ( used && (mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0) )
+						combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16,cnt,pn);
 				}
-				uint32_t base, nacc2;
-				if ( !rcached || !fcached )
-				{
-					// exact stretch set of the pair (split at first, then at last)
-					viewClear();
-					if ( same )
-					{
-						uint32_t const pf = L.posF()[fi], pl = L.posL()[li];
-						viewRemove(sf);
-						if ( pf == pl ) { viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
-						else
-						{
-							if ( !pl_midready )
-							{
-								pl_midpar = sf; pl_midA = pf < pl ? pf : pl; pl_midB = pf < pl ? pl : pf;
-								return 1;
-							}
-							pl_midready = false;
-							if ( pf < pl ) { viewAdd(L.pieF()[fi]); viewAdd(L.pieL()[li]+1); } else { viewAdd(L.pieL()[li]); viewAdd(L.pieF()[fi]+1); }
-							viewAdd(npool-1);   // the middle piece just appended to the pool
-						}
-					}
-					else
-					{
-						if ( sf != FNOPAR ) { viewRemove(sf); viewAdd(L.pieF()[fi]); viewAdd(L.pieF()[fi]+1); }
-						if ( sl != FNOPAR ) { viewRemove(sl); viewAdd(L.pieL()[li]); viewAdd(L.pieL()[li]+1); }
-					}
-					if ( !rcached ) { rb = rctop; reverseEnumerate(lastk,lastnode,lmax); if ( flags ) return 0; }
-					if ( !fcached ) { forwardEnumerate(firstnode,lmax); if ( flags ) return 0; fcur_fi = fi; fcur_li = li; }
-				}
-				uint64_t rfm;
-				if ( rcached ) { base = L.rbase()[li]; nacc2 = L.rn()[li]; rfm = L.rfmask()[li]; } else { base = rb; nacc2 = narp; rfm = rfmcur; }
-
-				if ( (rfm & ffmask) == 0 ) { pcount(28,1); continue; }   // the forward tree and the reverse block share no junction k-mer
-				{ uint64_t const tq0 = pclock(); combinePair(base,nacc2,rfm,lmin,lmax,16); pcount(24,pclock()-tq0); }
-				if ( !rcached || !fcached ) pcount(21,1);
+				else { pcount(23,1); combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16); }
 				if ( flags ) return 0;
+				continue;
 			}
+			// exact stretch set of the pair (split at first, then at last)
+			pcount(22,1);
+			bool const rcached = mode & 1, fcached = mode & 2, same = mode & 4;
+			uint32_t const sf = L.parF()[fi], sl = L.parL()[li];
+			int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
+			int32_t const lastnode = L.lnode()[li] == 0xFFFF ? -1 : L.lnode()[li];
+			View V; viewClear(V);
+			if ( same )
+			{
+				uint32_t const pf = L.posF()[fi], pl = L.posL()[li];
+				viewRemove(V,sf);
+				if ( pf == pl ) { viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
+				else
+				{
+					if ( !pl_midready )
+					{
+						pl_midpar = sf; pl_midA = pf < pl ? pf : pl; pl_midB = pf < pl ? pl : pf;
+						return 1;
+					}
+					pl_midready = false;
+					if ( pf < pl ) { viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieL()[li]+1); } else { viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieF()[fi]+1); }
+					viewAdd(V,npool-1);   // the middle piece just appended to the pool
+				}
+			}
+			else
+			{
+				if ( sf != FNOPAR ) { viewRemove(V,sf); viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
+				if ( sl != FNOPAR ) { viewRemove(V,sl); viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieL()[li]+1); }
+			}
+			uint32_t const rsave = L.ctr()[0], fsave = L.ctr()[1];
+			uint32_t sbase = L.rbase()[li], nacc2 = L.rn()[li]; uint64_t rfm = L.rfmask()[li];
+			if ( !rcached )
+			{
+				REnum RX;
+				reverseEnumerateLane(RX,L.rchx(),V,L.lkmer()[li],lastnode,lmax,reinterpret_cast<LDSQ id_t *>(L.lscr()),FastLds<CT>::lscrbytes/sizeof(id_t));
+				if ( flags ) return 0;
+				if ( rstop + RX.narp > CT::rccap ) { over(512|0x4000); return 0; }
+				reverseBlockCopy(RX,rstop);
+				reverseBlockFinish(RX,rstop,FNC,lastnode,lmax);
+				if ( flags ) return 0;
+				sbase = rstop; nacc2 = RX.narp; rfm = L.rfmask()[FNC];
+			}
+			ChunkList<FNW> FC; uint32_t nfp; uint64_t ffmx;
+			if ( !fcached )
+			{
+				FEnum FX;
+				forwardEnumerateLane(FX,L.fchb() + 8*FNW*FNC,V,firstnode,lmax,reinterpret_cast<LDSQ id_t *>(L.lscr()));
+				if ( flags == (512|0x10000) && FX.np < 8*FNW*FCH && !alone )
+				{
+					// the trees of the batch leave no room for this one: the batch is cut here and continues with the tree
+					// of this first k-mer alone in the pool
+					flags = 0; L.ctr()[0] = rsave; L.ctr()[1] = fsave;
+					return 2;
+				}
+				if ( flags ) return 0;
+				FC = FX.C; nfp = FX.nfpop; ffmx = FX.ffm;
+			}
+			else { forwardTreeLoad(FC,fi); nfp = L.fnp()[fi]; ffmx = L.ffm()[fi]; }
+			if ( rfm & ffmx ) combinePair(FC,nfp,sbase,nacc2,rfm,lmin,lmax,16);   // else: no junction k-mer in common
+			L.ctr()[0] = rsave; L.ctr()[1] = fsave;
+			if ( flags ) return 0;
 		}
 		return 0;
 	}
@@ -1660,37 +2008,160 @@ struct FastEngine
 	DEV bool traverse(int64_t const lmin, int64_t const lmax)
 	{
 		PROF_T0
-		cfree = 0xFFFFu; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; rctop = 0; fcur_fi = -1; fcur_li = -1;
+		cfree = 0xFFFFu; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; nsiq = 0;
 		computeBaseStretches();
 		flags = wv_or(flags); if ( flags ) return false;
 		PROF(*this,8)
 		findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
 		loadTab();
-		computeStretchFeas<false>(0,npool);
+		computeStretchFeasLanes(0,npool);
 		flags = wv_or(flags); if ( flags ) return false;
-		for ( uint32_t i = lane; i < FNC+1; i += WSZ ) L.rvalid()[i] = 0;
-		wv_sync();
-
 		PROF(*this,9)
-		pl_fi = 0; pl_li = 0; pl_midready = false;
-		while ( true )
+
+		// ---- reverse blocks of all last k-mer candidates, lane = candidate ----
+		if ( lane == 0 ) { L.ctr()[0] = 0; L.ctr()[1] = 0; }
+		wv_sync();
 		{
-			uint32_t req = 0;
-			if ( lane == 0 ) req = pairLoop(lmin,lmax);
+			uint32_t sb = 0;
+			for ( uint32_t c = 0; c < nL; c += WSZ )
+			{
+				uint32_t const li = c + lane;
+				bool const ract = li < nL;
+				REnum R; clInit(R.C,L.rchb() + 8*RNW*lane); R.nrp = 0; R.narp = 0; R.lastk = 0;
+				int32_t lastnode = -1;
+				View V; viewClear(V);
+				bool rover = false;
+				if ( ract )
+				{
+					viewOfLast(V,li);
+					lastnode = L.lnode()[li] == 0xFFFF ? -1 : L.lnode()[li];
+					reverseEnumerateLane(R,L.rchb() + 8*RNW*lane,V,L.lkmer()[li],lastnode,lmax,reinterpret_cast<LDSQ id_t *>(L.lscr()) + RPSTL*lane,RPSTL);
+					if ( flags == (512|0x8000) ) { rover = true; flags = 0; }
+				}
+				// an enumeration whose heap of pending paths outgrew the lane's share of the scratch runs again with all of it
+				for ( uint64_t ro = wv_ballot(rover); ro; ro &= ro-1 )
+				{
+					wv_sync();
+					if ( lane == static_cast<int>(__builtin_ctzll(ro)) )
+						reverseEnumerateLane(R,L.rchb() + 8*RNW*lane,V,L.lkmer()[li],lastnode,lmax,reinterpret_cast<LDSQ id_t *>(L.lscr()),FastLds<CT>::lscrbytes/sizeof(id_t));
+				}
+				wv_sync();
+				flags = wv_or(flags); if ( flags ) return false;
+				uint32_t tot; uint32_t const sbase = sb + wv_scan_excl(ract ? R.narp : 0u,tot);
+				if ( sb + tot > CT::rccap ) { over(512|0x4000); return false; }
+				if ( ract ) reverseBlockCopy(R,sbase);
+				// blocks of more than 16 entries are sorted with an explicit stack (one lane at a time)
+				uint64_t big = wv_ballot(ract && R.narp > 16);
+				if ( ract && R.narp <= 16 ) reverseBlockFinish(R,sbase,li,lastnode,lmax);
+				while ( big )
+				{
+					int const b = __builtin_ctzll(big); big &= big-1;
+					if ( lane == b ) reverseBlockFinish(R,sbase,li,lastnode,lmax);
+				}
+				sb += tot;
+				flags = wv_or(flags); if ( flags ) return false;
+			}
+			rstop = sb;
+		}
+		wv_sync();
+		PROF(*this,11)
+
+		// ---- batches of forward trees (lane = first k-mer candidate) and their pairs ----
+		pl_midready = false;
+		uint32_t fstart = 0, bw = WSZ, pskip = 0;
+		while ( fstart < nF )
+		{
+			if ( lane == 0 ) L.ctr()[1] = 0;
 			wv_sync();
-			flags = wv_bcast(flags,0); if ( flags ) return false;
-			req = wv_bcast(req,0);
-			if ( !req ) break;
-			// middle piece of a stretch split twice: appended to the pool (kept, candidates may refer to it)
-			uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
-			if ( npool+1 > CT::scap || npool+1 > 250 ) { over(32); return false; }
-			if ( lane == 0 ) { makePiece(npool,par,ma,mb); L.ppos()[npool] = basePos(npool); }
-			wv_sync();
-			computeStretchFeas<true>(npool,npool+1);
+			uint32_t const fi = fstart + lane;
+			bool const fact = static_cast<uint32_t>(lane) < bw && fi < nF;
+			FEnum F; clInit(F.C,L.fchb() + 8*FNW*(fi < nF ? fi : static_cast<uint32_t>(FNC))); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
+			int32_t firstnode = -1;
+			uint32_t fover = 0;
+			if ( fact )
+			{
+				uint32_t const saved = flags; flags = 0;
+				View V; viewOfFirst(V,fi);
+				firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
+				forwardEnumerateLane(F,L.fchb() + 8*FNW*fi,V,firstnode,lmax,reinterpret_cast<LDSQ id_t *>(L.lscr()) + 12*lane);
+				if ( flags == (512|0x10000) && F.np < 8*FNW*FCH ) { fover = 1; flags = saved; }   // no pool space left for this tree
+				else flags |= saved;
+			}
 			flags = wv_or(flags); if ( flags ) return false;
-			++npool;
-			if ( lane == 0 ) pl_midready = true;
+			uint64_t const fo = wv_ballot(fover);
+			uint32_t nb = nF - fstart; if ( nb > bw ) nb = bw;
+			if ( fo ) { uint32_t const f0 = __builtin_ctzll(fo); if ( f0 < nb ) nb = f0; }
+			if ( nb == 0 )
+			{
+				// the first tree of the batch lost the race for pool space: run it alone, and give up if even that fails
+				if ( bw == 1 ) { over(512|0x10000); return false; }
+				bw = 1;
+				continue;
+			}
+			// a batch that did not fit sets the width of the next ones
+			bw = fo ? nb : ((2*bw < WSZ) ? 2*bw : static_cast<uint32_t>(WSZ));
+			if ( fact && static_cast<uint32_t>(lane) < nb ) forwardTreeFinish(F,fi,firstnode,lmax);
+			wv_sync();
+			PROF(*this,10)
+			if ( lane == 0 ) { pcount(26,1); pcount(25,nb*nL); }
+			uint32_t const npairs = nb*nL;
+			bool restart = false;
+			for ( uint32_t p0 = pskip; p0 < npairs && !restart; p0 += NPL )
+			{
+				uint32_t const nround = (npairs-p0 < NPL) ? (npairs-p0) : static_cast<uint32_t>(NPL);
+				bool const cfull = wv_bcast(ncdh == 16 ? 1u : 0u,0) != 0;
+				roundT0 = cfull ? L.cdh()[0].w : 0ull;
+				for ( uint32_t t = lane; t < nround; t += WSZ )
+				{
+					uint32_t const p = p0 + t;
+					uint32_t const pfi = fstart + p/nL, pli = p%nL;
+					uint32_t const cl = classifyPair(pfi,pli,lmax);
+					uint32_t mode;
+					if ( cl != 3 ) mode = PM_EXACT | cl;
+					else if ( (L.rfmask()[pli] & L.ffm()[pfi]) == 0 ) mode = PM_SKIP;     // the forward tree and the reverse block share no junction k-mer
+					else
+					{
+						ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
+						uint32_t const cnt = combineLane(FC,L.fnp()[pfi],L.rbase()[pli],L.rn()[pli],L.rfmask()[pli],lmin,lmax,16,
+							reinterpret_cast<LDSQ PSI *>(L.lscr()) + PSIQ*t,L.pout() + 32*t,cfull,roundT0);
+						mode = cnt == 0xFF ? static_cast<uint32_t>(PM_SERIAL) : (cnt ? cnt : static_cast<uint32_t>(PM_SKIP));
+					}
+					L.poutn()[t] = mode;
+				}
+				wv_sync();
+				PROF(*this,5)
+				if ( lane == 0 ) pcount(27,1);
+				uint32_t q = 0;
+				while ( true )
+				{
+					uint32_t req = 0;
+					if ( lane == 0 ) req = replayRound(q,nround,p0,fstart,lmin,lmax,nb == 1);
+					wv_sync();
+					flags = wv_bcast(flags,0); if ( flags ) return false;
+					req = wv_bcast(req,0);
+					if ( !req ) break;
+					if ( req == 2 )
+					{
+						uint32_t const pq = p0 + wv_bcast(q,0);
+						fstart += pq/nL; pskip = pq%nL; bw = 1; restart = true;
+						if ( lane == 0 ) pcount(28,1);
+						break;
+					}
+					// middle piece of a stretch split twice: appended to the pool (kept, candidates may refer to it)
+					uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
+					if ( npool+1 > CT::scap || npool+1 > 250 ) { over(32); return false; }
+					if ( lane == 0 ) { makePiece(npool,par,ma,mb); L.ppos()[npool] = basePos(npool); }
+					wv_sync();
+					computeStretchFeas<true>(npool,npool+1);
+					flags = wv_or(flags); if ( flags ) return false;
+					++npool;
+					if ( lane == 0 ) pl_midready = true;
+				}
+				PROF(*this,7)
+			}
+			if ( restart ) continue;
+			fstart += nb; pskip = 0;
 		}
 		PROF(*this,12)
 		if ( lane == 0 )
@@ -1743,7 +2214,7 @@ struct FastEngine
 		wv_sync();
 		PROF(*this,13)
 		FSTAT_MX(0,mao); FSTAT_MX(1,npre); FSTAT_MX(2,nn); FSTAT_MX(3,n0); FSTAT_MX(4,npool); FSTAT_MX(5,nlinks); FSTAT_MX(6,nwF); FSTAT_MX(7,nwR);
-		FSTAT_MX(8,rctop); FSTAT_MX(9,nF); FSTAT_MX(10,nL); FSTAT_ADD(11,1); FSTAT_MX(12,nc);
+		FSTAT_MX(8,rstop); FSTAT_MX(9,nF); FSTAT_MX(10,nL); FSTAT_ADD(11,1); FSTAT_MX(12,nc);
 		return nc != 0;
 	}
 
@@ -1896,8 +2367,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	{ char const * pz = getenv("DACC_EMUL_POISON"); if ( pz ) __builtin_memset(static_cast<void *>(&E),atoi(pz),sizeof(E)); }   // debugging aid: no member may be read before it is set
 #endif
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
-	E.rctop = 0; E.np = E.nfpop = E.nsiq = E.ncdh = E.nacc = 0; E.fcur_fi = E.fcur_li = -1; E.rb = E.nrp = E.narp = E.rlastk = 0; E.rmaxw = E.fmaxw = 0;
-	E.apqm0 = E.apqm1 = 0; E.cfree = 0; E.pl_fi = E.pl_li = E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false; E.ftmask = 0; E.ffmask = 0; E.rfmcur = 0; E.V.nadd = 0; E.V.r0 = E.V.r1 = 0xFFFF;
+	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 #if defined(DACC_EMUL)

@@ -127,6 +127,8 @@
   DEV uint64_t wv_shfl64(uint64_t v, int src) { return __shfl(v,src,64); }
   DEV int dacc_popc64(uint64_t v) { return __popcll(v); }
   DEV void atomicOrFlag(uint32_t * f) { atomicOr(f,1u); }
+  // workgroup scope atomic add on an LDS (or global) word, returns the old value
+  template<typename PT> DEV uint32_t wv_atomic_add(PT p, uint32_t const v) { return __hip_atomic_fetch_add(p,v,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_WORKGROUP); }
   }
 #endif
 

@@ -6,10 +6,10 @@ import numpy as np
 from daccord_amd import engine
 from daccord_amd._structs import default_params
 from daccord_amd.synth import SynthData
-NAMES = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors", "feasible", "gapfill", "firstlast",
-         "stretches", "stretchfeas", "stretchlinks", "reverse-enum", "forward+pairs", "cand-errors", "align+emit", "-",
+NAMES = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors", "pair-gen (lanes)", "gapfill", "pair-replay (lane 0)",
+         "stretches", "cand+tab+stretchfeas", "F trees (lanes)", "R blocks (lanes)", "tail", "cand-errors", "align+emit", "-",
          " s:predcounts", " s:walk1", " s:walk2", " s:splits", " s:sort+uniq"]
-EXTRA = {21: "pairs exact (count)", 22: "R enum cycles", 23: "F enum cycles", 24: "combine cycles", 25: "R enums (count)", 26: "F enums (count)", 27: "pairs (count)", 28: "pairs pruned (count)"}
+EXTRA = {21: "cut sequences continued", 22: "exact pairs", 23: "serial combines", 25: "pairs", 26: "F batches", 27: "pair rounds", 28: "batch restarts"}
 npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 d = SynthData(250000, 1000, 5000, seed=3)
 ovl, piles = engine.pile_select(d.ovl, d.piles)

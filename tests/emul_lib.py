@@ -1,4 +1,6 @@
-"""ctypes wrapper of the 1-lane host emulation of the kernels (tests/emul/emul.cpp): TEST HARNESS ONLY."""
+"""ctypes wrapper of the host emulation of the kernels (tests/emul/emul.cpp): TEST HARNESS ONLY.
+Two builds of the same device headers: a 1-lane wavefront (fast, logic only) and a real 64-lane wavefront with one
+coroutine per lane (daccord_amd/csrc/wave_emul64.hpp: ballots, scans, shuffles and barriers behave as on the GPU)."""
 import ctypes as C
 import os
 import subprocess
@@ -11,6 +13,7 @@ sys.path.insert(0, _ROOT)
 from daccord_amd._structs import DaccParams, DaccFragment, DaccWindowResult  # noqa: E402
 
 _SO = os.environ.get("DACC_EMUL_LIB") or os.path.join(_HERE, "emul", "libdacc_emul.so")
+_SO64 = os.path.join(_HERE, "emul", "libdacc_emul64.so")
 _SRCS = [os.path.join(_HERE, "emul", "emul.cpp")] + [os.path.join(_ROOT, "daccord_amd", "csrc", f)
                                                       for f in os.listdir(os.path.join(_ROOT, "daccord_amd", "csrc"))
                                                       if f.endswith((".hpp", ".cpp"))]
@@ -21,17 +24,20 @@ def build(force=False):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", _SO,
                                os.path.join(_HERE, "emul", "emul.cpp"),
                                os.path.join(_ROOT, "daccord_amd", "csrc", "host_tables.cpp")])
+    if force or not os.path.exists(_SO64) or os.path.getmtime(_SO64) < max(os.path.getmtime(s) for s in _SRCS):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-DDACC_EMUL_LANES=64",
+                               "-DDACC_EMUL_IMPL", "-o", _SO64, os.path.join(_HERE, "emul", "emul.cpp"),
+                               os.path.join(_ROOT, "daccord_amd", "csrc", "host_tables.cpp")])
     return _SO
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
+def lib(lanes=1):
+    if lanes not in _libs:
         build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(_SO64 if lanes == 64 else _SO)
         L.emul_create.restype = C.c_void_p
         L.emul_create.argtypes = [C.POINTER(DaccParams)]
         L.emul_destroy.argtypes = [C.c_void_p]
@@ -46,8 +52,8 @@ def lib():
         L.emul_set_fast.argtypes = [C.c_void_p, C.c_int]
         L.emul_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.emul_counts4.argtypes = [C.c_void_p, C.c_void_p]
-        _lib = L
-    return _lib
+        _libs[lanes] = L
+    return _libs[lanes]
 
 
 def _ptr(a):
@@ -55,8 +61,8 @@ def _ptr(a):
 
 
 class Emul:
-    def __init__(self, params):
-        self.L = lib()
+    def __init__(self, params, lanes=1):
+        self.L = lib(lanes)
         self.h = self.L.emul_create(C.byref(params))
 
     def __del__(self):

@@ -107,3 +107,17 @@ def test_deep_piles_reach_later_tiers_first_and_then_need_the_generic_engine():
     t1, t2, t3, gen = E.counts()
     assert t3 > 0 and gen > 0 and t1 == 0
     assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
+
+
+@pytest.mark.parametrize("kw", [dict(k=8), dict(k=14), dict(klow=8, khigh=9, maxalign=6)])
+def test_64_lane_wavefront_emulation(small_data, kw):
+    """The same kernel headers as a real 64-lane wavefront on the host (coroutine per lane, checked collectives):
+    ballot / scan / shuffle / barrier code paths, not only the 1-lane logic."""
+    d, ovl, piles = small_data
+    p = default_params(**kw)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p, lanes=64); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[3:5], ovl, d.trace, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[3:5], ovl, d.trace)
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)

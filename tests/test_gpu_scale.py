@@ -1,0 +1,49 @@
+"""Parity at BASELINE scale: the HIP path through the C ABI against the oracle's frozen output.
+
+The oracle ran in the build container (tests/golden/make_golden_scale.py, deterministic synthetic input); the fixtures
+tests/golden/scale_<case>.json hold SHA-256 digests of its FASTA text and of its per-window records plus one short digest
+per pile.  Here the same input is regenerated, corrected on the GPU and hashed."""
+import hashlib
+import json
+import os
+import numpy as np
+import pytest
+from daccord_amd import engine
+from daccord_amd._structs import default_params
+from scale_cases import CASES, make_case, window_digest, pile_digests
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden(name):
+    fn = os.path.join(HERE, "golden", "scale_%s.json" % name)
+    if not os.path.exists(fn):
+        pytest.skip("no golden fixture for %s" % name)
+    with open(fn) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["cfg1k8", "cfg4", "cfg5", "cfg2"])
+def test_scale_case_matches_oracle_digests(name):
+    G = _golden(name)
+    case = CASES[name]
+    assert {k: v for k, v in G["spec"].items() if k != "params"} == json.loads(json.dumps({k: v for k, v in case.items() if k != "params"}))
+    d, ovl, piles, sel = make_case(case, engine.pile_select)
+    for run in G["runs"]:
+        p = default_params(**run["params"])
+        E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+        fx, bx = E(sel, ovl, d.trace)
+        t = E.timing()
+        w = E.debug_windows()
+        txt = engine.fasta(fx, bx)
+        print("%s %s: %d windows, %d bases, window kernel %.1f ms, tiers handed on %s"
+              % (name, run["params"], len(w), len(bx), t.window_ms, list(t.tier_out)))
+        assert len(w) == run["nwindows"]
+        pd = pile_digests(fx, bx, sel, engine.fasta)
+        badp = [i for i, (a, b) in enumerate(zip(pd, run["pile_sha256"])) if a != b]
+        assert badp == [], ("piles whose FASTA differs from the oracle's", run["params"], len(badp), badp[:10])
+        assert window_digest(w) == run["windows_sha256"], run["params"]
+        assert len(bx) == run["nbases"] and len(fx) == run["nfragments"]
+        assert hashlib.sha256(txt.encode()).hexdigest() == run["fasta_sha256"], run["params"]
+        E.close()
