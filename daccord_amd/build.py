@@ -29,6 +29,18 @@ def build_hip(force=False, verbose=False):
     return LIB
 
 
+def build_prof(force=False):
+    """Profiling build of the same library (-DDACC_PROFILE: per-phase shader-cycle counters, scripts/prof_phases.py)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp"))]
+    out = os.path.join(_HERE, "libdaccord_hip_prof.so")
+    if force or _newer(out, srcs):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc] + HIPCC_FLAGS + ["-DDACC_PROFILE", "-o", out, os.path.join(CSRC, "capi.hip"),
+                               os.path.join(CSRC, "host_tables.cpp"), os.path.join(CSRC, "host_piles.cpp"),
+                               os.path.join(CSRC, "host_io.cpp")])
+    return out
+
+
 def build_io(force=False):
     """Host-only library with the .db / .las readers and writers (include/daccord_io.h) and the pile selection;
     the same objects are also linked into libdaccord_hip.so."""

@@ -223,6 +223,8 @@ struct dacc_ctx
 	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly; DevBuf<uint8_t> d_arena2;
 	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_threads, win_grid;
+	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
+	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
 	dacc_timing timing;
@@ -255,6 +257,12 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	if ( !c ) return DACC_ENOMEM;
 	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0;
 	std::memset(&c->timing,0,sizeof(c->timing));
+	{
+		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
+		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
+		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 7;      // bit t enables LDS tier t+1
+		char const * dr = getenv("DACC_DEBUG_RETRY"); c->env_dbgretry = (dr && dr[0] == '1');
+	}
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
 	{ int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo,&hi); if ( hipStreamCreateWithPriority(&c->stream2,hipStreamNonBlocking,hi) != hipSuccess ) { delete c; return DACC_EHIP; } }
 	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming);
@@ -403,6 +411,15 @@ static int runDevice(dacc_ctx * c)
 				}
 				hipEventRecord(c->evtier[t],s);
 			}
+			if ( c->env_dbgretry && list )
+			{
+				// debugging: which windows did the last LDS tier hand on, and why (flags of its FFAIL)
+				HIPCHK(hipStreamSynchronize(s));
+				uint32_t n = 0; HIPCHK(hipMemcpy(&n,list,sizeof(uint32_t),hipMemcpyDeviceToHost));
+				std::vector<uint32_t> idx(n); if ( n ) HIPCHK(hipMemcpy(idx.data(),list+1,n*sizeof(uint32_t),hipMemcpyDeviceToHost));
+				c->retry_flags.clear();
+				for ( uint32_t i = 0; i < n; ++i ) { WindowOut o; HIPCHK(hipMemcpy(&o,c->d_wout.p+idx[i],sizeof(WindowOut),hipMemcpyDeviceToHost)); c->retry_flags.push_back(idx[i]); c->retry_flags.push_back(o.flags); c->retry_flags.push_back(o.mao); c->retry_flags.push_back(static_cast<uint32_t>(o.filterfreq)); }
+			}
 			// what is left (rare shapes) goes through the generic engine
 			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0));
 			if ( early ) HIPCHK(hipStreamWaitEvent(s,c->evEarlyGeneric,0));
@@ -527,10 +544,8 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	if ( wg > maxwg ) wg = maxwg;
 	if ( wg < 8 ) wg = 8;
 	{
-		char const * e = getenv("DACC_NOFAST");
-		c->usefast = !(e && e[0] == '1');
-		char const * sc = getenv("DACC_SCHED");   // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
-		c->sched = sc ? atoi(sc) : 1;
+		c->usefast = !c->env_nofast;
+		c->sched = c->env_sched;
 		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
 		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP ) c->usefast = 0;
 	}
@@ -541,7 +556,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		{
 			FastCaps const & F = BP.ftier[t];
 			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= F.tabcap) && F.ldsbytes <= 160*1024;
-			{ char const * tm = getenv("DACC_TIERS"); if ( tm && !((atoi(tm)>>t)&1) ) c->tier_ok[t] = 0; }   // debugging: bit t enables tier t+1
+			if ( !((c->env_tiers>>t)&1) ) c->tier_ok[t] = 0;
 			uint64_t percu = (160*1024) / (F.ldsbytes ? F.ldsbytes : 1);
 			if ( percu > 8 ) percu = 8;
 			if ( percu < 1 ) percu = 1;
@@ -617,6 +632,15 @@ int dacc_debug_profile(dacc_ctx * c, uint64_t * out32)
 		for ( int i = 0; i < 32; ++i ) out32[i] = 0;
 		for ( int b = 0; b < 4096; ++b ) for ( int i = 0; i < 32; ++i ) { if ( i == 29 ) out32[i] = std::max(out32[i],H[32*b+i]); else out32[i] += H[32*b+i]; }
 	}
+	return DACC_OK;
+}
+
+// DACC_DEBUG_RETRY=1: (window, flags, mao, filterfreq) of the windows the last LDS tier handed to the generic engine
+int dacc_debug_retry(dacc_ctx * c, uint32_t * out, uint64_t cap, uint64_t * n)
+{
+	if ( !c || !n ) return DACC_EINVAL;
+	*n = c->retry_flags.size();
+	if ( out ) std::memcpy(out,c->retry_flags.data(),sizeof(uint32_t)*std::min<uint64_t>(cap,c->retry_flags.size()));
 	return DACC_OK;
 }
 

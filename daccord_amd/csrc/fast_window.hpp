@@ -48,7 +48,7 @@
 namespace dacc {
 
 enum { WS_RETRY = 4 };
-enum { FNC = 48 };          // max first / last k-mer candidates on the fast path
+enum { FNC = 40 };          // max first / last k-mer candidates on the fast path
 enum { FNOPAR = 0xFF };
 enum { FSUPCAP = 128 };
 enum { FSEQCAP = 48 };      // max stretches of one candidate path     // max width (read offsets) of the model table copy in LDS
@@ -67,10 +67,10 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 8, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 8, idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -205,7 +205,7 @@ struct FastLds
 	FLD(fp_front,uint32_t,CT::fcap,e_fp_cl)
 	FLD(fp_adj,uint64_t,CT::fcap,e_fp_front)
 	// per first k-mer candidate: chunk list of its tree, popped paths, junction k-mer bits, scan target bits, heaviest path
-	FLD(fchb,uint8_t,16*(FNC+1),e_fp_adj)
+	FLD(fchb,uint8_t,8*CT::fnw*(FNC+1),e_fp_adj)   // chunk ids of the forward trees: 8*fnw per first k-mer candidate (+ one exact tree)
 	FLD(fnp,uint16_t,FNC+1,e_fchb)
 	FLD(ffm,uint64_t,FNC+1,e_fnp)
 	FLD(ftm,uint64_t,FNC+1,e_ffm)
@@ -216,9 +216,9 @@ struct FastLds
 	FLD(ctr,uint32_t,4,e_poutn)
 	FLD(rchx,uint8_t,32,e_ctr)              // chunk ids of a reverse enumeration on lane 0 alone
 	static constexpr uint32_t upool = e_rchx;
-	// chunk ids of the reverse enumerations of all last k-mers (32 per lane): over the per first k-mer tables, which are
+	// chunk ids of the reverse enumerations of all last k-mers (32 per lane, lanes < FNC): over the per first k-mer tables, which are
 	// written after those enumerations have been copied to their blocks
-	FLD(rchb,uint8_t,64*32,o_fchb)
+	FLD(rchb,uint8_t,FNC*32,o_fchb)
 	static_assert(e_rchb <= o_pout,"reverse chunk lists must fit the per first k-mer tables");
 	// raw stretches (overlay of the caches)
 	FLD(tfirst,uint16_t,CT::scap,pbase)
@@ -240,8 +240,14 @@ struct FastLds
 	// fixed-point model table [pos][row], row stride nrows+1.  It shares the bytes of the enumeration pools: it is
 	// (re)loaded from HBM/L2 for gap filling and for the stretch feasibility of a traverse call, both of which are over
 	// before the pools are used.
-	FLD(tab,uint32_t,(upool-o_cdh)/4,o_cdh)   // also over the candidate buffers, which are dead at that time
-	static constexpr uint32_t tabcap = (upool-o_cdh)/4;
+	// feasibility tasks (with the table, dead before the pools are used): first task, first and end start position of
+	// every (stretch, direction)
+	static constexpr uint32_t taskbytes = ((2*CT::scap+2)*2 + 2*(2*CT::scap) + 15u) & ~15u;
+	FLD(toff,uint16_t,2*CT::scap+2,upool-taskbytes)
+	FLD(ulo,uint8_t,2*CT::scap,e_toff)
+	FLD(uhi,uint8_t,2*CT::scap,e_ulo)
+	FLD(tab,uint32_t,(upool-taskbytes-o_cdh)/4,o_cdh)   // also over the candidate buffers, which are dead at that time
+	static constexpr uint32_t tabcap = (upool-taskbytes-o_cdh)/4;
 	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
 };
 #undef FLD
@@ -290,6 +296,7 @@ static inline void fstats_dump(int const tier)
 	if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_STATS"); if ( fn ) sf = fopen(fn,"w"); }
 	if ( sf ) { fprintf(sf,"%d",tier); for ( int i = 0; i < 24; ++i ) fprintf(sf," %u",g_fstats.v[i]); fprintf(sf,"\n"); fflush(sf); }
 }
+static inline FILE * ftrav_file() { static FILE * f = 0; static bool tried = false; if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_TRAV"); if ( fn ) f = fopen(fn,"w"); } return f; }
 #define FSTAT_MX(i,x) g_fstats.mx(i,x)
 #define FSTAT_ADD(i,x) g_fstats.add(i,x)
 #else
@@ -311,7 +318,13 @@ struct FastEngine
 	uint32_t n0, npool, nlinks, nwF, nwR;
 	uint32_t nF, nL;
 
+#if defined(DACC_EMUL)
+	// emulation only: DACC_EMUL_OVER=1 reports where a tier overflowed
+	DEV void over_(uint32_t b, int line) { flags |= b; static char const * ov = getenv("DACC_EMUL_OVER"); if ( ov ) fprintf(stderr,"[over] tier maxs=%d line %d bits 0x%x nn=%u n0=%u npool=%u nF=%u nL=%u nwF=%u nwR=%u rstop=%u\n",int(CT::maxs),line,b,nn,n0,npool,nF,nL,nwF,nwR,rstop); }
+	#define over(b) over_(b,__LINE__)
+#else
 	DEV void over(uint32_t b) { flags |= b; }
+#endif
 #if defined(DACC_PROFILE) && !defined(DACC_EMUL)
 	DEV void pcount(int id, uint64_t v) { if ( prof ) atomicAdd(reinterpret_cast<unsigned long long *>(prof+id),static_cast<unsigned long long>(v)); }
 	DEV uint64_t pclock() { return clock64(); }
@@ -320,6 +333,13 @@ struct FastEngine
 	DEV uint64_t pclock() { return 0; }
 #endif
 
+#if defined(DACC_PROFILE) && !defined(DACC_EMUL)
+	#define PROFX_T0 uint64_t _px = clock64();
+	#define PROFX(id) { uint64_t const _n = clock64(); if ( lane == 0 && prof ) atomicAdd(reinterpret_cast<unsigned long long *>(prof+(id)),static_cast<unsigned long long>(_n-_px)); _px = _n; }
+#else
+	#define PROFX_T0
+	#define PROFX(id)
+#endif
 	DEV int32_t findNode(uint32_t const v) const
 	{
 		int32_t lo = 0, hi = static_cast<int32_t>(nn)-1;
@@ -356,34 +376,57 @@ struct FastEngine
 	// ================= build: instances, nodes, successors =================
 	DEV void buildInstances()
 	{
-		uint32_t base = 0;
-		for ( uint32_t j = 0; j < mao; ++j ) { uint32_t const len = L.slen()[j]; base += (len >= k) ? (len-k+1) : 0; }
+		PROFX_T0
+		// k-mer instances of all strings at once, lane = instance: the number of k-mers of string j and its first output
+		// slot live in lane j%64 (register c = j/64), so a lane finds the string of its instance by comparing against
+		// broadcast (scalar) offsets instead of walking LDS
+		enum { NCH = (CT::maxs+WSZ-1)/WSZ };
+		uint32_t nk[NCH], off[NCH]; uint32_t base = 0, nl = 0;
+		#pragma unroll
+		for ( int c = 0; c < NCH; ++c )
+		{
+			uint32_t const j = c*WSZ + lane;
+			uint32_t const len = j < mao ? L.slen()[j] : 0u;
+			nk[c] = len >= k ? (len-k+1) : 0u;
+			uint32_t tot; uint32_t const pre = wv_scan_excl(nk[c],tot);
+			off[c] = base + pre; base += tot;
+			uint32_t t2; wv_scan_flag(nk[c] != 0,t2); nl += t2;
+		}
 		npre = base;
 		nlast = 0;
 		if ( npre > CT::precap ) { over(1); npre = 0; return; }
-		uint32_t o = 0, lo = 0;
-		for ( uint32_t j = 0; j < mao; ++j )
+		for ( uint32_t t0 = 0; t0 < npre; t0 += WSZ )
 		{
-			uint32_t const len = L.slen()[j];
-			if ( len < k ) continue;
-			uint32_t const numk = len-k+1;
-			LDSQ uint8_t const * s = L.str() + j*64;
-			for ( uint32_t i = lane; i < numk; i += WSZ )
+			uint32_t const t = t0 + lane;
+			uint32_t j = 0, oj = 0, lo = 0;
+			#pragma unroll
+			for ( int c = 0; c < NCH; ++c )
+				for ( uint32_t jj = 0; jj < WSZ && c*WSZ + jj < mao; ++jj )
+				{
+					uint32_t const o = wv_bcast(off[c],jj), n = wv_bcast(nk[c],jj);
+					if ( t >= o ) { j = c*WSZ + jj; oj = o; lo += (n != 0); }
+				}
+			if ( t < npre )
 			{
+				uint32_t const i = t - oj;
+				LDSQ uint8_t const * sp = L.str() + j*64 + i;
 				uint64_t v = 0;
-				for ( uint32_t q = 0; q < k; ++q ) v = (v<<2) | s[i+q];
+				#pragma unroll
+				for ( uint32_t q = 0; q < 16; ++q ) { uint64_t const c = sp[q]; v = q < k ? ((v<<2) | c) : v; }
 				uint64_t const word = (v<<32) | (static_cast<uint64_t>(i)<<16) | j;
-				L.pre()[o+i] = word;
-				if ( i == numk-1 ) L.lastk()[lo] = word;
+				L.pre()[t] = word;
+				if ( i + k == L.slen()[j] ) L.lastk()[lo-1] = word;
 			}
-			o += numk; ++lo;
 		}
-		nlast = lo;
+		nlast = nl;
 		uint32_t const lp2 = next_pow2(nlast < 2 ? 2 : nlast);
 		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk()[i] = ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.lastk(),lp2);
-		wv_bitonic_sort_n(L.pre(),npre);
+		PROFX(18)
+		wv_sort_keys<FastLds<CT>::keycap>(L.lastk(),nlast);
+		PROFX(19)
+		wv_sort_keys<CT::precap>(L.pre(),npre);
+		PROFX(20)
 	}
 
 	DEV void buildNodes(uint32_t const f)
@@ -460,8 +503,8 @@ struct FastEngine
 		uint32_t const q2 = next_pow2(nmlast < 2 ? 2 : nmlast);
 		for ( uint32_t i = nmlast + lane; i < q2; i += WSZ ) L.mlast()[i] = ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.mfirst(),p2);
-		wv_bitonic_sort(L.mlast(),q2);
+		wv_sort_keys<FastLds<CT>::keycap>(L.mfirst(),nmfirst);
+		wv_sort_keys<FastLds<CT>::keycap>(L.mlast(),nmlast);
 	}
 
 	DEV void buildSuccessors(uint32_t const no)
@@ -608,7 +651,7 @@ struct FastEngine
 		if ( npre + base > CT::precap ) { over(1); return; }
 		npre += base;
 		wv_sync();
-		wv_bitonic_sort_n(L.pre(),npre);
+		wv_sort_keys<CT::precap>(L.pre(),npre);
 	}
 
 	// ================= stretches, once per activation state =================
@@ -714,7 +757,7 @@ struct FastEngine
 		for ( uint32_t q = lane; q < p2; q += WSZ )
 			L.skey()[q] = q < ns ? ((sortKey(L.tfirst()[q],L.links()[L.tlink()[q]+1],L.tslen()[q],L.tlast()[q])<<8) | q) : ~0ull;
 		wv_sync();
-		wv_bitonic_sort(L.skey(),p2);
+		wv_sort_keys<fcpow2(CT::scap)>(L.skey(),ns);
 		// distinct (first,ext) by construction; a duplicate would need stretchesUnique's tie handling -> generic engine
 		uint32_t dup = 0;
 		for ( uint32_t q = lane; q < ns; q += WSZ )
@@ -731,7 +774,7 @@ struct FastEngine
 		for ( uint32_t q = lane; q < p2; q += WSZ ) L.skey()[q] = q < ns ? ((static_cast<uint64_t>(L.slast()[q])<<8) | q) : ~0ull;
 		wv_sync();
 		for ( uint32_t q = lane; q < ns; q += WSZ ) if ( q == 0 || L.sfirst()[q-1] != L.sfirst()[q] ) L.npred()[L.sfirst()[q]] = q;
-		wv_bitonic_sort(L.skey(),p2);
+		wv_sort_keys<fcpow2(CT::scap)>(L.skey(),ns);
 		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
 			uint64_t const e = L.skey()[q];
@@ -892,145 +935,132 @@ struct FastEngine
 		wv_sync();
 	}
 
-	// ---- stretch feasibility, one LANE per (stretch, direction) (the wavefront-per-stretch form above walks the
-	// stretches one after the other and leaves most lanes idle for the short position ranges that survive the node
-	// supports).  A lane first intersects the support ranges of its nodes (start positions that every node allows),
-	// reserves that many weight slots by a wave scan and then evaluates FNP start positions at a time: node and instance
-	// loads are shared by the FNP positions and run three nodes ahead of the table reads (the chain link -> node ->
-	// instance -> table would otherwise be paid per node).  Same sums in the same order as computeStretchFeas, entries in
-	// ascending start position.  If the reservations (upper bounds) of all stretches do not fit, the feasible positions
-	// are counted first and evaluated again at their exact offsets.
-	enum { FNP = 8 };
-	DEV uint64_t evalStretchLane(bool const rev, bool const maskonly, uint32_t const len, LDSQ uint16_t const * Lk, int32_t const lo, int32_t const hi, uint32_t const wbase)
+	// ---- stretch feasibility, one LANE per (stretch, direction, start position) ----
+	// The wavefront-per-stretch form above walks the stretches one after the other with lanes = start positions and leaves
+	// most lanes idle (few positions survive the node supports).  Here one lane per (stretch, direction) first intersects
+	// the support ranges of its nodes; the surviving (stretch, direction, position) triples are then numbered and
+	// evaluated 64 at a time, a stretch after the other in each direction, so that the feasible ones can be appended to
+	// the weight lists with a ballot.  Same sums in the same order as computeStretchFeas, entries in ascending start
+	// position.  The loads of a node (link -> node -> first instance -> table) run ahead of the table reads.
+	DEV void computeStretchFeasLanes(uint32_t const sfrom, uint32_t const sto)
 	{
+		uint32_t const ns = sto-sfrom, nu = 2*ns;          // units: forward stretches, then reverse stretches
 		uint32_t const stride = nrows+1;
-		LDSQ uint8_t const * IP = rev ? L.irpos() : L.ipos();
-		uint64_t mask = 0; uint32_t cnt = 0;
-		#define DACC_LKN(J) static_cast<uint32_t>(Lk[rev ? (len-1-(J)) : (J)])
-		for ( int32_t P0 = lo; P0 < hi; P0 += FNP )
+		uint32_t tbase = 0;
+		for ( uint32_t c = 0; c < nu; c += WSZ )
 		{
-			uint64_t sum[FNP], f1[FNP], fl[FNP]; uint32_t okm = 0;
-			#pragma unroll
-			for ( int u = 0; u < FNP; ++u ) { sum[u] = 0; f1[u] = 0; fl[u] = 0; if ( P0+u < hi ) okm |= 1u<<u; }
-			// software pipeline over the nodes: a = node j (instances known), b = node j+1 (index known), c = node j+2
-			uint32_t z_b = len > 1 ? DACC_LKN(1) : 0u, z_c = len > 2 ? DACC_LKN(2) : 0u;
-			uint32_t i0_a, f_a, ip_a, i0_b, f_b;
-			{ uint32_t const z_a = DACC_LKN(0); i0_a = L.nps()[z_a]; f_a = L.nfreq()[z_a]; ip_a = IP[i0_a]; i0_b = L.nps()[z_b]; f_b = L.nfreq()[z_b]; }
-			for ( uint32_t j = 0; j < len && okm; ++j )
+			uint32_t const u = c + lane;
+			uint32_t w = 0;
+			if ( u < nu )
 			{
-				uint32_t const z_d = j+3 < len ? DACC_LKN(j+3) : 0u;
-				uint32_t const i0_c = L.nps()[z_c], f_c = L.nfreq()[z_c];
-				uint32_t const ip_b = IP[i0_b];
-				uint64_t U[FNP];
+				bool const rev = u >= ns; uint32_t const s = sfrom + (rev ? u-ns : u);
+				uint32_t const len = L.sslen()[s]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+				int32_t lo = 0, hi = static_cast<int32_t>(nrows);
+				uint32_t const sh = rev ? 16 : 0;
+				for ( uint32_t j = 0; j < len; ++j )
 				{
-					uint32_t const row = ip_a*stride;
-					#pragma unroll
-					for ( int u = 0; u < FNP; ++u )
-					{
-						uint32_t const pp = static_cast<uint32_t>(P0+u)+j;
-						U[u] = L.tab()[row + (pp < nrows ? pp : nrows)];
-					}
+					uint32_t const g = L.nrange()[Lk[rev ? (len-1-j) : j]] >> sh;
+					int32_t const jj = static_cast<int32_t>(j);
+					int32_t const a = static_cast<int32_t>(g&0xFF)-jj, b = static_cast<int32_t>((g>>8)&0xFF)-jj;
+					lo = a > lo ? a : lo; hi = b < hi ? b : hi;
 				}
-				for ( uint32_t q = 1; q < f_a; ++q )
-				{
-					uint32_t const row = static_cast<uint32_t>(IP[i0_a+q])*stride;
-					#pragma unroll
-					for ( int u = 0; u < FNP; ++u )
-					{
-						uint32_t const pp = static_cast<uint32_t>(P0+u)+j;
-						U[u] += L.tab()[row + (pp < nrows ? pp : nrows)];
-					}
-				}
-				#pragma unroll
-				for ( int u = 0; u < FNP; ++u )
-				{
-					if ( U[u] < FW_THRES_FEAS ) okm &= ~(1u<<u);
-					sum[u] += U[u];
-					if ( j == 0 ) f1[u] = U[u];
-					fl[u] = U[u];
-				}
-				i0_a = i0_b; f_a = f_b; ip_a = ip_b; i0_b = i0_c; f_b = f_c; z_c = z_d;
+				if ( hi < lo ) hi = lo;
+				w = static_cast<uint32_t>(hi-lo);
+				L.ulo()[u] = lo; L.uhi()[u] = hi;
+				if ( rev ) { L.maskR()[s] = 0; L.woffR()[s] = 0; } else { L.maskF()[s] = 0; L.woffF()[s] = 0; }
 			}
-			#pragma unroll
-			for ( int u = 0; u < FNP; ++u )
-				if ( (okm>>u)&1 )
+			uint32_t tot; uint32_t const pre = wv_scan_excl(w,tot);
+			if ( u < nu ) L.toff()[u] = tbase + pre;
+			tbase += tot;
+		}
+		if ( tbase > 0xFFFF ) { over(128); return; }
+		if ( lane == 0 ) L.toff()[nu] = tbase;
+		wv_sync();
+		uint32_t const ntask = tbase;
+		uint64_t const ltmask = wv_lanemask_lt();
+		for ( uint32_t c = 0; c < ntask; c += WSZ )
+		{
+			uint32_t const t = c + lane;
+			bool const act = t < ntask;
+			uint32_t u = 0;
+			if ( act )
+			{
+				// unit of task t: last u with toff[u] <= t (empty units share their successor's offset)
+				uint32_t lo = 0, hi = nu;
+				while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( L.toff()[mid] <= t ) lo = mid; else hi = mid; }
+				u = lo;
+			}
+			bool const rev = u >= ns; uint32_t const s = sfrom + (rev ? u-ns : u);
+			uint32_t const t0 = act ? L.toff()[u] : 0u;
+			uint32_t const P = act ? (static_cast<uint32_t>(L.ulo()[u]) + (t-t0)) : 0u;
+			bool ok = act;
+			uint64_t sum = 0, f1 = 0, fl = 0;
+			if ( act )
+			{
+				uint32_t const len = L.sslen()[s]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+				LDSQ uint8_t const * IP = rev ? L.irpos() : L.ipos();
+				#define DACC_LKN(J) static_cast<uint32_t>(Lk[rev ? (len-1-(J)) : (J)])
+				// software pipeline over the nodes: a = node j (first instance known), b = node j+1 (index known), c = node j+2
+				uint32_t z_b = len > 1 ? DACC_LKN(1) : 0u, z_c = len > 2 ? DACC_LKN(2) : 0u;
+				uint32_t i0_a, f_a, ip_a, i0_b, f_b;
+				{ uint32_t const z_a = DACC_LKN(0); i0_a = L.nps()[z_a]; f_a = L.nfreq()[z_a]; ip_a = IP[i0_a]; i0_b = L.nps()[z_b]; f_b = L.nfreq()[z_b]; }
+				for ( uint32_t j = 0; j < len; ++j )
 				{
-					uint32_t const o = wbase + cnt; ++cnt;
-					mask |= 1ull << (P0+u);
-					if ( maskonly ) continue;
+					uint32_t const z_d = j+3 < len ? DACC_LKN(j+3) : 0u;
+					uint32_t const i0_c = L.nps()[z_c], f_c = L.nfreq()[z_c];
+					uint32_t const ip_b = IP[i0_b];
+					uint32_t const pp = P+j;
+					uint32_t const pc = pp < nrows ? pp : nrows;
+					uint64_t U = L.tab()[ip_a*stride + pc];
+					for ( uint32_t q = 1; q < f_a; ++q ) U += L.tab()[static_cast<uint32_t>(IP[i0_a+q])*stride + pc];
+					if ( U < FW_THRES_FEAS ) { ok = false; break; }
+					sum += U;
+					if ( j == 0 ) f1 = U;
+					fl = U;
+					i0_a = i0_b; f_a = f_b; ip_a = ip_b; i0_b = i0_c; f_b = f_c; z_c = z_d;
+				}
+				#undef DACC_LKN
+			}
+			// append the feasible ones: forward tasks precede reverse tasks, the tasks of a stretch are consecutive
+			uint64_t const okb = wv_ballot(ok);
+			uint64_t const revb = wv_ballot(act && rev);
+			uint64_t const mydir = rev ? revb : ~revb;
+			uint32_t const base = rev ? nwR : nwF;
+			if ( ok )
+			{
+				uint32_t const o = base + dacc_popc64(okb & mydir & ltmask);
+				if ( o < CT::wcap )
+				{
 					if ( rev )
 					{
-						L.wR_lo()[o] = static_cast<uint32_t>(sum[u]); L.wR_hi()[o] = static_cast<uint16_t>(sum[u]>>32);
-						L.wR1_lo()[o] = static_cast<uint32_t>(f1[u]); L.wR1_hi()[o] = static_cast<uint8_t>(f1[u]>>32);
+						L.wR_lo()[o] = static_cast<uint32_t>(sum); L.wR_hi()[o] = static_cast<uint16_t>(sum>>32);
+						L.wR1_lo()[o] = static_cast<uint32_t>(f1); L.wR1_hi()[o] = static_cast<uint8_t>(f1>>32);
 					}
 					else
 					{
-						L.wF_lo()[o] = static_cast<uint32_t>(sum[u]); L.wF_hi()[o] = static_cast<uint16_t>(sum[u]>>32);
-						L.wF1_lo()[o] = static_cast<uint32_t>(f1[u]); L.wF1_hi()[o] = static_cast<uint8_t>(f1[u]>>32);
-						L.wFl_lo()[o] = static_cast<uint32_t>(fl[u]); L.wFl_hi()[o] = static_cast<uint8_t>(fl[u]>>32);
+						L.wF_lo()[o] = static_cast<uint32_t>(sum); L.wF_hi()[o] = static_cast<uint16_t>(sum>>32);
+						L.wF1_lo()[o] = static_cast<uint32_t>(f1); L.wF1_hi()[o] = static_cast<uint8_t>(f1>>32);
+						L.wFl_lo()[o] = static_cast<uint32_t>(fl); L.wFl_hi()[o] = static_cast<uint8_t>(fl>>32);
 					}
 				}
-		}
-		#undef DACC_LKN
-		return mask;
-	}
-	// start positions [lo,hi) that the supports of all nodes of stretch s allow in direction rev
-	DEV void stretchRange(uint32_t const s, bool const rev, uint32_t & len, LDSQ uint16_t const * & Lk, int32_t & lo, int32_t & hi) const
-	{
-		len = L.sslen()[s]; Lk = L.links() + L.slink()[s];
-		lo = 0; hi = static_cast<int32_t>(nrows);
-		uint32_t const sh = rev ? 16 : 0;
-		for ( uint32_t j = 0; j < len; ++j )
-		{
-			uint32_t const g = L.nrange()[Lk[rev ? (len-1-j) : j]] >> sh;
-			int32_t const jj = static_cast<int32_t>(j);
-			int32_t const a = static_cast<int32_t>(g&0xFF)-jj, b = static_cast<int32_t>((g>>8)&0xFF)-jj;
-			lo = a > lo ? a : lo; hi = b < hi ? b : hi;
-		}
-		if ( hi < lo ) hi = lo;
-	}
-	DEV void computeStretchFeasLanes(uint32_t const sfrom, uint32_t const sto)
-	{
-		// do the reservations of all stretches fit?
-		bool exact = false;
-		{
-			uint32_t tF = 0, tR = 0;
-			for ( uint32_t c = 2*sfrom; c < 2*sto; c += WSZ )
-			{
-				uint32_t const u = c + lane;
-				uint32_t w = 0; bool const rev = u & 1;
-				if ( u < 2*sto ) { uint32_t len; LDSQ uint16_t const * Lk; int32_t lo, hi; stretchRange(u>>1,rev,len,Lk,lo,hi); w = static_cast<uint32_t>(hi-lo); }
-				tF += wv_sum(rev ? 0u : w); tR += wv_sum(rev ? w : 0u);
 			}
-			exact = (nwF + tF > CT::wcap) || (nwR + tR > CT::wcap);
-		}
-		for ( uint32_t c = 2*sfrom; c < 2*sto; c += WSZ )
-		{
-			uint32_t const u = c + lane;
-			bool const act = u < 2*sto;
-			bool const rev = u & 1;
-			uint32_t const s = u>>1;
-			uint32_t len = 0; int32_t lo = 0, hi = 0;
-			LDSQ uint16_t const * Lk = L.links();
-			if ( act ) stretchRange(s,rev,len,Lk,lo,hi);
-			uint64_t m = 0;
-			uint32_t wF, wR;
-			if ( exact )
-			{
-				if ( act ) m = evalStretchLane(rev,true,len,Lk,lo,hi,0);
-				wF = act && !rev ? dacc_popc64(m) : 0u; wR = act && rev ? dacc_popc64(m) : 0u;
-			}
-			else { wF = act && !rev ? static_cast<uint32_t>(hi-lo) : 0u; wR = act && rev ? static_cast<uint32_t>(hi-lo) : 0u; }
-			uint32_t totF, totR;
-			uint32_t const preF = wv_scan_excl(wF,totF), preR = wv_scan_excl(wR,totR);
-			if ( nwF + totF > CT::wcap || nwR + totR > CT::wcap ) { over(128); return; }
 			if ( act )
 			{
-				uint32_t const wb = rev ? (nwR+preR) : (nwF+preF);
-				uint64_t const mm = evalStretchLane(rev,false,len,Lk,lo,hi,wb);
-				if ( rev ) { L.maskR()[s] = mm; L.woffR()[s] = wb; } else { L.maskF()[s] = mm; L.woffF()[s] = wb; }
+				// the first lane of a stretch in this round adds the round's bits to its mask; the lane with the stretch's first
+				// task sets the offset of its list
+				uint32_t const firstlane = (t0 > c) ? (t0-c) : 0u;
+				if ( static_cast<uint32_t>(lane) == firstlane )
+				{
+					uint32_t const tend = L.toff()[u+1];
+					uint32_t const lastlane = (tend-c < WSZ) ? (tend-c) : static_cast<uint32_t>(WSZ);     // exclusive
+					uint64_t const span = (lastlane-firstlane >= 64) ? ~0ull : ((1ull << (lastlane-firstlane))-1ull);
+					uint64_t const bits = ((okb >> firstlane) & span) << P;
+					if ( rev ) L.maskR()[s] |= bits; else L.maskF()[s] |= bits;
+					if ( t == t0 ) { uint32_t const wo = base + dacc_popc64(okb & mydir & ltmask); if ( rev ) L.woffR()[s] = wo; else L.woffF()[s] = wo; }
+				}
 			}
-			nwF += totF; nwR += totR;
+			nwF += dacc_popc64(okb & ~revb); nwR += dacc_popc64(okb & revb);
+			if ( nwF > CT::wcap || nwR > CT::wcap ) { over(128); return; }
 		}
 		wv_sync();
 	}
@@ -1240,7 +1270,7 @@ struct FastEngine
 	// the same routines run on lane 0 alone for the rare pair that needs its exact stretch set.  Paths live in shared
 	// pools (rc_* / f_*, indexed by a pool-wide id); a lane takes pool entries in chunks of RCH / FCH through an LDS
 	// counter and keeps its chunk list in registers (entry i of an enumeration -> clSlot).
-	enum { RCH = CT::rch, RNW = 4, FCH = CT::fch, FNW = 2 };         // entries per chunk, 64 bit words of chunk ids (8 per word)
+	enum { RCH = CT::rch, RNW = 4, FCH = CT::fch, FNW = CT::fnw };         // entries per chunk, 64 bit words of chunk ids (8 per word)
 	// The chunk ids of an enumeration are a row of bytes in LDS (a register array indexed at run time would end up in
 	// scratch memory): NW*8 chunks per enumeration.
 	template<int NW> struct ChunkList { LDSQ uint8_t * ids; uint32_t n; };
@@ -2014,7 +2044,9 @@ struct FastEngine
 		PROF(*this,8)
 		findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
+		PROF(*this,16)
 		loadTab();
+		PROF(*this,17)
 		computeStretchFeasLanes(0,npool);
 		flags = wv_or(flags); if ( flags ) return false;
 		PROF(*this,9)
@@ -2050,6 +2082,9 @@ struct FastEngine
 				flags = wv_or(flags); if ( flags ) return false;
 				uint32_t tot; uint32_t const sbase = sb + wv_scan_excl(ract ? R.narp : 0u,tot);
 				if ( sb + tot > CT::rccap ) { over(512|0x4000); return false; }
+#if defined(DACC_EMUL)
+				if ( ract ) { FILE * f = ftrav_file(); if ( f ) fprintf(f,"R %d %u %u 0\n",int(CT::maxs),R.nrp,R.narp); }
+#endif
 				if ( ract ) reverseBlockCopy(R,sbase);
 				// blocks of more than 16 entries are sorted with an explicit stack (one lane at a time)
 				uint64_t big = wv_ballot(ract && R.narp > 16);
@@ -2087,6 +2122,9 @@ struct FastEngine
 				forwardEnumerateLane(F,L.fchb() + 8*FNW*fi,V,firstnode,lmax,reinterpret_cast<LDSQ id_t *>(L.lscr()) + 12*lane);
 				if ( flags == (512|0x10000) && F.np < 8*FNW*FCH ) { fover = 1; flags = saved; }   // no pool space left for this tree
 				else flags |= saved;
+#if defined(DACC_EMUL)
+				{ FILE * f = ftrav_file(); if ( f ) fprintf(f,"T %d %u %u %u\n",int(CT::maxs),F.np,F.nfpop,fover); }
+#endif
 			}
 			flags = wv_or(flags); if ( flags ) return false;
 			uint64_t const fo = wv_ballot(fover);
@@ -2098,6 +2136,16 @@ struct FastEngine
 				if ( bw == 1 ) { over(512|0x10000); return false; }
 				bw = 1;
 				continue;
+			}
+			if ( fo )
+			{
+				// the lanes that lost the race for chunks have left holes in the pool and the chunk counter beyond its end
+				if ( nb == 1 && bw != 1 ) { bw = 1; continue; }       // a single tree is kept: run it again with the pool to itself
+				uint32_t mx = 0;
+				if ( fact && static_cast<uint32_t>(lane) < nb ) for ( uint32_t i = 0; i < F.C.n; ++i ) { uint32_t const id = F.C.ids[i]; mx = id+1 > mx ? id+1 : mx; }
+				mx = wv_max(mx);
+				if ( lane == 0 ) L.ctr()[1] = mx;      // exact trees of the batch's pairs go behind the kept trees
+				wv_sync();
 			}
 			// a batch that did not fit sets the width of the next ones
 			bw = fo ? nb : ((2*bw < WSZ) ? 2*bw : static_cast<uint32_t>(WSZ));
@@ -2215,6 +2263,9 @@ struct FastEngine
 		PROF(*this,13)
 		FSTAT_MX(0,mao); FSTAT_MX(1,npre); FSTAT_MX(2,nn); FSTAT_MX(3,n0); FSTAT_MX(4,npool); FSTAT_MX(5,nlinks); FSTAT_MX(6,nwF); FSTAT_MX(7,nwR);
 		FSTAT_MX(8,rstop); FSTAT_MX(9,nF); FSTAT_MX(10,nL); FSTAT_ADD(11,1); FSTAT_MX(12,nc);
+#if defined(DACC_EMUL)
+		if ( lane == 0 ) { FILE * f = ftrav_file(); if ( f ) { uint32_t nlv = 0; for ( uint32_t i = 0; i < nL; ++i ) nlv += L.lnode()[i] != 0xFFFF; fprintf(f,"%d %u %u %u %u %u %u %u %u %u %u %u %u\n",int(CT::maxs),mao,npre,nn,n0,npool,nF,nL,nlv,rstop,nwF,nwR,nc); fflush(f); } }
+#endif
 		return nc != 0;
 	}
 
@@ -2416,7 +2467,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	uint32_t const ap2 = next_pow2(nact < 2 ? 2 : nact);
 	for ( uint32_t i = nact + lane; i < ap2; i += WSZ ) L.pre()[i] = ~0ull;
 	wv_sync();
-	wv_bitonic_sort(L.pre(),ap2);
+	wv_sort_keys<CT::precap>(L.pre(),nact);
 	uint32_t mao = 0;
 	if ( nact )
 	{
@@ -2567,5 +2618,8 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	#undef FFAIL
 }
 
+#if defined(DACC_EMUL)
+#undef over
+#endif
 }
 #endif

@@ -26,6 +26,7 @@
   static inline int wv_lane() { return 0; }
   static inline void wv_sync() {}
   static inline uint32_t wv_scan_excl(uint32_t v, uint32_t & total) { total = v; return 0; }
+  static inline uint32_t wv_scan_flag(bool p, uint32_t & total) { total = p ? 1u : 0u; return 0; }
   static inline uint32_t wv_sum(uint32_t v) { return v; }
   static inline uint64_t wv_sum64(uint64_t v) { return v; }
   static inline uint32_t wv_max(uint32_t v) { return v; }
@@ -56,18 +57,36 @@
   DEV int wv_lane() { return threadIdx.x & 63; }
   // one wavefront per workgroup: barrier + LDS/global visibility inside the wavefront
   DEV void wv_sync() { __syncthreads(); }
+  // Cross-lane data movement inside the VALU (DPP: row_shr inside rows of 16 lanes, row_bcast15 / row_bcast31 across rows,
+  // v_readlane for the result) instead of ds_bpermute round trips through the LDS pipeline: a scan or reduction is six
+  // dependent VALU instructions.  `old` (the value a lane keeps when its DPP source lane does not exist) is the identity.
+  #define DACC_DPP(old_,src_,ctrl_,rmask_) static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old_),static_cast<int>(src_),ctrl_,rmask_,0xF,false))
+  enum { DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143 };
+  // inclusive prefix "sums" under OP over the 64 lanes (OP associative and commutative, ID its identity)
+  #define DACC_DPP_SCAN(x_,OP,ID) \
+	{ uint32_t y_; \
+	  y_ = DACC_DPP(ID,x_,DPP_ROW_SHR1,0xF); x_ = OP(x_,y_); \
+	  y_ = DACC_DPP(ID,x_,DPP_ROW_SHR2,0xF); x_ = OP(x_,y_); \
+	  y_ = DACC_DPP(ID,x_,DPP_ROW_SHR4,0xF); x_ = OP(x_,y_); \
+	  y_ = DACC_DPP(ID,x_,DPP_ROW_SHR8,0xF); x_ = OP(x_,y_); \
+	  y_ = DACC_DPP(ID,x_,DPP_ROW_BCAST15,0xA); x_ = OP(x_,y_); \
+	  y_ = DACC_DPP(ID,x_,DPP_ROW_BCAST31,0xC); x_ = OP(x_,y_); }
+  #define DACC_OP_ADD(a_,b_) ((a_)+(b_))
+  #define DACC_OP_MAX(a_,b_) ((a_) > (b_) ? (a_) : (b_))
+  #define DACC_OP_OR(a_,b_) ((a_)|(b_))
   DEV uint32_t wv_scan_excl(uint32_t v, uint32_t & total)
   {
 	uint32_t x = v;
-	int const lane = wv_lane();
-	#pragma unroll
-	for ( int d = 1; d < 64; d <<= 1 )
-	{
-		uint32_t const y = __shfl_up(x,d,64);
-		if ( lane >= d ) x += y;
-	}
-	total = __shfl(x,63,64);
+	DACC_DPP_SCAN(x,DACC_OP_ADD,0u)
+	total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(x),63));
 	return x - v;
+  }
+  // exclusive count of set predicates below this lane (ballot + mbcnt: no cross-lane data movement at all)
+  DEV uint32_t wv_scan_flag(bool const p, uint32_t & total)
+  {
+	uint64_t const b = __ballot(p);
+	total = static_cast<uint32_t>(__popcll(b));
+	return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(b>>32),__builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(b),0u));
   }
   // value of the first active lane as a wave-uniform (scalar) value: keeps the control flow that depends on it uniform
   DEV uint32_t wv_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -78,9 +97,8 @@
   }
   DEV uint32_t wv_sum(uint32_t v)
   {
-	#pragma unroll
-	for ( int d = 32; d >= 1; d >>= 1 ) v += __shfl_xor(v,d,64);
-	return wv_uni(v);
+	DACC_DPP_SCAN(v,DACC_OP_ADD,0u)
+	return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v),63));
   }
   DEV uint64_t wv_sum64(uint64_t v)
   {
@@ -90,9 +108,8 @@
   }
   DEV uint32_t wv_max(uint32_t v)
   {
-	#pragma unroll
-	for ( int d = 32; d >= 1; d >>= 1 ) { uint32_t const o = __shfl_xor(v,d,64); v = o > v ? o : v; }
-	return wv_uni(v);
+	DACC_DPP_SCAN(v,DACC_OP_MAX,0u)
+	return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v),63));
   }
   DEV uint64_t wv_max64(uint64_t v)
   {
@@ -109,20 +126,26 @@
   DEV int wv_any(int p) { return __any(p); }
   DEV uint32_t wv_or(uint32_t v)
   {
-	#pragma unroll
-	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
-	return wv_uni(v);
+	DACC_DPP_SCAN(v,DACC_OP_OR,0u)
+	return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v),63));
   }
   DEV uint64_t wv_or64(uint64_t v)
   {
-	#pragma unroll
-	for ( int d = 32; d >= 1; d >>= 1 ) v |= __shfl_xor(v,d,64);
-	return wv_uni64(v);
+	uint32_t lo = static_cast<uint32_t>(v), hi = static_cast<uint32_t>(v>>32);
+	DACC_DPP_SCAN(lo,DACC_OP_OR,0u)
+	DACC_DPP_SCAN(hi,DACC_OP_OR,0u)
+	uint32_t const l = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(lo),63)), h = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(hi),63));
+	return (static_cast<uint64_t>(h)<<32) | l;
   }
   DEV uint64_t wv_ballot(int p) { return __ballot(p); }
   DEV uint64_t wv_lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
-  DEV uint32_t wv_bcast(uint32_t v, int src) { return wv_uni(__shfl(v,src,64)); }
-  DEV uint64_t wv_bcast64(uint64_t v, int src) { return wv_uni64(__shfl(v,src,64)); }
+  DEV uint32_t wv_bcast(uint32_t v, int src) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v),__builtin_amdgcn_readfirstlane(src))); }   // src is wave-uniform
+  DEV uint64_t wv_bcast64(uint64_t v, int src)
+  {
+	int const sl = __builtin_amdgcn_readfirstlane(src);
+	uint32_t const lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v)),sl)), hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(v>>32)),sl));
+	return (static_cast<uint64_t>(hi)<<32) | lo;
+  }
   DEV uint32_t wv_shfl(uint32_t v, int src) { return __shfl(v,src,64); }
   DEV uint64_t wv_shfl64(uint64_t v, int src) { return __shfl(v,src,64); }
   DEV int dacc_popc64(uint64_t v) { return __popcll(v); }
@@ -244,6 +267,71 @@ DEV void wv_bitonic_sort_idx(uint32_t * I, uint64_t const * K, uint32_t const n)
 			}
 			wv_sync();
 		}
+}
+
+#if WSZ == 64
+// ascending sort of n <= 64*R distinct 64-bit keys held in registers: lane l keeps elements l*R .. l*R+R-1 (missing ones
+// are +infinity), so the compare-exchange steps at distances below R stay inside a lane and the others exchange whole
+// registers with the partner lane; the memory is touched once for the load and once for the store.  The step structure
+// is a run time loop (the code stays small), only the register indices are compile time constants.
+template<int R, int J> DEV void wv_sort_inlane(uint64_t (&v)[R], uint32_t const base, uint32_t const k)
+{
+	#pragma unroll
+	for ( int r = 0; r < R; ++r )
+		if ( (r & J) == 0 )
+		{
+			uint64_t const a = v[r], b = v[r|J];
+			bool const up = ((base + r) & k) == 0;
+			bool const sw = (a > b) == up;
+			v[r] = sw ? b : a; v[r|J] = sw ? a : b;
+		}
+}
+template<int R, typename PT>
+DEV void wv_sort_regs(PT A, uint32_t const n)
+{
+	static_assert(R == 2 || R == 4 || R == 8 || R == 16,"elements per lane");
+	uint32_t const lane = wv_lane(), base = lane*R;
+	uint64_t v[R];
+	#pragma unroll
+	for ( int r = 0; r < R; ++r ) v[r] = (base + r < n) ? A[base+r] : ~0ull;
+	uint32_t n2 = 2; while ( n2 < n ) n2 <<= 1;
+	for ( uint32_t k = 2; k <= n2; k <<= 1 )
+	{
+		for ( uint32_t j = k>>1; j >= static_cast<uint32_t>(R); j >>= 1 )
+		{
+			uint32_t const m = j/R;
+			bool const keepmin = ((lane & m) == 0) == ((base & k) == 0);
+			#pragma unroll
+			for ( int r = 0; r < R; ++r )
+			{
+				uint64_t const p = wv_shfl64(v[r],static_cast<int>(lane ^ m));
+				bool const plt = p < v[r];
+				v[r] = (plt == keepmin) ? p : v[r];
+			}
+		}
+		uint32_t const h = k>>1;
+		if ( R > 8 && h >= 8 ) wv_sort_inlane<R,(R > 8 ? 8 : 1)>(v,base,k);
+		if ( R > 4 && h >= 4 ) wv_sort_inlane<R,(R > 4 ? 4 : 1)>(v,base,k);
+		if ( R > 2 && h >= 2 ) wv_sort_inlane<R,(R > 2 ? 2 : 1)>(v,base,k);
+		wv_sort_inlane<R,1>(v,base,k);
+	}
+	wv_sync();
+	#pragma unroll
+	for ( int r = 0; r < R; ++r ) if ( base + r < n ) A[base+r] = v[r];
+	wv_sync();
+}
+#endif
+// ascending sort of n distinct 64-bit keys in memory (all lanes call); cap = compile time bound of n
+template<uint32_t CAP, typename PT>
+DEV void wv_sort_keys(PT A, uint32_t const n)
+{
+#if WSZ == 64
+	if ( CAP <= 128 || n <= 128 ) { wv_sort_regs<2>(A,n); return; }
+	if ( CAP <= 256 || n <= 256 ) { wv_sort_regs<4>(A,n); return; }
+	if ( CAP <= 512 || n <= 512 ) { wv_sort_regs<8>(A,n); return; }
+	if ( CAP <= 1024 || n <= 1024 ) { wv_sort_regs<16>(A,n); return; }
+#endif
+	wv_bitonic_sort_n(A,n);
 }
 
 HDEV uint32_t next_pow2(uint32_t v)

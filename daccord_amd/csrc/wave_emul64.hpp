@@ -133,6 +133,7 @@ static inline uint32_t wv_scan_excl(uint32_t v, uint32_t & total)
 	uint32_t pre = 0, tot = 0; for ( int i = 0; i < 64; ++i ) { if ( i < me ) pre += static_cast<uint32_t>(V[i]); tot += static_cast<uint32_t>(V[i]); }
 	total = tot; return pre;
 }
+static inline uint32_t wv_scan_flag(bool p, uint32_t & total) { return wv_scan_excl(p ? 1u : 0u,total); }
 static inline uint32_t wv_sum(uint32_t v) { uint64_t const * V = wave_collect(v,3); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s += static_cast<uint32_t>(V[i]); return s; }
 static inline uint64_t wv_sum64(uint64_t v) { uint64_t const * V = wave_collect(v,4); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s += V[i]; return s; }
 static inline uint32_t wv_max(uint32_t v) { uint64_t const * V = wave_collect(v,5); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s = static_cast<uint32_t>(V[i]) > s ? static_cast<uint32_t>(V[i]) : s; return s; }

@@ -52,13 +52,14 @@ def lib():
         L.dacc_debug_windows.argtypes = [vp, vp, C.c_uint64, vp]
         L.dacc_debug_tables.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
         L.dacc_debug_profile.argtypes = [vp, vp]
+        L.dacc_debug_retry.argtypes = [vp, vp, C.c_uint64, vp]
         _lib = L
     return _lib
 
 
 EXPORTS = ["dacc_create", "dacc_destroy", "dacc_set_error_profile", "dacc_load_db", "dacc_submit_piles", "dacc_collect",
            "dacc_release", "dacc_last_error", "dacc_pile_select", "dacc_last_timing", "dacc_rerun_resident",
-           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile"]
+           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile", "dacc_debug_retry"]
 
 
 def _ptr(a):
@@ -152,6 +153,14 @@ class Engine:
         out = np.zeros(32, dtype=np.uint64)
         self._chk(self.L.dacc_debug_profile(self.h, _ptr(out)))
         return out
+
+    def debug_retry(self):
+        n = C.c_uint64()
+        self._chk(self.L.dacc_debug_retry(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            self._chk(self.L.dacc_debug_retry(self.h, _ptr(out), n.value, C.byref(n)))
+        return out.reshape(-1, 4)
 
     def tables(self, klimit_n=128):
         n = C.c_uint64()

@@ -172,6 +172,10 @@ int  dacc_debug_tables(dacc_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *n, 
  * built with -DDACC_PROFILE). */
 int  dacc_debug_profile(dacc_ctx *ctx, uint64_t *out32);
 
+/* Debugging hook (environment DACC_DEBUG_RETRY=1 at dacc_create): quadruples (window, flags, strings, filter frequency)
+ * of the windows the last LDS capacity tier handed to the generic engine in the last run. */
+int  dacc_debug_retry(dacc_ctx *ctx, uint32_t *out, uint64_t cap, uint64_t *n);
+
 #ifdef __cplusplus
 }
 #endif

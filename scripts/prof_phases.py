@@ -8,7 +8,7 @@ from daccord_amd._structs import default_params
 from daccord_amd.synth import SynthData
 NAMES = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors", "pair-gen (lanes)", "gapfill", "pair-replay (lane 0)",
          "stretches", "cand+tab+stretchfeas", "F trees (lanes)", "R blocks (lanes)", "tail", "cand-errors", "align+emit", "-",
-         " s:predcounts", " s:walk1", " s:walk2", " s:splits", " s:sort+uniq"]
+         " candidates+pieces", " loadTab", " inst:generate", " inst:sort last", " inst:sort pre"]
 EXTRA = {21: "cut sequences continued", 22: "exact pairs", 23: "serial combines", 25: "pairs", 26: "F batches", 27: "pair rounds", 28: "batch restarts"}
 npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 d = SynthData(250000, 1000, 5000, seed=3)
@@ -21,7 +21,7 @@ for k in (8, 14):
     print("k=%d piles=%d windows=%d blocks=%d bases=%d wall=%.2fs trace=%.1fms window=%.1fms vote=%.1fms h2d=%.1fms tiers_out=%s tiers_ms=%s" % (
         k, npiles, t.nwindows, t.nblocks, len(ba), t1, t.trace_ms, t.window_ms, t.vote_ms, t.h2d_ms, list(t.tier_out), [round(x, 1) for x in t.tier_ms]))
     print("  status", dict(zip(*np.unique(w["status"], return_counts=True))), "ff", dict(zip(*np.unique(w["filterfreq"][w["status"] == 1], return_counts=True))), "mean mao %.1f" % w["mao"].mean())
-    tot = pr[:15].sum()
+    tot = pr[:15].sum() + pr[16:18].sum()
     if tot > 0:
         for i, n in enumerate(NAMES):
             print("  %-16s %6.2f%%  %10.0f cyc/window" % (n, 100 * pr[i] / tot, pr[i] / max(1, t.nwindows)))
