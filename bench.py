@@ -4,18 +4,29 @@
 One "step" = one pass of the hot path (trace expansion -> per-window consensus -> pile vote ->
 fragments on the host) over one batch of synthetic piles that is already resident in HBM when the
 timed region starts.  Workload at N=1 = BASELINE.json configs[1]: synthetic 10k A-reads x 10 kb x 20x
-PacBio-like piles, k=14.  With N GPUs every rank processes its own shard of that size (piles are
-independent: static sharding, no data-path collective; weak scaling) and rank 0 gathers the corrected
-bases over RCCL at the end of every step.
+PacBio-like piles, k=14.
+
+Multi-GPU: ONE data set, sharded over the ranks by A-read range exactly like the reference's
+`-J g,G` option (src/daccord.cpp:1156-1183, daccord_amd/shard.py); piles are independent, so there is no
+data-path collective, and rank 0 gathers the corrected fragments over RCCL at the end of every step.
+  --scaling weak   (default): the data set has N x --reads A-reads (fixed work per GPU)
+  --scaling strong          : the data set has --reads A-reads in total
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, backend nccl = RCCL).
 
 Prints ONE JSON line on rank 0 (see the driver contract), including
-  roofline     : algorithmic bytes of the dominant kernel / its HIP-event duration vs the 8 TB/s HBM peak
-  cpu_baseline : the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's
-                 cores on a bounded sample of the same piles (N=1, rank 0 only).
+  roofline     : algorithmic bytes of the dominant kernel / its HIP-event duration vs the 8 TB/s HBM peak, the HBM
+                 traffic and issue-slot counters of the same kernel from the committed PMC passes (profiles/)
+  cpu_baseline : the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores on a
+                 bounded sample of the same piles, single thread and all cores (N=1, rank 0 only)
+  parity       : SHA-256 of the GPU FASTA of the first 1000 piles against the oracle's committed digest
+                 (tests/golden/scale_cfg2.json, default workload only) and the live oracle sample
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,19 +34,37 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10000, help="A-reads (= piles) per GPU")
+    ap.add_argument("--reads", type=int, default=10000, help="A-reads (= piles) per GPU (weak) or in total (strong)")
     ap.add_argument("--readlen", type=int, default=10000)
     ap.add_argument("--coverage", type=float, default=20.0)
     ap.add_argument("--k", type=int, default=14)
     ap.add_argument("--seed", type=int, default=3)
-    ap.add_argument("--cpu-piles", type=int, default=0, help="piles in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--ont", action="store_true", help="config 5 error mix (ins/del/sub = 1/3 each)")
+    return ap.parse_args()
+
+
+def respawn(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks (one per GPU) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(respawn(args))
 
     import numpy as np
     import torch
@@ -51,34 +80,37 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from daccord_amd import engine
+    from daccord_amd import engine, shard
     from daccord_amd._structs import default_params
     from daccord_amd.synth import SynthData
 
-    # synthetic shard of this rank (seed differs per rank)
-    genome = int(args.reads * args.readlen / args.coverage)
+    # one synthetic data set, the same on every rank; rank g corrects the -J g,G part of it
+    total_reads = args.reads * world if args.scaling == "weak" else args.reads
+    genome = int(total_reads * args.readlen / args.coverage)
     ncpu = os.cpu_count() or 1
     t0 = time.time()
-    d = SynthData(genome, args.reads, args.readlen, seed=args.seed + rank, nthreads=max(1, ncpu // max(world, 1)))
-    ovl, piles = engine.pile_select(d.ovl, d.piles)
+    skw = dict(ins_frac=1 / 3.0, del_frac=1 / 3.0, sub_frac=1 / 3.0) if args.ont else {}
+    d = SynthData(genome, total_reads, args.readlen, seed=args.seed, nthreads=max(1, ncpu // max(world, 1)), **skw)
+    ovl, allpiles = engine.pile_select(d.ovl, d.piles)
+    piles = shard.shard_piles(allpiles, rank, world)
     tgen = time.time() - t0
 
     p = default_params(k=args.k, device=local_rank)
     E = engine.Engine(p)
     E.set_error_profile(*d.error_profile())
-    E.load_db(d.bps, d.boff, d.rlen)
+    E.load_db(d.bps, d.boff, d.rlen)                # read store replicated on every GPU (B reads are arbitrary)
     t0 = time.time()
     frags, bases = E(piles, ovl, d.trace)          # H2D + first pass (not timed)
     tfirst = time.time() - t0
     tm0 = E.timing()
 
-    from daccord_amd import shard
+    gathered = [None, None]
 
     def step():
         E.rerun()
         fr, ba = E.collect()
         # the only communication of a step: corrected fragments of all ranks to rank 0 (RCCL gather; no-op at N=1)
-        shard.gather_fragments(fr, ba, device="cuda")
+        gathered[0], gathered[1] = shard.gather_fragments(fr, ba, device="cuda")
 
     for _ in range(args.warmup):
         step()
@@ -109,6 +141,8 @@ def main():
 
     if rank == 0:
         t = E.timing()
+        allfr, allba = (gathered[0], gathered[1]) if gathered[0] is not None else (frags, bases)
+        assert float(len(allba)) == total_bases, "gathered bases do not add up"
         ms_per_step = 1e3 * dt / args.steps
         value = total_bases * args.steps / dt / 1e6
         kern = {"k_trace": tsum / args.steps, "k_vote": vsum / args.steps,
@@ -117,48 +151,111 @@ def main():
         dom = max(kern, key=kern.get)
         # algorithmic bytes (every input byte once + corrected bases) of the launch / its duration
         achieved = t.algo_bytes / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
-        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
-        # profiles/r01_pmc/): only quoted when it was collected on this very workload and kernel
-        traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 7), "traffic": None,
+                "algo_bytes_per_launch": int(t.algo_bytes), "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
+                "window_ms_all_tiers": round(wsum / args.steps, 3),
+                "windows_handed_on": {"tier1": touts[0], "tier2": touts[1], "tier3_to_generic": touts[2]}}
+        # HBM traffic and issue counters of the dominant kernel from the PMC passes (rocprofv3 --pmc, separate runs,
+        # scripts/gpu_pmc.sh -> profiles/r02_pmc_summary.json): only quoted when collected on this very workload
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
             wl = pm["workload"]
-            if (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) == (args.reads, args.readlen, args.coverage, args.k) and pm["kernel"] == dom:
-                traffic = int(pm["traffic_bytes_per_launch"])
+            if (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) == (args.reads, args.readlen, args.coverage, args.k) and dom in pm["kernels"]:
+                kk = pm["kernels"][dom]
+                roof["traffic"] = int(kk["traffic_bytes_per_launch"])
+                for key in ("valu_issue_frac", "salu_issue_frac", "lds_issue_frac", "wait_frac", "resident_waves_per_cu", "pmc_kernel_ms"):
+                    if key in kk:
+                        roof[key] = kk[key]
+                roof["traffic_all_kernels"] = {k: int(v["traffic_bytes_per_launch"]) for k, v in pm["kernels"].items()}
+                roof["pmc_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this workload)"
         except Exception:
-            traffic = None
+            pass
         res = {
             "metric": "corrected Mbase/s (whole node), synthetic 20x PacBio piles",
             "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64+f64", "data": "synthetic",
-            "config": {"workload": "synthetic %d A-reads x %d b x %.0fx per GPU, 15%% error (ins 80/del 13.3/sub 6.7), k=%d, w=40, a=10, tspace=100"
-                       % (args.reads, args.readlen, args.coverage, args.k),
-                       "piles_per_gpu": int(len(piles)), "overlaps_per_gpu": int(len(ovl)), "windows_per_gpu": int(t.nwindows),
-                       "trace_blocks_per_gpu": int(t.nblocks), "corrected_bases_per_gpu": int(len(bases)),
-                       "sharding": "static by A-read, no data-path collective; RCCL gather of corrected bases per step"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                         "algo_bytes_per_launch": int(t.algo_bytes), "kernel_ms": {k: round(v, 3) for k, v in kern.items()}, "window_ms_all_tiers": round(wsum / args.steps, 3),
-                         "windows_handed_on": {"tier1": touts[0], "tier2": touts[1], "tier3_to_generic": touts[2]}},
+            "config": {"workload": "synthetic %d A-reads x %d b x %.0fx%s, 15%% error (%s), k=%d, w=40, a=10, tspace=100"
+                       % (total_reads, args.readlen, args.coverage, " (%d per GPU)" % args.reads if args.scaling == "weak" and world > 1 else "",
+                          "ins/del/sub 1/3 each" if args.ont else "ins 80/del 13.3/sub 6.7", args.k),
+                       "piles_total": int(len(allpiles)), "piles_rank0": int(len(piles)), "overlaps_total": int(len(ovl)), "windows_rank0": int(t.nwindows),
+                       "trace_blocks_rank0": int(t.nblocks), "corrected_bases_total": int(total_bases),
+                       "sharding": "one data set, A-read ranges as -J g,G (daccord.cpp:1156-1183), no data-path collective; RCCL gather of corrected fragments per step"},
+            "roofline": roof,
             "setup_s": {"generate": round(tgen, 2), "first_pass_incl_h2d": round(tfirst, 2), "h2d_ms": round(tm0.h2d_ms, 2)},
         }
+        # ---- parity: full-batch digest, the oracle's committed digest of the first 1000 piles, live oracle sample ----
+        par = {"gpu_fasta_sha256_all": hashlib.sha256(engine.fasta(allfr, allba).encode()).hexdigest(), "piles_all": int(len(allpiles))}
+        gold = os.path.join(ROOT, "tests", "golden", "scale_cfg2.json")
+        default_set = (total_reads, args.readlen, args.coverage, args.k, args.seed, args.ont) == (10000, 10000, 20.0, 14, 3, False)
+        if default_set and os.path.exists(gold):
+            G = json.load(open(gold))["runs"][0]
+            n = G["npiles"]
+            lim = int(allpiles[n - 1]["aread"])
+            sel = allfr[allfr["aread"] <= lim]
+            h = hashlib.sha256(engine.fasta(sel, allba).encode()).hexdigest()
+            par.update({"piles_compared": n, "gpu_fasta_sha256": h, "oracle_fasta_sha256": G["fasta_sha256"], "identical": h == G["fasta_sha256"],
+                        "oracle_source": "tests/golden/scale_cfg2.json (oracle run in the build container, tests/golden/make_golden_scale.py)"})
+        res["parity"] = par
         if world == 1 and not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle
             O = pyoracle.Oracle(p)
             O.set_error_profile(*d.error_profile())
             O.load_db(d.bps, d.boff, d.rlen)
-            # bounded sample: one pile per thread, at most 32 threads (about 10-30 s of CPU work at k=14)
-            nthr = min(ncpu, 32)
-            ncp = min(len(piles), args.cpu_piles or nthr)
+            # bounded samples of the same batch (a pile of this workload costs the oracle about 5-10 s on one thread):
+            # (a) one thread, (b) all CPUs this process may use (cgroup quota / affinity; the logical CPU count of the
+            # host is reported beside it), schedule(dynamic,1) over A-reads like src/daccord.cpp:2109.  (b) runs in two
+            # stages so that a host that delivers fewer cores than it shows cannot blow the time budget.  The piles of
+            # (b) lie behind the first 1000, which the committed digest covers.
+            def usable_cpus():
+                n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else ncpu
+                try:
+                    q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                    if q != "max":
+                        n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+                except Exception:
+                    pass
+                return max(1, n)
             tc = time.perf_counter()
-            fo, bo = O.run(piles[:ncp], ovl, d.trace, nthreads=nthr)
-            tcpu = time.perf_counter() - tc
-            same = engine.fasta(frags[frags["aread"] < piles[ncp - 1]["aread"] + 1], bases) == pyoracle.fasta(fo, bo) if ncp else True
-            res["cpu_baseline"] = {"value": round(len(bo) / tcpu / 1e6, 5), "unit": "Mbase/s", "cores": nthr, "kind": "port", "host_logical_cpus": ncpu,
-                                   "sample": "first %d piles of the same batch, oracle with %d OpenMP threads, %.1f s" % (ncp, nthr, tcpu),
-                                   "identical_to_gpu_on_sample": bool(same)}
+            f1, b1 = O.run(piles[:1], ovl, d.trace, nthreads=1)
+            t1 = time.perf_counter() - tc
+            n1 = 1
+            if t1 < args.cpu_seconds / 2:
+                n1 = max(1, min(len(piles), int(args.cpu_seconds / max(t1, 1e-3))))
+                tc = time.perf_counter()
+                f1, b1 = O.run(piles[:n1], ovl, d.trace, nthreads=1)
+                t1 = time.perf_counter() - tc
+            per_pile = t1 / n1
+            nthr = usable_cpus()
+            first = min(1000, max(0, len(piles) - 1))
+            nall = min(len(piles) - first, nthr)
+            tc = time.perf_counter()
+            fa, ba = O.run(piles[first:first + nall], ovl, d.trace, nthreads=nthr)
+            ta = time.perf_counter() - tc
+            if ta < args.cpu_seconds / 3:
+                more = min(len(piles) - first, int(nall * args.cpu_seconds / max(ta, 1e-3)))
+                if more > nall:
+                    nall = more
+                    tc = time.perf_counter()
+                    fa, ba = O.run(piles[first:first + nall], ovl, d.trace, nthreads=nthr)
+                    ta = time.perf_counter() - tc
+            lo, hi = int(piles[first]["aread"]), int(piles[first + nall - 1]["aread"])
+            gsel = frags[(frags["aread"] >= lo) & (frags["aread"] <= hi)]
+            same_all = engine.fasta(gsel, bases) == pyoracle.fasta(fa, ba)
+            g1 = frags[frags["aread"] <= int(piles[n1 - 1]["aread"])]
+            same_1 = engine.fasta(g1, bases) == pyoracle.fasta(f1, b1)
+            res["cpu_baseline"] = {
+                "value": round(len(ba) / ta / 1e6, 5), "unit": "Mbase/s", "cores": nthr, "kind": "port", "host_logical_cpus": ncpu,
+                "parallel_speedup_over_single_thread": round((len(ba) / ta) / max(len(b1) / t1, 1e-12), 2),
+                "sample": "piles %d..%d of the same batch (%d piles, %d windows each), oracle with %d OpenMP threads schedule(dynamic,1), %.1f s"
+                          % (first, first + nall - 1, nall, int(t.nwindows // max(1, len(piles))), nthr, ta),
+                "single_thread": {"value": round(len(b1) / t1 / 1e6, 6), "cores": 1, "sample": "first %d pile(s), %.1f s" % (n1, t1)},
+                "identical_to_gpu_on_sample": bool(same_all and same_1), "piles_compared_live": int(nall + n1),
+                "note": "the oracle follows the reference and recomputes stretches, feasibility and both path enumerations for every "
+                        "(first,last) k-mer pair; the GPU path caches them per k-mer, so the ratio is not like for like",
+            }
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -145,10 +145,35 @@ __global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const
 #endif
 }
 
+// exclusive scan of one value per thread over the 256 threads of the workgroup (4 wavefronts): DPP scan inside a
+// wavefront, the four wavefront totals through LDS; MAXOP: running maximum instead of a sum
+template<bool MAXOP>
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t const v, uint32_t * part4, uint32_t & total)
+{
+	uint32_t const wave = threadIdx.x >> 6;
+	uint32_t x = v;
+	if ( MAXOP ) { DACC_DPP_SCAN(x,DACC_OP_MAX,0u) } else { DACC_DPP_SCAN(x,DACC_OP_ADD,0u) }
+	// x = inclusive value of this lane; the exclusive one is the inclusive value of the lane before
+	uint32_t excl = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0,static_cast<int>(x),0x138 /* wave_shr:1 */,0xF,0xF,false));
+	__syncthreads();
+	if ( (threadIdx.x & 63) == 63 ) part4[wave] = x;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+	#pragma unroll
+	for ( uint32_t i = 0; i < 4; ++i )
+	{
+		uint32_t const t = part4[i];
+		if ( i < wave ) base = MAXOP ? (t > base ? t : base) : (base + t);
+		tot = MAXOP ? (t > tot ? t : tot) : (tot + t);
+	}
+	total = tot;
+	return MAXOP ? (excl > base ? excl : base) : (base + excl);
+}
+
 // one workgroup per pile
 __global__ void __launch_bounds__(256) k_vote(VoteBatch B)
 {
-	__shared__ uint32_t part[256];
+	__shared__ uint32_t part4[4];
 	uint32_t const pi = blockIdx.x;
 	DevPile const pile = B.piles[pi];
 	uint32_t const np = pileNpos(pile);
@@ -157,24 +182,58 @@ __global__ void __launch_bounds__(256) k_vote(VoteBatch B)
 	__syncthreads();
 	// contiguous chunk per thread: counts, then a block-wide exclusive scan
 	uint32_t const chunk = (np + 255)/256;
-	uint32_t const p0 = tid*chunk, p1 = (p0+chunk < np) ? (p0+chunk) : np;
+	uint32_t const p0 = tid*chunk < np ? tid*chunk : np, p1 = (p0+chunk < np) ? (p0+chunk) : np;
 	uint32_t sum = 0;
 	for ( uint32_t p = p0; p < p1; ++p ) { uint32_t const n = votePass2(B,pile,p,0); B.oc[pile.posbase+p] = n; sum += n; }
-	part[tid] = sum;
-	__syncthreads();
-	if ( tid == 0 ) { uint32_t run = 0; for ( uint32_t i = 0; i < 256; ++i ) { uint32_t const t = part[i]; part[i] = run; run += t; } if ( run > 2*np+64 ) atomicOr(B.errflag,2u); }
-	__syncthreads();
-	uint32_t run = part[tid];
-	uint32_t const total = part[255] + ((tid == 255) ? 0 : 0);
-	(void)total;
+	uint32_t total;
+	uint32_t run = block_scan_excl<false>(sum,part4,total);
+	bool const fits = total <= 2*np+64;
+	if ( !fits && tid == 0 ) atomicOr(B.errflag,2u);
 	uint64_t const symbase = 2*pile.posbase + 64ull*pi;
 	for ( uint32_t p = p0; p < p1; ++p ) { B.ocs[pile.posbase+p] = run; run += B.oc[pile.posbase+p]; }
-	__syncthreads();
-	bool const fits = (*B.errflag & 2u) == 0;
 	if ( fits )
 		for ( uint32_t p = p0; p < p1; ++p ) votePass2(B,pile,p,B.outsym+symbase+B.ocs[pile.posbase+p]);
 	__syncthreads();
-	if ( tid == 0 ) { if ( fits ) voteRuns(B,pile,pi); else B.nfrag[pi] = 0; }
+	// runs of consecutive positions with elements, kept if last-first >= 100 (HandleContext.hpp:2590-2612): every thread
+	// walks its chunk; the start of the run that is open at the chunk's first position comes from a running maximum
+	// over the chunks before it (start position + 1, 0 = none)
+	uint8_t const * has = B.has + pile.posbase;
+	uint32_t laststart = 0; bool open = false;
+	for ( uint32_t p = p0; p < p1; ++p )
+		if ( has[p] && (p == 0 || !has[p-1]) ) laststart = p+1;
+	uint32_t dummy;
+	uint32_t const instart = block_scan_excl<true>(laststart,part4,dummy);
+	(void)open;
+	uint32_t cur = instart;       // start+1 of the run a position of this chunk belongs to
+	uint32_t nfr = 0;
+	for ( int pass = 0; pass < 2; ++pass )
+	{
+		uint32_t fbase = 0, ftot = 0;
+		if ( pass == 1 ) { fbase = block_scan_excl<false>(nfr,part4,ftot); if ( tid == 0 ) B.nfrag[pi] = fits ? ftot : 0; if ( !fits ) break; }
+		cur = instart; uint32_t k = 0;
+		VoteFragment * F = B.frags + B.fragbase[pi];
+		for ( uint32_t p = p0; p < p1; ++p )
+		{
+			if ( ! has[p] ) continue;
+			if ( p == 0 || !has[p-1] ) cur = p+1;
+			if ( p+1 == np || !has[p+1] )
+			{
+				uint32_t const first = cur-1, q = p;
+				if ( q-first >= 100 )
+				{
+					uint32_t const so = B.ocs[pile.posbase+first];
+					uint32_t const eo = B.ocs[pile.posbase+q] + B.oc[pile.posbase+q];
+					uint32_t const len = eo-so;
+					if ( B.P.producefull || len >= B.P.minlen )
+					{
+						if ( pass == 1 ) { VoteFragment & f = F[fbase+k]; f.first = first; f.last = q; f.len = len; f.pad = 0; f.off = symbase + so; }
+						++k;
+					}
+				}
+			}
+		}
+		nfr = k;
+	}
 }
 
 // ---------------------------------------------------------------- host

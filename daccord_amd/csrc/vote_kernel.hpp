@@ -44,50 +44,54 @@ DEV uint32_t symAscii(uint32_t const s)
 		case 5: return 'a'; case 6: return 'c'; case 7: return 'g'; default: return 't'; }
 }
 
-struct Cover { uint8_t const * rec; uint32_t r; };
-
-// windows of the pile whose records contribute at position p; returns count (<= 8 kept)
-DEV uint32_t coveringWindows(VoteBatch const & B, DevPile const & pile, uint32_t const p, Cover * cov, uint32_t const cap)
+// The windows of the pile whose records contribute at position p, in window order (the snapped last window comes
+// last): an iterator instead of a list, so that nothing of it lives in scratch memory.
+struct CoverIt { uint32_t y, yhi; uint32_t state; };     // state 0: regular windows, 1: the last window is still due, 2: done
+DEV void coverBegin(VoteBatch const & B, DevPile const & pile, uint32_t const p, CoverIt & it)
 {
 	uint32_t const a = B.P.a, w = B.P.w, nwin = pile.nwin;
-	uint32_t n = 0;
-	if ( ! nwin ) return 0;
-	uint32_t const ylo = (p > w) ? ((p-w + a-1)/a) : 0;
-	uint32_t yhi = p / a; if ( yhi > nwin-1 ) yhi = nwin-1;
-	bool lastseen = false;
-	for ( uint32_t y = ylo; y <= yhi; ++y )
+	if ( ! nwin ) { it.y = 1; it.yhi = 0; it.state = 2; return; }
+	it.y = (p > w) ? ((p-w + a-1)/a) : 0;
+	it.yhi = p / a; if ( it.yhi > nwin-1 ) it.yhi = nwin-1;
+	it.state = (it.y <= it.yhi && it.yhi == nwin-1) ? 2 : 1;     // the regular range already ends with the last window
+	if ( it.y > it.yhi ) it.state = 1;
+}
+DEV bool coverNext(VoteBatch const & B, DevPile const & pile, uint32_t const p, CoverIt & it, uint8_t const * & rec, uint32_t & r)
+{
+	uint32_t const a = B.P.a, w = B.P.w, nwin = pile.nwin;
+	while ( it.y <= it.yhi )
 	{
+		uint32_t const y = it.y++;
 		uint32_t s, e; windowInterval(pile.l,a,w,y,s,e);
-		if ( y == nwin-1 ) lastseen = true;
 		if ( s <= p && p <= e )
 		{
-			uint8_t const * rec = B.wrec + (pile.winbase+y)*WREC;
-			if ( rec[0] == 1 ) { if ( n < cap ) { cov[n].rec = rec; cov[n].r = p-s; ++n; } else atomicOrFlag(B.errflag); }
+			uint8_t const * rc = B.wrec + (pile.winbase+y)*WREC;
+			if ( rc[0] == 1 ) { rec = rc; r = p-s; return true; }
 		}
 	}
-	if ( !lastseen )
+	if ( it.state == 1 )
 	{
+		it.state = 2;
 		uint32_t s, e; windowInterval(pile.l,a,w,nwin-1,s,e);
 		if ( s <= p && p <= e )
 		{
-			uint8_t const * rec = B.wrec + (pile.winbase+nwin-1)*WREC;
-			if ( rec[0] == 1 ) { if ( n < cap ) { cov[n].rec = rec; cov[n].r = p-s; ++n; } else atomicOrFlag(B.errflag); }
+			uint8_t const * rc = B.wrec + (pile.winbase+nwin-1)*WREC;
+			if ( rc[0] == 1 ) { rec = rc; r = p-s; return true; }
 		}
 	}
-	return n;
+	return false;
 }
 
 // pass 1: has[p], ld0[p]
 DEV void votePass1(VoteBatch const & B, DevPile const & pile, uint32_t const p)
 {
-	Cover cov[24];
 	uint32_t const w = B.P.w;
-	uint32_t const nc = coveringWindows(B,pile,p,cov,24);
 	uint32_t l0 = 0, T = 0;
-	for ( uint32_t c = 0; c < nc; ++c )
+	CoverIt it; coverBegin(B,pile,p,it);
+	uint8_t const * rec; uint32_t r;
+	while ( coverNext(B,pile,p,it,rec,r) )
 	{
-		uint8_t const * off = cov[c].rec+1;
-		uint32_t const r = cov[c].r;
+		uint8_t const * off = rec+1;
 		uint32_t const sz = off[r+1]-off[r];
 		uint32_t const nins = sz - (r < w ? 1 : 0);
 		if ( r < w ) ++l0;
@@ -100,71 +104,86 @@ DEV void votePass1(VoteBatch const & B, DevPile const & pile, uint32_t const p)
 	B.ld0[pile.posbase+p] = l0;
 }
 
+// winner of a column: maximum (count, ASCII code), HandleContext.hpp:2695; counts packed 7 bits per symbol would
+// overflow for deep piles, so nine scalars (registers, the loops below are fully unrolled)
+struct ColCnt { uint32_t c0, c1, c2, c3, c4, c5, c6, c7, c8; };
+DEV void colClear(ColCnt & C) { C.c0 = C.c1 = C.c2 = C.c3 = C.c4 = C.c5 = C.c6 = C.c7 = C.c8 = 0; }
+DEV void colAdd(ColCnt & C, uint32_t const s, uint32_t const v)
+{
+	C.c0 += (s == 0) ? v : 0; C.c1 += (s == 1) ? v : 0; C.c2 += (s == 2) ? v : 0; C.c3 += (s == 3) ? v : 0; C.c4 += (s == 4) ? v : 0;
+	C.c5 += (s == 5) ? v : 0; C.c6 += (s == 6) ? v : 0; C.c7 += (s == 7) ? v : 0; C.c8 += (s >= 8) ? v : 0;
+}
+DEV bool colWinner(ColCnt const & C, uint32_t & best)
+{
+	uint32_t bk = 0; best = 0;
+	#define DACC_CW(cnt_,s_,ch_) { uint32_t const key = ((cnt_)<<8) | (ch_); if ( key > bk ) { bk = key; best = s_; } }
+	DACC_CW(C.c0,0,'A') DACC_CW(C.c1,1,'C') DACC_CW(C.c2,2,'G') DACC_CW(C.c3,3,'T') DACC_CW(C.c4,4,'D')
+	DACC_CW(C.c5,5,'a') DACC_CW(C.c6,6,'c') DACC_CW(C.c7,7,'g') DACC_CW(C.c8,8,'t')
+	#undef DACC_CW
+	return (bk>>8) != 0 && best != 4;
+}
+
 // pass 2: vote the columns of position p; if out != 0 write the emitted symbols; returns their number
 DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const p, uint8_t * out)
 {
 	if ( ! B.has[pile.posbase+p] ) return 0;
-	Cover cov[24];
 	uint32_t const w = B.P.w;
-	uint32_t const nc = coveringWindows(B,pile,p,cov,24);
 	uint32_t const npos = pileNpos(pile);
 	// depth: count of the apre==0 column of p, else carried from the nearest such column to the right in the run
 	int32_t depth = -1;
 	for ( uint32_t q = p; q < npos && B.has[pile.posbase+q]; ++q )
 		if ( B.ld0[pile.posbase+q] ) { depth = B.ld0[pile.posbase+q]; break; }
 	uint32_t T = 0;
-	for ( uint32_t c = 0; c < nc; ++c )
 	{
-		uint8_t const * off = cov[c].rec+1; uint32_t const r = cov[c].r;
-		uint32_t const nins = (off[r+1]-off[r]) - (r < w ? 1 : 0);
-		T = nins > T ? nins : T;
+		CoverIt it; coverBegin(B,pile,p,it);
+		uint8_t const * rec; uint32_t r;
+		while ( coverNext(B,pile,p,it,rec,r) )
+		{
+			uint8_t const * off = rec+1;
+			uint32_t const nins = (off[r+1]-off[r]) - (r < w ? 1 : 0);
+			T = nins > T ? nins : T;
+		}
 	}
 	uint32_t no = 0;
 	// insertion columns apre = -T .. -1
 	for ( uint32_t t = T; t >= 1; --t )
 	{
-		uint32_t cnt[9] = {0,0,0,0,0,0,0,0,0}; uint32_t ld = 0;
-		for ( uint32_t c = 0; c < nc; ++c )
+		ColCnt C; colClear(C); uint32_t ld = 0;
+		CoverIt it; coverBegin(B,pile,p,it);
+		uint8_t const * rec; uint32_t r;
+		while ( coverNext(B,pile,p,it,rec,r) )
 		{
-			uint8_t const * off = cov[c].rec+1; uint32_t const r = cov[c].r;
-			uint8_t const * sym = cov[c].rec + 1 + (w+2);
+			uint8_t const * off = rec+1;
+			uint8_t const * sym = rec + 1 + (w+2);
 			uint32_t const nins = (off[r+1]-off[r]) - (r < w ? 1 : 0);
-			if ( nins >= t ) { ++cnt[sym[off[r]+nins-t]]; ++ld; }
+			if ( nins >= t ) { colAdd(C,sym[off[r]+nins-t],1); ++ld; }
 		}
-		if ( depth > static_cast<int32_t>(ld) ) cnt[4] += depth-ld;
-		uint32_t best = 0, bestkey = 0;
-		for ( uint32_t s = 0; s < 9; ++s )
-		{
-			uint32_t const key = (cnt[s]<<8) | symAscii(s);
-			if ( key > bestkey ) { bestkey = key; best = s; }
-		}
-		if ( cnt[best] && best != 4 ) { if ( out ) out[no] = best; ++no; }
+		if ( depth > static_cast<int32_t>(ld) ) C.c4 += depth-ld;
+		uint32_t best;
+		if ( colWinner(C,best) ) { if ( out ) out[no] = best; ++no; }
 	}
 	// apre == 0 column
 	uint32_t const l0 = B.ld0[pile.posbase+p];
 	if ( l0 )
 	{
-		uint32_t cnt[9] = {0,0,0,0,0,0,0,0,0};
+		ColCnt C; colClear(C);
 		uint32_t real = 0;
-		for ( uint32_t c = 0; c < nc; ++c )
+		CoverIt it; coverBegin(B,pile,p,it);
+		uint8_t const * rec; uint32_t r;
+		while ( coverNext(B,pile,p,it,rec,r) )
 		{
-			uint8_t const * off = cov[c].rec+1; uint32_t const r = cov[c].r;
-			uint8_t const * sym = cov[c].rec + 1 + (w+2);
-			if ( r < w ) { ++cnt[sym[off[r+1]-1]]; ++real; }
+			uint8_t const * off = rec+1;
+			uint8_t const * sym = rec + 1 + (w+2);
+			if ( r < w ) { colAdd(C,sym[off[r+1]-1],1); ++real; }
 		}
 		if ( !real )
 		{
 			// producefull fill: lower-case A base (HandleContext.hpp:2556-2573)
 			uint8_t const b = readBase(B.bps,B.boff[pile.aread],B.rlen[pile.aread],false,p);
-			++cnt[5+b];
+			colAdd(C,5+b,1);
 		}
-		uint32_t best = 0, bestkey = 0;
-		for ( uint32_t s = 0; s < 9; ++s )
-		{
-			uint32_t const key = (cnt[s]<<8) | symAscii(s);
-			if ( key > bestkey ) { bestkey = key; best = s; }
-		}
-		if ( cnt[best] && best != 4 ) { if ( out ) out[no] = best; ++no; }
+		uint32_t best;
+		if ( colWinner(C,best) ) { if ( out ) out[no] = best; ++no; }
 	}
 	return no;
 }
