@@ -154,7 +154,7 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t const v, uint32_t *
 	uint32_t x = v;
 	if ( MAXOP ) { DACC_DPP_SCAN(x,DACC_OP_MAX,0u) } else { DACC_DPP_SCAN(x,DACC_OP_ADD,0u) }
 	// x = inclusive value of this lane; the exclusive one is the inclusive value of the lane before
-	uint32_t excl = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0,static_cast<int>(x),0x138 /* wave_shr:1 */,0xF,0xF,false));
+	uint32_t excl = __shfl_up(x,1,64); if ( (threadIdx.x & 63) == 0 ) excl = 0;
 	__syncthreads();
 	if ( (threadIdx.x & 63) == 63 ) part4[wave] = x;
 	__syncthreads();
@@ -170,30 +170,67 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t const v, uint32_t *
 	return MAXOP ? (excl > base ? excl : base) : (base + excl);
 }
 
-// one workgroup per pile
+// one workgroup per pile.  The pile is walked in tiles of 256 positions (thread = position); the records of the windows
+// that cover a tile (256/a + w/a + 2 of them, 256 B each) are staged in LDS once per pass, coalesced, so that the
+// byte-wise reads of the vote hit LDS and every record leaves HBM once per pass.
+enum { VOTE_STAGE = 48 };
+__device__ __forceinline__ VoteTile vote_stage(VoteBatch const & B, DevPile const & pile, uint32_t const p0, uint32_t const np, uint8_t * lds)
+{
+	VoteTile VT; VT.stage = (LDSQ uint8_t const *)lds; VT.y0 = 0; VT.n = 0;
+	uint32_t const a = B.P.a, w = B.P.w, nwin = pile.nwin;
+	if ( ! nwin ) return VT;
+	uint32_t const plast = (p0+255 < np) ? (p0+255) : (np-1);
+	uint32_t const ylo = (p0 > w) ? ((p0-w + a-1)/a) : 0;
+	uint32_t yhi = plast / a; if ( yhi > nwin-1 ) yhi = nwin-1;
+	__syncthreads();      // the previous tile's readers are done
+	if ( ylo <= yhi && yhi-ylo+1 <= VOTE_STAGE )
+	{
+		VT.y0 = ylo; VT.n = yhi-ylo+1;
+		uint4 const * src = reinterpret_cast<uint4 const *>(B.wrec + (pile.winbase+ylo)*WREC);
+		uint4 * dst = reinterpret_cast<uint4 *>(lds);
+		for ( uint32_t i = threadIdx.x; i < VT.n*(WREC/16); i += 256 ) dst[i] = src[i];
+	}
+	__syncthreads();
+	return VT;
+}
 __global__ void __launch_bounds__(256) k_vote(VoteBatch B)
 {
 	__shared__ uint32_t part4[4];
+	__shared__ __attribute__((aligned(16))) uint8_t stage[VOTE_STAGE*WREC];
 	uint32_t const pi = blockIdx.x;
 	DevPile const pile = B.piles[pi];
 	uint32_t const np = pileNpos(pile);
 	uint32_t const tid = threadIdx.x;
-	for ( uint32_t p = tid; p < np; p += 256 ) votePass1(B,pile,p);
+	for ( uint32_t t0 = 0; t0 < np; t0 += 256 )
+	{
+		VoteTile const VT = vote_stage(B,pile,t0,np,stage);
+		if ( t0+tid < np ) votePass1(B,pile,t0+tid,VT);
+	}
 	__syncthreads();
-	// contiguous chunk per thread: counts, then a block-wide exclusive scan
-	uint32_t const chunk = (np + 255)/256;
-	uint32_t const p0 = tid*chunk < np ? tid*chunk : np, p1 = (p0+chunk < np) ? (p0+chunk) : np;
-	uint32_t sum = 0;
-	for ( uint32_t p = p0; p < p1; ++p ) { uint32_t const n = votePass2(B,pile,p,0); B.oc[pile.posbase+p] = n; sum += n; }
-	uint32_t total;
-	uint32_t run = block_scan_excl<false>(sum,part4,total);
+	uint32_t run0 = 0;
+	for ( uint32_t t0 = 0; t0 < np; t0 += 256 )
+	{
+		VoteTile const VT = vote_stage(B,pile,t0,np,stage);
+		uint32_t const p = t0+tid;
+		uint32_t const n = p < np ? votePass2(B,pile,p,0,VT) : 0u;
+		uint32_t tot; uint32_t const ex = block_scan_excl<false>(n,part4,tot);
+		if ( p < np ) { B.oc[pile.posbase+p] = n; B.ocs[pile.posbase+p] = run0 + ex; }
+		run0 += tot;
+	}
+	uint32_t const total = run0;
 	bool const fits = total <= 2*np+64;
 	if ( !fits && tid == 0 ) atomicOr(B.errflag,2u);
 	uint64_t const symbase = 2*pile.posbase + 64ull*pi;
-	for ( uint32_t p = p0; p < p1; ++p ) { B.ocs[pile.posbase+p] = run; run += B.oc[pile.posbase+p]; }
 	if ( fits )
-		for ( uint32_t p = p0; p < p1; ++p ) votePass2(B,pile,p,B.outsym+symbase+B.ocs[pile.posbase+p]);
+		for ( uint32_t t0 = 0; t0 < np; t0 += 256 )
+		{
+			VoteTile const VT = vote_stage(B,pile,t0,np,stage);
+			uint32_t const p = t0+tid;
+			if ( p < np ) votePass2(B,pile,p,B.outsym+symbase+B.ocs[pile.posbase+p],VT);
+		}
 	__syncthreads();
+	uint32_t const chunk = (np + 255)/256;
+	uint32_t const p0 = tid*chunk < np ? tid*chunk : np, p1 = (p0+chunk < np) ? (p0+chunk) : np;
 	// runs of consecutive positions with elements, kept if last-first >= 100 (HandleContext.hpp:2590-2612): every thread
 	// walks its chunk; the start of the run that is open at the chunk's first position comes from a running maximum
 	// over the chunks before it (start position + 1, 0 = none)

@@ -47,6 +47,18 @@ DEV uint32_t symAscii(uint32_t const s)
 // The windows of the pile whose records contribute at position p, in window order (the snapped last window comes
 // last): an iterator instead of a list, so that nothing of it lives in scratch memory.
 struct CoverIt { uint32_t y, yhi; uint32_t state; };     // state 0: regular windows, 1: the last window is still due, 2: done
+// records of windows [y0,y0+n) of the pile staged in LDS by the workgroup (n == 0: none, read them from HBM/L2)
+struct VoteTile { LDSQ uint8_t const * stage; uint32_t y0, n; };
+// a window record, either in the LDS stage or in HBM (no generic pointers: the two address spaces stay apart)
+struct VRec { uint8_t const * g; LDSQ uint8_t const * l; bool lds; };     // an explicit flag: LDS address 0 is a valid address
+DEV uint32_t vrb(VRec const & R, uint32_t const i) { return R.lds ? static_cast<uint32_t>(R.l[i]) : static_cast<uint32_t>(R.g[i]); }
+DEV VRec voteRecord(VoteBatch const & B, DevPile const & pile, VoteTile const & VT, uint32_t const y)
+{
+	uint32_t const d = y - VT.y0;
+	VRec R;
+	if ( d < VT.n ) { R.l = VT.stage + d*WREC; R.g = B.wrec; R.lds = true; } else { R.l = VT.stage; R.g = B.wrec + (pile.winbase+y)*WREC; R.lds = false; }
+	return R;
+}
 DEV void coverBegin(VoteBatch const & B, DevPile const & pile, uint32_t const p, CoverIt & it)
 {
 	uint32_t const a = B.P.a, w = B.P.w, nwin = pile.nwin;
@@ -56,7 +68,7 @@ DEV void coverBegin(VoteBatch const & B, DevPile const & pile, uint32_t const p,
 	it.state = (it.y <= it.yhi && it.yhi == nwin-1) ? 2 : 1;     // the regular range already ends with the last window
 	if ( it.y > it.yhi ) it.state = 1;
 }
-DEV bool coverNext(VoteBatch const & B, DevPile const & pile, uint32_t const p, CoverIt & it, uint8_t const * & rec, uint32_t & r)
+DEV bool coverNext(VoteBatch const & B, DevPile const & pile, VoteTile const & VT, uint32_t const p, CoverIt & it, VRec & rec, uint32_t & r)
 {
 	uint32_t const a = B.P.a, w = B.P.w, nwin = pile.nwin;
 	while ( it.y <= it.yhi )
@@ -65,8 +77,8 @@ DEV bool coverNext(VoteBatch const & B, DevPile const & pile, uint32_t const p, 
 		uint32_t s, e; windowInterval(pile.l,a,w,y,s,e);
 		if ( s <= p && p <= e )
 		{
-			uint8_t const * rc = B.wrec + (pile.winbase+y)*WREC;
-			if ( rc[0] == 1 ) { rec = rc; r = p-s; return true; }
+			VRec const rc = voteRecord(B,pile,VT,y);
+			if ( vrb(rc,0) == 1 ) { rec = rc; r = p-s; return true; }
 		}
 	}
 	if ( it.state == 1 )
@@ -75,24 +87,23 @@ DEV bool coverNext(VoteBatch const & B, DevPile const & pile, uint32_t const p, 
 		uint32_t s, e; windowInterval(pile.l,a,w,nwin-1,s,e);
 		if ( s <= p && p <= e )
 		{
-			uint8_t const * rc = B.wrec + (pile.winbase+nwin-1)*WREC;
-			if ( rc[0] == 1 ) { rec = rc; r = p-s; return true; }
+			VRec const rc = voteRecord(B,pile,VT,nwin-1);
+			if ( vrb(rc,0) == 1 ) { rec = rc; r = p-s; return true; }
 		}
 	}
 	return false;
 }
 
 // pass 1: has[p], ld0[p]
-DEV void votePass1(VoteBatch const & B, DevPile const & pile, uint32_t const p)
+DEV void votePass1(VoteBatch const & B, DevPile const & pile, uint32_t const p, VoteTile const VT = VoteTile{0,0,0})
 {
 	uint32_t const w = B.P.w;
 	uint32_t l0 = 0, T = 0;
 	CoverIt it; coverBegin(B,pile,p,it);
-	uint8_t const * rec; uint32_t r;
-	while ( coverNext(B,pile,p,it,rec,r) )
+	VRec rec; uint32_t r;
+	while ( coverNext(B,pile,VT,p,it,rec,r) )
 	{
-		uint8_t const * off = rec+1;
-		uint32_t const sz = off[r+1]-off[r];
+		uint32_t const sz = vrb(rec,1+r+1)-vrb(rec,1+r);
 		uint32_t const nins = sz - (r < w ? 1 : 0);
 		if ( r < w ) ++l0;
 		T = nins > T ? nins : T;
@@ -124,7 +135,7 @@ DEV bool colWinner(ColCnt const & C, uint32_t & best)
 }
 
 // pass 2: vote the columns of position p; if out != 0 write the emitted symbols; returns their number
-DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const p, uint8_t * out)
+DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const p, uint8_t * out, VoteTile const VT = VoteTile{0,0,0})
 {
 	if ( ! B.has[pile.posbase+p] ) return 0;
 	uint32_t const w = B.P.w;
@@ -136,11 +147,10 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 	uint32_t T = 0;
 	{
 		CoverIt it; coverBegin(B,pile,p,it);
-		uint8_t const * rec; uint32_t r;
-		while ( coverNext(B,pile,p,it,rec,r) )
+		VRec rec; uint32_t r;
+		while ( coverNext(B,pile,VT,p,it,rec,r) )
 		{
-			uint8_t const * off = rec+1;
-			uint32_t const nins = (off[r+1]-off[r]) - (r < w ? 1 : 0);
+			uint32_t const nins = (vrb(rec,1+r+1)-vrb(rec,1+r)) - (r < w ? 1 : 0);
 			T = nins > T ? nins : T;
 		}
 	}
@@ -150,13 +160,12 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 	{
 		ColCnt C; colClear(C); uint32_t ld = 0;
 		CoverIt it; coverBegin(B,pile,p,it);
-		uint8_t const * rec; uint32_t r;
-		while ( coverNext(B,pile,p,it,rec,r) )
+		VRec rec; uint32_t r;
+		while ( coverNext(B,pile,VT,p,it,rec,r) )
 		{
-			uint8_t const * off = rec+1;
-			uint8_t const * sym = rec + 1 + (w+2);
-			uint32_t const nins = (off[r+1]-off[r]) - (r < w ? 1 : 0);
-			if ( nins >= t ) { colAdd(C,sym[off[r]+nins-t],1); ++ld; }
+			uint32_t const o0 = vrb(rec,1+r);
+			uint32_t const nins = (vrb(rec,1+r+1)-o0) - (r < w ? 1 : 0);
+			if ( nins >= t ) { colAdd(C,vrb(rec,1+(w+2)+o0+nins-t),1); ++ld; }
 		}
 		if ( depth > static_cast<int32_t>(ld) ) C.c4 += depth-ld;
 		uint32_t best;
@@ -169,12 +178,10 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 		ColCnt C; colClear(C);
 		uint32_t real = 0;
 		CoverIt it; coverBegin(B,pile,p,it);
-		uint8_t const * rec; uint32_t r;
-		while ( coverNext(B,pile,p,it,rec,r) )
+		VRec rec; uint32_t r;
+		while ( coverNext(B,pile,VT,p,it,rec,r) )
 		{
-			uint8_t const * off = rec+1;
-			uint8_t const * sym = rec + 1 + (w+2);
-			if ( r < w ) { colAdd(C,sym[off[r+1]-1],1); ++real; }
+			if ( r < w ) { colAdd(C,vrb(rec,1+(w+2)+vrb(rec,1+r+1)-1),1); ++real; }
 		}
 		if ( !real )
 		{
