@@ -47,6 +47,8 @@ struct BatchPlan
 	std::vector<uint64_t> fragbase;
 	uint64_t nwindows, nblocks, nwt, npos, nfragslots, algo_bytes;
 	uint32_t maxdepth, maxcols;
+	std::vector<int32_t> pile_status;         // per submitted pile: DACC_OK or why it was dropped
+	std::vector<std::string> pile_errors;     // first messages of dropped piles
 	ArenaCaps caps;
 	enum { NTIER = 3 };
 	FastCaps ftier[NTIER];    // LDS fast path capacity tiers: 3, 2, 1 wavefronts per CU
@@ -55,39 +57,59 @@ struct BatchPlan
 		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err,
 		uint32_t const tab_nrows = 0, uint32_t const tab_nsup = 0)
 	{
-		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear();
+		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear(); pile_status.assign(np,DACC_OK); pile_errors.clear();
 		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0;
-		if ( trace_bytes != 1 ) { err = "only 1-byte trace values (tspace <= 125) are supported by the kernels"; return DACC_ENOTSUP; }
-		if ( par.tspace <= 0 || par.tspace > 128 ) { err = "tspace must be in [1,128]"; return DACC_ENOTSUP; }
-		uint8_t const * tr = static_cast<uint8_t const *>(trace);
+		if ( trace_bytes != 1 && trace_bytes != 2 ) { err = "trace values are 1 byte (tspace <= 125) or 2 bytes"; return DACC_EINVAL; }
+		if ( par.tspace <= 0 || par.tspace > 128 ) { err = "tspace must be in [1,128] (128-bit column vectors of the trace kernel)"; return DACC_ENOTSUP; }
+		uint8_t const * tr8 = static_cast<uint8_t const *>(trace); uint16_t const * tr16 = static_cast<uint16_t const *>(trace);
+		auto const tv = [&](uint64_t const i) -> uint32_t { return trace_bytes == 2 ? tr16[i] : tr8[i]; };
 		std::vector<int32_t> diff;
 		for ( uint64_t pi = 0; pi < np; ++pi )
 		{
 			dacc_pile const & p = P[pi];
 			if ( p.aread < 0 || static_cast<uint64_t>(p.aread) >= nreads || p.first_ovl + p.novl > no ) { err = "pile out of range"; return DACC_EINVAL; }
-			DevPile d; d.aread = p.aread; d.novl = p.novl; d.first_ovl = ovl.size();
+			// A malformed pile is dropped (no overlaps -> no windows -> no fragments) and reported through pile_status, like
+			// the reference's per-read try/catch (src/daccord.cpp:2464-2478); the batch goes on.
 			dacc_overlap const * ita = O + p.first_ovl;
-			uint64_t maxaepos = 0;
-			double maxerate = 0.0, minerate = 1.0;
-			for ( uint32_t z = 0; z < p.novl; ++z )
+			char const * bad = 0;
+			int64_t const tsv = par.tspace;
+			for ( uint32_t z = 0; z < p.novl && !bad; ++z )
 			{
 				dacc_overlap const & o = ita[z];
 				if ( o.aread != p.aread || o.bread < 0 || static_cast<uint64_t>(o.bread) >= nreads || o.abpos < 0 || o.aepos <= o.abpos ||
 				     static_cast<uint32_t>(o.aepos) > rlen[o.aread] || o.bbpos < 0 || o.bepos < o.bbpos || static_cast<uint32_t>(o.bepos) > rlen[o.bread] ||
 				     (z && ita[z-1].abpos > o.abpos) )
-				{ err = "malformed overlap record (ranges / not sorted by abpos)"; return DACC_EINVAL; }
+				{ bad = "malformed overlap record (ranges / not sorted by abpos)"; break; }
+				int64_t const nblk = (o.aepos + tsv - 1)/tsv - o.abpos/tsv;
+				if ( o.tlen != 2*nblk || o.trace_off + o.tlen > ntrace ) { bad = "trace length does not match the overlap's tspace blocks"; break; }
+				uint64_t bsum = 0;
+				for ( int64_t b = 0; b < nblk; ++b ) bsum += tv(o.trace_off+2*b+1);
+				if ( static_cast<int64_t>(bsum) != o.bepos-o.bbpos ) { bad = "trace B lengths do not sum to bepos-bbpos"; break; }
+			}
+			uint32_t const pnovl = bad ? 0u : p.novl;
+			if ( bad )
+			{
+				pile_status[pi] = DACC_EINVAL;
+				if ( pile_errors.size() < 64 ) pile_errors.push_back("read " + std::to_string(p.aread) + ": " + bad);
+			}
+			DevPile d; d.aread = p.aread; d.novl = pnovl; d.first_ovl = ovl.size();
+			uint64_t maxaepos = 0;
+			double maxerate = 0.0, minerate = 1.0;
+			for ( uint32_t z = 0; z < pnovl; ++z )
+			{
+				dacc_overlap const & o = ita[z];
 				if ( static_cast<uint64_t>(o.aepos) > maxaepos ) maxaepos = o.aepos;
 				double const erate = static_cast<double>(o.diffs) / static_cast<double>(o.aepos-o.abpos);
 				if ( erate > maxerate ) maxerate = erate;
 				if ( erate < minerate ) minerate = erate;
 			}
 			double const ediv = (maxerate > minerate) ? (maxerate-minerate) : 1.0;
-			d.l = maxaepos; d.nwin = p.novl ? windowsN(maxaepos,par.a,par.w) : 0;
+			d.l = maxaepos; d.nwin = pnovl ? windowsN(maxaepos,par.a,par.w) : 0;
 			d.winbase = nwindows; d.posbase = npos; d.rl = rlen[p.aread]; d.pad = 0;
 			uint64_t const pilepos = std::max<uint64_t>(d.l,d.rl)+1;
 			diff.assign(d.nwin+2,0);
 			algo_bytes += (d.rl+3)/4;
-			for ( uint32_t z = 0; z < p.novl; ++z )
+			for ( uint32_t z = 0; z < pnovl; ++z )
 			{
 				dacc_overlap const & o = ita[z];
 				DevOvl v;
@@ -97,15 +119,8 @@ struct BatchPlan
 				v.ekey = static_cast<uint32_t>(escore);
 				int64_t const ts = par.tspace;
 				int64_t const nblk = (o.aepos + ts - 1)/ts - o.abpos/ts;
-				if ( o.tlen != 2*nblk || o.trace_off + o.tlen > ntrace ) { err = "trace length does not match the overlap's tspace blocks"; return DACC_EINVAL; }
 				v.nblk = nblk; v.blk0 = nblocks; v.trace_off = o.trace_off;
-				uint64_t bsum = 0;
-				for ( int64_t b = 0; b < nblk; ++b )
-				{
-					uint32_t const bl = tr[o.trace_off+2*b+1];
-					bsum += bl; if ( bl > maxcols ) maxcols = bl;
-				}
-				if ( static_cast<int64_t>(bsum) != o.bepos-o.bbpos ) { err = "trace B lengths do not sum to bepos-bbpos"; return DACC_EINVAL; }
+				for ( int64_t b = 0; b < nblk; ++b ) { uint32_t const bl = tv(o.trace_off+2*b+1); if ( bl > maxcols ) maxcols = bl; }
 				nblocks += nblk;
 				algo_bytes += 40 + static_cast<uint64_t>(o.tlen)*trace_bytes + (o.bepos-o.bbpos+3)/4;
 				// active window range [y0,y0+ny): start(y) >= abpos and end(y) <= aepos

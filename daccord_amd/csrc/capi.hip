@@ -24,7 +24,7 @@ using namespace dacc;
 
 struct PrepBatch
 {
-	DevOvl const * ovl; uint64_t novl; uint8_t const * trace;
+	DevOvl const * ovl; uint64_t novl; uint8_t const * trace; uint32_t trace_bytes;
 	uint32_t * blk_ovl; uint32_t * blk_b0;
 };
 
@@ -38,15 +38,20 @@ __global__ void k_prep(PrepBatch B)
 	for ( int32_t i = 0; i < ov.nblk; ++i )
 	{
 		B.blk_ovl[ov.blk0+i] = o; B.blk_b0[ov.blk0+i] = b;
-		b += B.trace[ov.trace_off+2*i+1];
+		b += B.trace_bytes == 2 ? reinterpret_cast<uint16_t const *>(B.trace)[ov.trace_off+2*i+1] : B.trace[ov.trace_off+2*i+1];
 	}
 }
 
-__global__ void __launch_bounds__(256) k_trace(TraceBatch B)
+// one lane per tspace block, one wavefront per workgroup; the column checkpoints and the current segment of every lane
+// live in the workgroup's dynamic LDS (traceSlots(maxcols) slots of 34 bytes per lane)
+__global__ void __launch_bounds__(64) k_trace(TraceBatch B)
 {
-	uint32_t const tid = blockIdx.x*blockDim.x + threadIdx.x;
-	for ( uint64_t task = tid; task < B.nblocks; task += B.nthreads )
-		traceBlock(B,task,tid);
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_trace[];
+	uint32_t const slots = traceSlots(B.maxcols);
+	TraceStoreLds st;
+	st.w = (LDSQ uint64_t *)lds_trace; st.sc = (LDSQ uint16_t *)(lds_trace + static_cast<size_t>(slots)*4*64*8); st.lane = threadIdx.x;
+	for ( uint64_t task = static_cast<uint64_t>(blockIdx.x)*64 + threadIdx.x; task < B.nblocks; task += static_cast<uint64_t>(gridDim.x)*64 )
+		traceBlock(B,task,st);
 }
 
 // Work distribution of the window kernels.  Windows differ in cost by orders of magnitude, so workgroups pull indices
@@ -97,10 +102,20 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 }
 
 // safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
-__global__ void k_check_done(WindowOut const * wout, uint64_t n, uint32_t * errflag)
+// after all engines: a window still marked as handed on is an internal error (errflag); a window the generic engine
+// could not hold even with grown scratch drops its pile (pilebad), the batch goes on
+__global__ void k_check_done(WindowOut const * wout, uint64_t n, uint32_t * errflag, DevPile const * piles, uint32_t npiles, uint8_t * pilebad)
 {
 	uint64_t const i = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
-	if ( i < n && wout[i].status == WS_RETRY ) atomicOr(errflag,1u);
+	if ( i >= n ) return;
+	uint32_t const st = wout[i].status;
+	if ( st == WS_RETRY ) atomicOr(errflag,1u);
+	if ( st == WS_OVERFLOW )
+	{
+		uint32_t lo = 0, hi = npiles;
+		while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( piles[mid].winbase <= i ) lo = mid; else hi = mid; }
+		pilebad[lo] = 1;
+	}
 }
 
 // windows the generic engine left as WS_OVERFLOW -> list (count in list[0])
@@ -201,6 +216,7 @@ __global__ void __launch_bounds__(256) k_vote(VoteBatch B)
 	DevPile const pile = B.piles[pi];
 	uint32_t const np = pileNpos(pile);
 	uint32_t const tid = threadIdx.x;
+	if ( B.pilebad && B.pilebad[pi] ) { if ( tid == 0 ) B.nfrag[pi] = 0; return; }     // dropped pile: no fragments
 	for ( uint32_t t0 = 0; t0 < np; t0 += 256 )
 	{
 		VoteTile const VT = vote_stage(B,pile,t0,np,stage);
@@ -312,16 +328,16 @@ struct dacc_ctx
 	BatchPlan BP;
 	DevBuf<DevPile> d_piles; DevBuf<DevOvl> d_ovl; DevBuf<uint32_t> d_ovl_pile; DevBuf<uint8_t> d_trace;
 	DevBuf<uint32_t> d_blk_ovl, d_blk_b0, d_wt_b, d_wt_e;
-	DevBuf<uint64_t> d_colv; DevBuf<uint16_t> d_colbot;
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
-	DevBuf<uint8_t> d_has, d_oc, d_outsym; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
+	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
 	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly; DevBuf<uint8_t> d_arena2;
 	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
-	uint32_t tr_threads, win_grid;
+	uint32_t tr_grid, tr_lds, trace_bytes, win_grid;
 	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
+	std::vector<int32_t> pile_status; std::vector<std::string> pile_errors; std::string pile_errors_joined;
 	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
 	dacc_timing timing;
 };
@@ -376,8 +392,8 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_dpnorm.release(); c->d_dpsq.release(); c->d_vs.release(); c->d_first.release(); c->d_size.release(); c->d_suplo.release(); c->d_suphi.release(); c->d_klim.release();
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
-	c->d_colv.release(); c->d_colbot.release(); c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_arena2.release();
+	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
+	c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_arena2.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric);
 	delete c;
@@ -452,7 +468,7 @@ static int runDevice(dacc_ctx * c)
 	HIPCHK(hipEventRecord(c->ev[0],s));
 	if ( BP.ovl.size() )
 	{
-		PrepBatch PB; PB.ovl = c->d_ovl.p; PB.novl = BP.ovl.size(); PB.trace = c->d_trace.p; PB.blk_ovl = c->d_blk_ovl.p; PB.blk_b0 = c->d_blk_b0.p;
+		PrepBatch PB; PB.ovl = c->d_ovl.p; PB.novl = BP.ovl.size(); PB.trace = c->d_trace.p; PB.trace_bytes = c->trace_bytes; PB.blk_ovl = c->d_blk_ovl.p; PB.blk_b0 = c->d_blk_b0.p;
 		hipLaunchKernelGGL(k_prep,dim3((BP.ovl.size()+255)/256),dim3(256),0,s,PB);
 	}
 	if ( BP.nblocks )
@@ -461,8 +477,8 @@ static int runDevice(dacc_ctx * c)
 		TB.P = c->P; TB.bps = c->d_bps.p; TB.boff = c->d_boff.p; TB.rlen = c->d_rlen.p;
 		TB.piles = c->d_piles.p; TB.ovl = c->d_ovl.p; TB.ovl_pile = c->d_ovl_pile.p; TB.trace = c->d_trace.p;
 		TB.blk_ovl = c->d_blk_ovl.p; TB.blk_b0 = c->d_blk_b0.p; TB.nblocks = BP.nblocks; TB.wt_b = c->d_wt_b.p; TB.wt_e = c->d_wt_e.p;
-		TB.colv = c->d_colv.p; TB.colbot = c->d_colbot.p; TB.maxcols = BP.maxcols; TB.nthreads = c->tr_threads; TB.errflag = c->d_err.p + 2;
-		hipLaunchKernelGGL(k_trace,dim3(c->tr_threads/256),dim3(256),0,s,TB);
+		TB.maxcols = BP.maxcols; TB.trace_bytes = c->trace_bytes; TB.errflag = c->d_err.p + 2;
+		hipLaunchKernelGGL(k_trace,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB);
 	}
 	HIPCHK(hipEventRecord(c->ev[1],s));
 	if ( BP.nwindows )
@@ -529,13 +545,14 @@ static int runDevice(dacc_ctx * c)
 	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
 	auto voteAndFetch = [&]() -> int
 	{
-		if ( BP.nwindows ) hipLaunchKernelGGL(k_check_done,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_err.p+3);
+		HIPCHK(hipMemsetAsync(c->d_pilebad.p,0,BP.piles.size()+1,s));
+		if ( BP.nwindows ) hipLaunchKernelGGL(k_check_done,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_err.p+3,c->d_piles.p,static_cast<uint32_t>(BP.piles.size()),c->d_pilebad.p);
 		if ( BP.piles.size() )
 		{
 			VoteBatch VB;
 			VB.P = c->P; VB.bps = c->d_bps.p; VB.boff = c->d_boff.p; VB.rlen = c->d_rlen.p; VB.piles = c->d_piles.p; VB.npiles = BP.piles.size();
 			VB.wrec = c->d_wrec.p; VB.has = c->d_has.p; VB.ld0 = c->d_ld0.p; VB.oc = c->d_oc.p; VB.ocs = c->d_ocs.p; VB.outsym = c->d_outsym.p;
-			VB.frags = c->d_frags.p; VB.fragbase = c->d_fragbase.p; VB.nfrag = c->d_nfrag.p; VB.errflag = c->d_err.p + 1;
+			VB.frags = c->d_frags.p; VB.fragbase = c->d_fragbase.p; VB.nfrag = c->d_nfrag.p; VB.errflag = c->d_err.p + 1; VB.pilebad = c->d_pilebad.p;
 			hipLaunchKernelGGL(k_vote,dim3(BP.piles.size()),dim3(256),0,s,VB);
 		}
 		HIPCHK(hipEventRecord(c->ev[3],s));
@@ -575,7 +592,19 @@ static int runDevice(dacc_ctx * c)
 		hipLaunchKernelGGL(k_window,dim3(g),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p),static_cast<uint32_t *>(0));
 		int const rc = voteAndFetch(); if ( rc ) return rc;
 	}
-	if ( herr[0] ) { c->err = "window kernel scratch capacity exceeded (depth / graph size); lower -d or use smaller piles"; return DACC_ENOTSUP; }
+	c->pile_status = BP.pile_status; c->pile_errors = BP.pile_errors;
+	if ( herr[0] && BP.piles.size() )
+	{
+		// windows the generic engine could not hold even with grown scratch: their piles were dropped by the vote
+		std::vector<uint8_t> bad(BP.piles.size());
+		HIPCHK(hipMemcpy(bad.data(),c->d_pilebad.p,bad.size(),hipMemcpyDeviceToHost));
+		for ( size_t pi = 0; pi < bad.size(); ++pi )
+			if ( bad[pi] )
+			{
+				c->pile_status[pi] = DACC_ENOTSUP;
+				if ( c->pile_errors.size() < 64 ) c->pile_errors.push_back("read " + std::to_string(BP.piles[pi].aread) + ": window kernel scratch capacity exceeded (depth / graph size), read skipped");
+			}
+	}
 	if ( herr[3] ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
 	if ( herr[1] ) { c->err = "vote kernel capacity exceeded"; return DACC_ENOTSUP; }
 	if ( herr[2] ) { c->err = "trace kernel capacity exceeded (tspace block longer than 128 or B span > 255)"; return DACC_ENOTSUP; }
@@ -626,13 +655,19 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	if ( (rc = upload(c,c->d_fragbase,BP.fragbase.data(),BP.fragbase.size())) ) return rc;
 	HIPCHK(c->d_blk_ovl.ensure(BP.nblocks+1)); HIPCHK(c->d_blk_b0.ensure(BP.nblocks+1));
 	HIPCHK(c->d_wt_b.ensure(BP.nwt+1)); HIPCHK(c->d_wt_e.ensure(BP.nwt+1));
-	// trace kernel geometry + column slabs
-	uint64_t tthreads = ((BP.nblocks+255)/256)*256;
-	if ( tthreads > 256ull*1024 ) tthreads = 256ull*1024;
-	if ( tthreads < 256 ) tthreads = 256;
-	c->tr_threads = tthreads;
-	HIPCHK(c->d_colv.ensure(static_cast<size_t>(BP.maxcols+2)*tthreads*4));
-	HIPCHK(c->d_colbot.ensure(static_cast<size_t>(BP.maxcols+2)*tthreads));
+	// trace kernel geometry: one wavefront per workgroup, as many workgroups per CU as their LDS column stores allow,
+	// a few rounds of blocks per workgroup
+	{
+		c->trace_bytes = trace_bytes;
+		c->tr_lds = traceSlots(BP.maxcols)*64u*34u;
+		if ( c->tr_lds > 160*1024 ) { c->err = "a trace block spans too many B bases for the trace kernel's LDS column store"; return DACC_ENOTSUP; }
+		if ( c->tr_lds > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
+		uint64_t percu = (160*1024) / (c->tr_lds ? c->tr_lds : 1); if ( percu > 8 ) percu = 8; if ( percu < 1 ) percu = 1;
+		uint64_t g = (BP.nblocks+63)/64, gmax = 256*percu*4;
+		if ( g > gmax ) g = gmax;
+		if ( g < 1 ) g = 1;
+		c->tr_grid = g;
+	}
 	// window kernel geometry + arenas
 	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
 	uint64_t wg = ((BP.nwindows+7)/8)*8;
@@ -682,7 +717,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
 	HIPCHK(c->d_has.ensure(BP.npos+1)); HIPCHK(c->d_oc.ensure(BP.npos+1)); HIPCHK(c->d_ld0.ensure(BP.npos+1)); HIPCHK(c->d_ocs.ensure(BP.npos+1));
 	HIPCHK(c->d_outsym.ensure(2*BP.npos + 64*BP.piles.size() + 64));
-	HIPCHK(c->d_nfrag.ensure(BP.piles.size()+1)); HIPCHK(c->d_frags.ensure(BP.nfragslots+1));
+	HIPCHK(c->d_nfrag.ensure(BP.piles.size()+1)); HIPCHK(c->d_frags.ensure(BP.nfragslots+1)); HIPCHK(c->d_pilebad.ensure(BP.piles.size()+1));
 	hipEvent_t h2dend; hipEventCreate(&h2dend); hipEventRecord(h2dend,s);
 	rc = runDevice(c);
 	float ms = 0; hipEventElapsedTime(&ms,c->ev[5],h2dend); c->timing.h2d_ms = ms; hipEventDestroy(h2dend);
@@ -738,6 +773,22 @@ int dacc_debug_retry(dacc_ctx * c, uint32_t * out, uint64_t cap, uint64_t * n)
 	*n = c->retry_flags.size();
 	if ( out ) std::memcpy(out,c->retry_flags.data(),sizeof(uint32_t)*std::min<uint64_t>(cap,c->retry_flags.size()));
 	return DACC_OK;
+}
+
+// per pile status of the last batch (DACC_OK or why the pile was dropped) and the messages a caller would log
+int dacc_pile_status(dacc_ctx * c, int32_t * out, uint64_t cap, uint64_t * n)
+{
+	if ( !c || !n ) return DACC_EINVAL;
+	*n = c->pile_status.size();
+	if ( out ) std::memcpy(out,c->pile_status.data(),sizeof(int32_t)*std::min<uint64_t>(cap,c->pile_status.size()));
+	return DACC_OK;
+}
+char const * dacc_pile_errors(dacc_ctx * c)
+{
+	if ( !c ) return "";
+	c->pile_errors_joined.clear();
+	for ( size_t i = 0; i < c->pile_errors.size(); ++i ) { c->pile_errors_joined += c->pile_errors[i]; c->pile_errors_joined += '\n'; }
+	return c->pile_errors_joined.c_str();
 }
 
 int dacc_debug_windows(dacc_ctx * c, dacc_window_result * out, uint64_t cap, uint64_t * nwin)

@@ -6,8 +6,9 @@
  * given by the trace point, per block), followed by the advanceA / getStringLengthUsed
  * bookkeeping of :1936-1949 and :2005-2029.  The reference materialises the whole edit script
  * and walks it window by window; here each block is aligned bit-parallel (Myers, 128-bit
- * column vectors for tspace <= 128) with the vertical delta vectors of every column kept in a
- * per-thread HBM slab, and the traceback emits only what the windows need: the B offset P(x)
+ * column vectors for tspace <= 128); the forward pass keeps every 16th column in LDS and the
+ * traceback recomputes the 16 columns of a segment when it enters it, so the alignment matrix
+ * never leaves the CU.  The traceback emits only what the windows need: the B offset P(x)
  * at every A position x that is a window start or end.  P(x) = bbpos + number of B symbols
  * consumed up to and including the (x-abpos)-th A-consuming step (trailing insertions belong
  * to the next window, exactly advanceA's stopping rule).
@@ -32,10 +33,8 @@ struct TraceBatch
 	uint32_t const * blk_ovl; uint32_t const * blk_b0;
 	uint64_t nblocks;
 	uint32_t * wt_b; uint32_t * wt_e;
-	uint64_t * colv;      // [maxcols+1][nthreads][4]  Pv0,Mv0,Pv1,Mv1 per column
-	uint16_t * colbot;    // [maxcols+1][nthreads]
-	uint32_t maxcols;
-	uint32_t nthreads;
+	uint32_t maxcols;     // largest B span of a block in the batch
+	uint32_t trace_bytes; // 1 (tspace <= 125) or 2 bytes per trace value
 	uint32_t * errflag;
 };
 
@@ -81,8 +80,69 @@ DEV void emitBoundary(TraceBatch const & B, DevPile const & pile, DevOvl const &
 	}
 }
 
-// tid = global thread id (slab index), task = block id
-DEV void traceBlock(TraceBatch const & B, uint64_t const task, uint32_t const tid)
+// One column of the bit-parallel alignment: vertical delta vectors (two 64-bit words for up to 128 A rows) and the score
+// of the bottom row.
+struct TCol { uint64_t pv0, mv0, pv1, mv1; uint32_t score; };
+
+// Column stores.  The forward pass keeps only every TRS-th column (checkpoints); the traceback, which walks the columns
+// downwards, recomputes the TRS columns of a segment from its checkpoint when it enters the segment.  A thread therefore
+// needs ncp + TRS column slots instead of one per column, which fits LDS: nothing of the alignment matrix goes to HBM.
+enum { TRS = 16 };
+// device: slots of the 64 lanes of a wavefront interleaved, word q of slot e of lane l at (e*4+q)*64 + l (no bank conflicts
+// whatever slot a lane is at)
+struct TraceStoreLds
+{
+	LDSQ uint64_t * w; LDSQ uint16_t * sc; uint32_t lane;
+	DEV void put(uint32_t const e, TCol const & c) const
+	{
+		LDSQ uint64_t * p = w + (e*4)*64 + lane;
+		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1; sc[e*64+lane] = static_cast<uint16_t>(c.score);
+	}
+	DEV TCol get(uint32_t const e) const
+	{
+		LDSQ uint64_t const * p = w + (e*4)*64 + lane;
+		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; c.score = sc[e*64+lane]; return c;
+	}
+};
+// host emulation: plain arrays of one thread
+struct TraceStoreMem
+{
+	uint64_t * w; uint16_t * sc;
+	void put(uint32_t const e, TCol const & c) const { w[e*4] = c.pv0; w[e*4+1] = c.mv0; w[e*4+2] = c.pv1; w[e*4+3] = c.mv1; sc[e] = static_cast<uint16_t>(c.score); }
+	TCol get(uint32_t const e) const { TCol c; c.pv0 = w[e*4]; c.mv0 = w[e*4+1]; c.pv1 = w[e*4+2]; c.mv1 = w[e*4+3]; c.score = sc[e]; return c; }
+};
+HDEV uint32_t traceSlots(uint32_t const maxcols) { return maxcols/TRS + 1 + TRS; }     // checkpoints 0,TRS,2*TRS,.. + one segment
+
+// Myers / Hyyro column step: C = column c -> column c+1 for B symbol tc
+DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, uint64_t const mask0, uint64_t const mask1, bool const two, uint64_t const top)
+{
+	uint64_t const Eq0 = peq[2*tc], Eq1 = peq[2*tc+1];
+	uint64_t const Xv0 = Eq0 | C.mv0;
+	uint64_t const Xh0 = (((Eq0 & C.pv0) + C.pv0) ^ C.pv0) | Eq0;
+	uint64_t Ph0 = C.mv0 | ~(Xh0 | C.pv0);
+	uint64_t Mh0 = C.pv0 & Xh0;
+	uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
+	if ( !two ) { if ( Ph0 & top ) ++C.score; else if ( Mh0 & top ) --C.score; }
+	Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
+	C.pv0 = (Mh0 | ~(Xv0 | Ph0)) & mask0;
+	C.mv0 = (Ph0 & Xv0) & mask0;
+	if ( two )
+	{
+		uint64_t const Eq1c = Eq1 | mhc;
+		uint64_t const Xv1 = Eq1 | C.mv1;
+		uint64_t const Xh1 = (((Eq1c & C.pv1) + C.pv1) ^ C.pv1) | Eq1c;
+		uint64_t Ph1 = C.mv1 | ~(Xh1 | C.pv1);
+		uint64_t Mh1 = C.pv1 & Xh1;
+		if ( Ph1 & top ) ++C.score; else if ( Mh1 & top ) --C.score;
+		Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
+		C.pv1 = (Mh1 | ~(Xv1 | Ph1)) & mask1;
+		C.mv1 = (Ph1 & Xv1) & mask1;
+	}
+}
+
+// task = block id; ST = column store of this thread (traceSlots(B.maxcols) slots)
+template<typename ST>
+DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 {
 	uint32_t const oi = B.blk_ovl[task];
 	DevOvl const o = B.ovl[oi];
@@ -94,7 +154,7 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, uint32_t const ti
 	uint32_t const a1 = (ai+ts) < o.aepos ? (ai+ts) : o.aepos;
 	uint32_t const m = a1-a0;
 	uint32_t const b0 = B.blk_b0[task];
-	uint32_t const n = B.trace[o.trace_off + 2*bi + 1];
+	uint32_t const n = B.trace_bytes == 2 ? reinterpret_cast<uint16_t const *>(B.trace)[o.trace_off + 2*bi + 1] : B.trace[o.trace_off + 2*bi + 1];
 	if ( m > 128 || n > B.maxcols || m == 0 ) { if ( m ) atomicOrFlag(B.errflag); return; }
 
 	uint64_t const aoff = B.boff[pile.aread]; uint32_t const arl = B.rlen[pile.aread];
@@ -111,81 +171,84 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, uint32_t const ti
 	uint64_t const mask0 = (m >= 64) ? ~0ull : ((1ull<<m)-1);
 	uint64_t const mask1 = (m <= 64) ? 0ull : ((m == 128) ? ~0ull : ((1ull<<(m-64))-1));
 	bool const two = m > 64;
-	uint64_t Pv0 = mask0, Mv0 = 0, Pv1 = mask1, Mv1 = 0;
-	uint32_t score = m;
 	uint64_t const top = two ? (1ull<<(m-65)) : (1ull<<(m-1));
-	uint64_t const stride = B.nthreads;
-	for ( uint32_t c = 0; c < n; ++c )
+	uint32_t const ncp = B.maxcols/TRS + 1;     // slots [0,ncp): checkpoints, [ncp,ncp+TRS): columns g*TRS+1 .. g*TRS+TRS of the loaded segment
+	TCol C; C.pv0 = mask0; C.mv0 = 0; C.pv1 = mask1; C.mv1 = 0; C.score = m;
+	st.put(0,C);
+	// B symbols are fetched TRS at a time (independent loads, one wait) and kept packed 2 bits each
+	#define DACC_LOADB(c0_,cnt_,dst_) { dst_ = 0; _Pragma("unroll") for ( uint32_t u = 0; u < TRS; ++u ) if ( u < (cnt_) ) dst_ |= static_cast<uint32_t>(readBase(B.bps,boffs,brl,inv,b0+(c0_)+u)) << (2*u); }
+	for ( uint32_t c0 = 0; c0 < n; c0 += TRS )
 	{
-		uint8_t const tc = readBase(B.bps,boffs,brl,inv,b0+c);
-		uint64_t const Eq0 = peq[2*tc], Eq1 = peq[2*tc+1];
-		uint64_t const Xv0 = Eq0 | Mv0;
-		uint64_t const Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
-		uint64_t Ph0 = Mv0 | ~(Xh0 | Pv0);
-		uint64_t Mh0 = Pv0 & Xh0;
-		uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
-		if ( !two ) { if ( Ph0 & top ) ++score; else if ( Mh0 & top ) --score; }
-		Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
-		Pv0 = (Mh0 | ~(Xv0 | Ph0)) & mask0;
-		Mv0 = (Ph0 & Xv0) & mask0;
-		if ( two )
-		{
-			uint64_t const Eq1c = Eq1 | mhc;
-			uint64_t const Xv1 = Eq1 | Mv1;
-			uint64_t const Xh1 = (((Eq1c & Pv1) + Pv1) ^ Pv1) | Eq1c;
-			uint64_t Ph1 = Mv1 | ~(Xh1 | Pv1);
-			uint64_t Mh1 = Pv1 & Xh1;
-			if ( Ph1 & top ) ++score; else if ( Mh1 & top ) --score;
-			Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
-			Pv1 = (Mh1 | ~(Xv1 | Ph1)) & mask1;
-			Mv1 = (Ph1 & Xv1) & mask1;
-		}
-		uint64_t * col = B.colv + ((static_cast<uint64_t>(c+1))*stride + tid)*4;
-		col[0] = Pv0; col[1] = Mv0; col[2] = Pv1; col[3] = Mv1;
-		B.colbot[(static_cast<uint64_t>(c+1))*stride + tid] = score;
+		uint32_t const cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
+		uint32_t bb; DACC_LOADB(c0,cnt,bb)
+		for ( uint32_t u = 0; u < cnt; ++u ) traceStep(peq,(bb>>(2*u))&3,C,mask0,mask1,two,top);
+		if ( cnt == TRS ) st.put(c0/TRS+1,C);
 	}
-	// traceback
-	uint32_t i = m, j = n, d = score;
-	while ( i )
+	// window boundaries are rare among the A positions: x is a window start iff x % a == 0 or x == l-w, a window end iff
+	// (x-w) % a == 0 or x == l; x % a is tracked incrementally (no division per step)
+	uint32_t const wa = B.P.w % B.P.a, lw = pile.l >= B.P.w ? pile.l - B.P.w : 0xFFFFFFFFu;
+	uint32_t xa = (a0+m) % B.P.a;
+	#define DACC_EMIT(x_,b_) { uint32_t const xx_ = (x_); if ( xa == 0 || xa == wa || xx_ == lw || xx_ == pile.l ) emitBoundary(B,pile,o,xx_,b_); }
+	#define DACC_XDEC { xa = xa ? xa-1 : B.P.a-1; }
+	// traceback.  Step (i,j) with j >= 1 reads columns j and j-1 and the B symbol of step j, all of which lie in segment
+	// (j-1)/TRS or are checkpoints.  The segments are visited in a loop that is uniform over the wavefront (top segment of
+	// the batch downwards), so the lanes recompute their segments in lock step instead of one lane at a time.
+	uint32_t i = m, j = n, d = C.score;
+	for ( int32_t g = static_cast<int32_t>((B.maxcols ? B.maxcols-1 : 0)/TRS); g >= 0; --g )
 	{
-		// column j vectors
-		uint64_t cp0, cm0, cp1, cm1;
-		if ( j ) { uint64_t const * col = B.colv + (static_cast<uint64_t>(j)*stride + tid)*4; cp0 = col[0]; cm0 = col[1]; cp1 = col[2]; cm1 = col[3]; }
-		else { cp0 = mask0; cm0 = 0; cp1 = mask1; cm1 = 0; }
-		bool done = false;
-		if ( j )
+		if ( !(i && j && (j-1)/TRS == static_cast<uint32_t>(g)) ) continue;
+		uint32_t bseg;
 		{
-			// D[i-1][j-1] = bottom(j-1) - sum of vertical deltas of rows i..m in column j-1
-			uint64_t qp0, qm0, qp1, qm1; uint32_t bot;
-			if ( j-1 ) { uint64_t const * col = B.colv + (static_cast<uint64_t>(j-1)*stride + tid)*4; qp0 = col[0]; qm0 = col[1]; qp1 = col[2]; qm1 = col[3]; bot = B.colbot[static_cast<uint64_t>(j-1)*stride + tid]; }
-			else { qp0 = mask0; qm0 = 0; qp1 = mask1; qm1 = 0; bot = m; }
-			uint32_t const sh = i-1;
-			int32_t sum;
-			if ( sh < 64 ) sum = dacc_popc64(qp0>>sh) + dacc_popc64(qp1) - dacc_popc64(qm0>>sh) - dacc_popc64(qm1);
-			else sum = dacc_popc64(qp1>>(sh-64)) - dacc_popc64(qm1>>(sh-64));
-			uint32_t const dd = bot - sum;
-			uint8_t const ca = readBase(B.bps,aoff,arl,false,a0+i-1);
-			uint8_t const cb = readBase(B.bps,boffs,brl,inv,b0+j-1);
-			uint32_t const neq = (ca != cb);
-			if ( dd + neq == d )
+			TCol R = st.get(g);
+			uint32_t const c0 = g*TRS, cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
+			DACC_LOADB(c0,cnt,bseg)
+			for ( uint32_t u = 0; u < cnt; ++u )
 			{
-				emitBoundary(B,pile,o,a0+i,b0+j);
-				--i; --j; d = dd; done = true;
+				traceStep(peq,(bseg>>(2*u))&3,R,mask0,mask1,two,top);
+				st.put(ncp + u,R);
 			}
 		}
-		if ( !done )
+		while ( i && j && (j-1)/TRS == static_cast<uint32_t>(g) )
 		{
-			uint32_t const r = i-1;
-			bool const plus = (r < 64) ? ((cp0>>r)&1) : ((cp1>>(r-64))&1);
-			if ( plus )
+			bool done = false;
 			{
-				emitBoundary(B,pile,o,a0+i,b0+j);
-				--i; d = d-1; done = true;
+				// D[i-1][j-1] = bottom(j-1) - sum of vertical deltas of rows i..m in column j-1
+				TCol const q = ((j-1) % TRS) ? st.get(ncp + (j-2) % TRS) : st.get((j-1)/TRS);
+				uint32_t const sh = i-1;
+				int32_t sum;
+				if ( sh < 64 ) sum = dacc_popc64(q.pv0>>sh) + dacc_popc64(q.pv1) - dacc_popc64(q.mv0>>sh) - dacc_popc64(q.mv1);
+				else sum = dacc_popc64(q.pv1>>(sh-64)) - dacc_popc64(q.mv1>>(sh-64));
+				uint32_t const dd = q.score - sum;
+				// A[i-1] == B[j-1] <=> bit i-1 of the pattern mask of B's symbol
+				uint32_t const cb = (bseg >> (2*((j-1) - g*TRS))) & 3;
+				uint32_t const neq = ((peq[2*cb + (sh>>6)] >> (sh&63)) & 1) ? 0u : 1u;
+				if ( dd + neq == d )
+				{
+					DACC_EMIT(a0+i,b0+j)
+					--i; --j; d = dd; done = true; DACC_XDEC
+				}
 			}
+			if ( !done )
+			{
+				uint32_t const r = i-1;
+				uint64_t cp0, cp1;
+				if ( j % TRS ) { TCol const cj = st.get(ncp + (j-1) % TRS); cp0 = cj.pv0; cp1 = cj.pv1; }
+				else { TCol const cj = st.get(j/TRS); cp0 = cj.pv0; cp1 = cj.pv1; }
+				bool const plus = (r < 64) ? ((cp0>>r)&1) : ((cp1>>(r-64))&1);
+				if ( plus )
+				{
+					DACC_EMIT(a0+i,b0+j)
+					--i; d = d-1; done = true; DACC_XDEC
+				}
+			}
+			if ( !done ) { --j; d = d-1; }
 		}
-		if ( !done ) { --j; d = d-1; }
-		(void)cm0; (void)cm1;
 	}
+	// column 0: only A symbols are left (vertical deltas of the first column are all +1)
+	while ( i ) { DACC_EMIT(a0+i,b0) --i; DACC_XDEC }
+	#undef DACC_EMIT
+	#undef DACC_XDEC
+	#undef DACC_LOADB
 	// the overlap's first A position: no step consumed yet, P(abpos) = bbpos
 	if ( a0 == static_cast<uint32_t>(o.abpos) ) emitBoundary(B,pile,o,a0,b0);
 }

@@ -33,6 +33,7 @@ struct VoteBatch
 	uint64_t const * fragbase;
 	uint32_t * nfrag;         // per pile
 	uint32_t * errflag;
+	uint8_t const * pilebad;  // per pile: dropped (a window could not be processed), 0 = no such list
 };
 
 DEV uint32_t pileNpos(DevPile const & pile) { return (pile.l > pile.rl ? pile.l : pile.rl) + 1; }

@@ -53,13 +53,16 @@ def lib():
         L.dacc_debug_tables.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
         L.dacc_debug_profile.argtypes = [vp, vp]
         L.dacc_debug_retry.argtypes = [vp, vp, C.c_uint64, vp]
+        L.dacc_pile_status.argtypes = [vp, vp, C.c_uint64, vp]
+        L.dacc_pile_errors.restype = C.c_char_p
+        L.dacc_pile_errors.argtypes = [vp]
         _lib = L
     return _lib
 
 
 EXPORTS = ["dacc_create", "dacc_destroy", "dacc_set_error_profile", "dacc_load_db", "dacc_submit_piles", "dacc_collect",
            "dacc_release", "dacc_last_error", "dacc_pile_select", "dacc_last_timing", "dacc_rerun_resident",
-           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile", "dacc_debug_retry"]
+           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile", "dacc_debug_retry", "dacc_pile_status", "dacc_pile_errors"]
 
 
 def _ptr(a):
@@ -119,7 +122,7 @@ class Engine:
         """Correct a batch of piles; returns (fragments, bases)."""
         piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
         self._chk(self.L.dacc_submit_piles(self.h, _ptr(piles), len(piles), _ptr(ovl), len(ovl), _ptr(trace),
-                                           len(trace) // trace_bytes, trace_bytes))
+                                           trace.nbytes // trace_bytes, trace_bytes))
         return self.collect()
 
     correct = __call__
@@ -153,6 +156,16 @@ class Engine:
         out = np.zeros(32, dtype=np.uint64)
         self._chk(self.L.dacc_debug_profile(self.h, _ptr(out)))
         return out
+
+    def pile_status(self):
+        """(status per pile of the last batch, list of messages for dropped piles)."""
+        n = C.c_uint64()
+        self._chk(self.L.dacc_pile_status(self.h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.int32)
+        if n.value:
+            self._chk(self.L.dacc_pile_status(self.h, _ptr(out), n.value, C.byref(n)))
+        msg = (self.L.dacc_pile_errors(self.h) or b"").decode()
+        return out, [m for m in msg.split("\n") if m]
 
     def debug_retry(self):
         n = C.c_uint64()

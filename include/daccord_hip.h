@@ -143,6 +143,14 @@ typedef struct dacc_timing {
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 
+/* Per-pile outcome of the last dacc_submit_piles, in submission order: DACC_OK, or the reason the pile was dropped
+ * (DACC_EINVAL: malformed overlap / trace records; DACC_ENOTSUP: a window beyond every engine's capacity).  A dropped
+ * pile yields zero fragments and the batch goes on -- the reference logs the exception of one read and continues with
+ * the next (src/daccord.cpp:2464-2478).  dacc_pile_errors returns the messages a caller would log (one per line, at
+ * most 64), valid until the next call on this context. */
+int  dacc_pile_status(dacc_ctx *ctx, int32_t *status, uint64_t cap, uint64_t *n);
+const char *dacc_pile_errors(dacc_ctx *ctx);
+
 /* Re-run only the device part of the last submitted batch (inputs already resident
  * in HBM); used by bench.py so the timed region excludes H2D. */
 int  dacc_rerun_resident(dacc_ctx *ctx);

@@ -99,7 +99,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		for ( int32_t i = 0; i < BP.ovl[o].nblk; ++i )
 		{
 			blk_ovl[BP.ovl[o].blk0+i] = o; blk_b0[BP.ovl[o].blk0+i] = b;
-			b += tr[BP.ovl[o].trace_off+2*i+1];
+			b += trace_bytes == 2 ? reinterpret_cast<uint16_t const *>(trace)[BP.ovl[o].trace_off+2*i+1] : tr[BP.ovl[o].trace_off+2*i+1];
 		}
 	}
 	std::vector<uint32_t> wt_b(BP.nwt+1,0xDEADBEEF), wt_e(BP.nwt+1,0xDEADBEEF);
@@ -110,9 +110,10 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		TB.piles = BP.piles.data(); TB.ovl = BP.ovl.data(); TB.ovl_pile = BP.ovl_pile.data(); TB.trace = tr;
 		TB.blk_ovl = blk_ovl.data(); TB.blk_b0 = blk_b0.data(); TB.nblocks = BP.nblocks;
 		TB.wt_b = wt_b.data(); TB.wt_e = wt_e.data();
-		std::vector<uint64_t> colv((BP.maxcols+2)*4); std::vector<uint16_t> colbot(BP.maxcols+2);
-		TB.colv = colv.data(); TB.colbot = colbot.data(); TB.maxcols = BP.maxcols; TB.nthreads = 1; TB.errflag = &errflag;
-		for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,0);
+		std::vector<uint64_t> colw(traceSlots(BP.maxcols)*4); std::vector<uint16_t> colsc(traceSlots(BP.maxcols));
+		TraceStoreMem st; st.w = colw.data(); st.sc = colsc.data();
+		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag;
+		for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);
 	}
 	if ( errflag ) { c->err = "trace kernel capacity exceeded"; return DACC_ENOTSUP; }
 	for ( uint64_t i = 0; i < BP.nwt; ++i ) if ( wt_b[i] == 0xDEADBEEF || wt_e[i] == 0xDEADBEEF ) { c->err = "window table entry not written"; return DACC_EHIP; }
@@ -248,7 +249,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 	VoteBatch VB;
 	VB.P = P; VB.bps = c->bps.data(); VB.boff = c->boff.data(); VB.rlen = c->rlen.data(); VB.piles = BP.piles.data(); VB.npiles = BP.piles.size();
 	VB.wrec = wrec.data(); VB.has = has.data(); VB.ld0 = ld0.data(); VB.oc = oc.data(); VB.ocs = ocs.data(); VB.outsym = outsym.data();
-	VB.frags = vf.data(); VB.fragbase = BP.fragbase.data(); VB.nfrag = nfrag.data(); VB.errflag = &errflag;
+	VB.frags = vf.data(); VB.fragbase = BP.fragbase.data(); VB.nfrag = nfrag.data(); VB.errflag = &errflag; VB.pilebad = 0;
 	c->frags.clear(); c->bases.clear();
 	for ( uint64_t pi = 0; pi < BP.piles.size(); ++pi )
 	{

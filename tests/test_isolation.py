@@ -1,0 +1,57 @@
+"""Boundary behaviour of the C ABI: a pile that cannot be processed is dropped and reported, the batch
+goes on (the reference logs the exception of one read and continues, src/daccord.cpp:2464-2478); 2-byte trace values."""
+import numpy as np
+import pytest
+import pyoracle
+import emul_lib
+from daccord_amd._structs import default_params
+from common import frags_equal
+
+
+def _corrupt(ovl, piles, trace, pi):
+    """break the trace of the first overlap of pile pi: its B lengths no longer sum to bepos-bbpos"""
+    tr = trace.copy()
+    o = ovl[piles[pi]["first_ovl"]]
+    tr[o["trace_off"] + 1] = (int(tr[o["trace_off"] + 1]) + 7) % 200
+    return tr
+
+
+def test_malformed_pile_is_dropped_not_fatal_emulation(small_data):
+    d, ovl, piles = small_data
+    p = default_params(k=8)
+    tr = _corrupt(ovl, piles, d.trace, 1)
+    E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E.run(piles[:3], ovl, tr)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[[0, 2]], ovl, d.trace, nthreads=2)
+    assert frags_equal(fo, bo, fx, bx)
+    assert not (fx["aread"] == piles[1]["aread"]).any()
+
+
+@pytest.mark.gpu
+def test_malformed_pile_is_dropped_and_reported(small_data):
+    from daccord_amd import engine
+    d, ovl, piles = small_data
+    p = default_params(k=8, producefull=1)
+    tr = _corrupt(ovl, piles, d.trace, 2)
+    E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E(piles[:5], ovl, tr)
+    st, msgs = E.pile_status()
+    assert list(st) == [0, 0, -1, 0, 0]
+    assert len(msgs) == 1 and ("read %d" % piles[2]["aread"]) in msgs[0]
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[[0, 1, 3, 4]], ovl, d.trace, nthreads=4)
+    assert frags_equal(fo, bo, fx, bx)
+
+
+@pytest.mark.gpu
+def test_two_byte_trace_values(small_data):
+    from daccord_amd import engine
+    d, ovl, piles = small_data
+    p = default_params(k=8)
+    E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    f1, b1 = E(piles[:4], ovl, d.trace)
+    f2, b2 = E(piles[:4], ovl, d.trace.astype(np.uint16), trace_bytes=2)
+    assert frags_equal(f1, b1, f2, b2) and len(b1)
+    st, msgs = E.pile_status()
+    assert (st == 0).all() and not msgs
