@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libdaccord_hip.so")
 IOLIB = os.path.join(_HERE, "libdaccord_io.so")
+CLI = os.path.join(_HERE, "daccord_hip")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-Wno-unused-value"]
@@ -22,7 +23,8 @@ def build_hip(force=False, verbose=False):
     if force or _newer(LIB, srcs):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "host_tables.cpp"),
-                                       os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_io.cpp")]
+                                       os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_io.cpp"),
+                                       os.path.join(CSRC, "host_eprof.cpp")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -37,23 +39,33 @@ def build_prof(force=False):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         subprocess.check_call([hipcc] + HIPCC_FLAGS + ["-DDACC_PROFILE", "-o", out, os.path.join(CSRC, "capi.hip"),
                                os.path.join(CSRC, "host_tables.cpp"), os.path.join(CSRC, "host_piles.cpp"),
-                               os.path.join(CSRC, "host_io.cpp")])
+                               os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_eprof.cpp")])
     return out
 
 
 def build_io(force=False):
     """Host-only library with the .db / .las readers and writers (include/daccord_io.h) and the pile selection;
     the same objects are also linked into libdaccord_hip.so."""
-    srcs = [os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_piles.cpp"),
+    srcs = [os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_eprof.cpp"),
             os.path.join(_HERE, "..", "include", "daccord_io.h"), os.path.join(_HERE, "..", "include", "daccord_hip.h")]
     if force or _newer(IOLIB, srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", IOLIB, srcs[0], srcs[1]])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", IOLIB, srcs[0], srcs[1], srcs[2]])
     return IOLIB
+
+
+def build_cli(force=False):
+    """daccord_hip: the daccord command line (C++ host program) on libdaccord_hip.so."""
+    src = os.path.join(CSRC, "daccord_hip_main.cpp")
+    if force or _newer(CLI, [src, LIB, os.path.join(_HERE, "..", "include", "daccord_io.h"), os.path.join(_HERE, "..", "include", "daccord_hip.h")]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", CLI, src, "-L" + _HERE, "-ldaccord_hip",
+                               "-Wl,-rpath,$ORIGIN", "-Wl,--allow-shlib-undefined"])
+    return CLI
 
 
 def build_all(force=False, verbose=False):
     from . import synth
     build_hip(force, verbose)
     build_io(force)
+    build_cli(force)
     synth.build(force)
     return LIB

@@ -1,0 +1,291 @@
+/*
+ * daccord_hip -- the `daccord` command line on the MI355X path:
+ *
+ *     daccord_hip [options] reads.las reads.db [reads2.db]
+ *
+ * Host program above the C ABI (include/daccord_hip.h, include/daccord_io.h); the argument grammar, the read interval
+ * logic and the ordered FASTA output follow src/daccord.cpp:
+ *   :185-207, 1282-1305  options (flag and value joined: -w40 -k8 -I0,99; options precede the positionals)
+ *   :1156-1183           -J<i,j>  part i of j of the A-read range (takes precedence over -I)
+ *   :1222-1230           -I<lo,hi> both ends inclusive, intersected with the range of the .las
+ *   :2120-2126           --vard<v> per-read depth cap instead of -D
+ *   :2107-2112, 2481-2534 piles in A-read order, output in A-read order
+ *   HandleContext.hpp:2710-2724 FASTA records; the middle name field is numbered sequentially (the reference's -t1
+ *                        numbering; with -t>1 its numbering depends on the thread schedule)
+ *   :2464-2478           a read that fails is logged on stderr and skipped
+ * -t and -T are accepted and ignored (no host worker threads, no temporary files).  The error profile comes from
+ * --eprof<p_i,p_d,est_cor>, from -E<file> / <las>.eprof holding the three numbers as text (our own format: the binary
+ * .eprof of the reference is a libmaus2 serialisation that is not in the reference tree), or is estimated from the
+ * first 1024 piles like src/daccord.cpp:1653-1878 does (and written to <las>.eprof unless --eprofonly... see below).
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <fstream>
+#include <sstream>
+#include <iostream>
+#include <thread>
+#include "../../include/daccord_hip.h"
+#include "../../include/daccord_io.h"
+
+namespace {
+
+struct Options
+{
+	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
+	bool f = false; int V = 1; bool haveI = false, haveJ = false; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
+	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
+	bool eprofonly = false, keepeprof = false;
+	std::vector<std::string> pos;
+};
+
+[[noreturn]] void die(std::string const & m) { std::fprintf(stderr,"[E] %s\n",m.c_str()); std::exit(EXIT_FAILURE); }
+
+bool parsePair(std::string const & s, int64_t & x, int64_t & y)
+{
+	std::istringstream is(s); char c = 0;
+	if ( !(is >> x) ) return false;
+	if ( !(is.get(c)) || c != ',' ) return false;
+	if ( !(is >> y) ) return false;
+	return is.peek() == std::istringstream::traits_type::eof();
+}
+
+uint64_t num(std::string const & opt, std::string const & v)
+{
+	if ( v.empty() ) die("option " + opt + " needs a value");
+	char * end = 0; unsigned long long const x = std::strtoull(v.c_str(),&end,10);
+	if ( *end ) die("unable to parse " + opt + v);
+	return x;
+}
+
+Options parse(int argc, char ** argv)
+{
+	Options o;
+	for ( int i = 1; i < argc; ++i )
+	{
+		std::string const a = argv[i];
+		if ( !o.pos.empty() || a.size() < 2 || a[0] != '-' ) { o.pos.push_back(a); continue; }
+		if ( a[1] == '-' )
+		{
+			auto val = [&](char const * name, std::string & out) -> bool {
+				std::string const p = std::string("--") + name;
+				if ( a.compare(0,p.size(),p) != 0 ) return false;
+				out = a.substr(p.size()); if ( !out.empty() && out[0] == '=' ) out = out.substr(1);
+				return true;
+			};
+			std::string v;
+			if ( val("minfilterfreq",v) ) o.minff = static_cast<int32_t>(num("--minfilterfreq",v));
+			else if ( val("maxfilterfreq",v) ) o.maxff = static_cast<int32_t>(num("--maxfilterfreq",v));
+			else if ( val("vard",v) ) o.vard = num("--vard",v);
+			else if ( val("eprofonly",v) ) o.eprofonly = v.empty() || v != "0";
+			else if ( val("keepeprof",v) ) o.keepeprof = v.empty() || v != "0";
+			else if ( val("eprof",v) ) o.eprof = v;
+			else if ( val("deepprofileonly",v) ) die("--deepprofileonly (k-mer depth profile of the estimator) is not part of this path");
+			else die("unknown option " + a);
+			continue;
+		}
+		char const key = a[1]; std::string const v = a.substr(2);
+		switch ( key )
+		{
+			case 'w': o.w = num("-w",v); break;
+			case 'a': o.a = num("-a",v); break;
+			case 'm': o.m = num("-m",v); break;
+			case 'l': o.l = num("-l",v); break;
+			case 'D': o.D = num("-D",v); break;
+			case 'd': o.d = num("-d",v); break;
+			case 'e': o.e = num("-e",v); break;
+			case 'V': o.V = v.empty() ? 1 : static_cast<int>(num("-V",v)); break;
+			case 'f': o.f = v.empty() ? true : (num("-f",v) != 0); break;
+			case 't': case 'T': break;
+			case 'E': o.E = v; break;
+			case 'I': o.haveI = true; if ( !parsePair(v,o.Ilo,o.Ihi) ) die("unable to parse " + v); break;
+			case 'J': o.haveJ = true; if ( !parsePair(v,o.Jc,o.Jd) ) die("unable to parse " + v); break;
+			case 'k':
+			{
+				int64_t x, y;
+				if ( parsePair(v,x,y) ) { o.klow = x; o.khigh = y; } else { o.klow = o.khigh = num("-k",v); }
+				break;
+			}
+			default: die("unknown option " + a);
+		}
+	}
+	if ( o.pos.size() < 2 )
+	{
+		std::fprintf(stderr,"usage: daccord_hip [options] reads.las reads.db [reads2.db]\n"
+			"  -w<40> window  -a<10> advance  -k<8|lo,hi> k-mer size  -d<max depth>  -D<5000> max alignments per read  --vard<v>\n"
+			"  -m<3> min window coverage  -e<max window error>  -l<0> min output length  -f produce full reads\n"
+			"  -I<lo,hi> read interval (inclusive)  -J<i,j> part i of j  --minfilterfreq<0> --maxfilterfreq<2>\n"
+			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof\n");
+		std::exit(EXIT_FAILURE);
+	}
+	return o;
+}
+
+bool readProfileText(std::string const & fn, double v[3])
+{
+	std::ifstream in(fn.c_str());
+	if ( !in ) return false;
+	std::string s((std::istreambuf_iterator<char>(in)),std::istreambuf_iterator<char>());
+	for ( size_t i = 0; i < s.size(); ++i ) if ( s[i] == ',' ) s[i] = ' ';
+	std::istringstream is(s);
+	return static_cast<bool>(is >> v[0] >> v[1] >> v[2]);
+}
+
+struct Db { dacc_db * h = 0; uint8_t const * bps = 0; uint64_t nbytes = 0; uint64_t const * boff = 0; uint32_t const * rlen = 0; uint64_t n = 0; };
+void openDb(std::string const & fn, Db & d)
+{
+	if ( dacc_db_open(fn.c_str(),&d.h) ) die("cannot open database " + fn + ": " + (d.h ? dacc_db_error(d.h) : "out of memory"));
+	if ( dacc_db_arrays(d.h,&d.bps,&d.nbytes,&d.boff,&d.rlen,&d.n) ) die(std::string("database: ") + dacc_db_error(d.h));
+}
+
+}
+
+int main(int argc, char ** argv)
+{
+	Options const o = parse(argc,argv);
+	std::string const lasfn = o.pos[0];
+	dacc_las * las = 0;
+	if ( dacc_las_open(lasfn.c_str(),&las) ) die("cannot open " + lasfn + ": " + (las ? dacc_las_error(las) : "out of memory"));
+	int64_t novl = 0, lasmin = 0, lasmax = -1; int32_t tspace = 0, tbytes = 1;
+	if ( dacc_las_info(las,&novl,&tspace,&tbytes,&lasmin,&lasmax) ) die(std::string("las: ") + dacc_las_error(las));
+
+	Db A, B2; openDb(o.pos[1],A);
+	bool const twodb = o.pos.size() > 2;
+	if ( twodb && o.vard ) die("vard option is not supported for asymmetric (DB1 != DB2) alignments");       // daccord.cpp:1342-1348
+	std::vector<uint8_t> bps; std::vector<uint64_t> boff; std::vector<uint32_t> rlen;
+	uint64_t nA = 0;
+	if ( twodb )
+	{
+		// asymmetric mode (daccord.cpp:1337-1364): A reads from the first database, B reads from the second; on the device
+		// both live in one read store, ids of B shifted behind A's
+		openDb(o.pos[2],B2);
+		bps.assign(A.bps,A.bps+A.nbytes); bps.insert(bps.end(),B2.bps,B2.bps+B2.nbytes);
+		boff.assign(A.boff,A.boff+A.n); for ( uint64_t i = 0; i < B2.n; ++i ) boff.push_back(B2.boff[i]+A.nbytes);
+		rlen.assign(A.rlen,A.rlen+A.n); rlen.insert(rlen.end(),B2.rlen,B2.rlen+B2.n);
+		nA = A.n;
+	}
+	uint8_t const * const pbps = twodb ? bps.data() : A.bps; uint64_t const nbps = twodb ? bps.size() : A.nbytes;
+	uint64_t const * const pboff = twodb ? boff.data() : A.boff; uint32_t const * const prlen = twodb ? rlen.data() : A.rlen;
+	uint64_t const nreads = twodb ? rlen.size() : A.n;
+	// average read length of the B database (DB2.getAverageReadLength(), daccord.cpp:1366): --vard scales with it
+	Db const & DB2 = twodb ? B2 : A;
+	uint64_t tot = 0; for ( uint64_t i = 0; i < DB2.n; ++i ) tot += DB2.rlen[i];
+	uint64_t const avgrl = DB2.n ? tot/DB2.n : 0;
+
+	// read interval (daccord.cpp:1096-1230)
+	int64_t minaread = lasmin, maxaread = lasmax;
+	if ( o.haveJ )
+	{
+		int64_t const toparead = maxaread + 1, span = toparead > minaread ? toparead-minaread : 0;
+		if ( span && !o.Jd ) die("denominator of J argument cannot be zero");
+		if ( toparead > minaread )
+		{
+			int64_t const part = o.Jd ? (span + o.Jd - 1)/o.Jd : 0;
+			int64_t const ilow = std::min(minaread + o.Jc*part,toparead), ihigh = std::min(ilow+part,toparead);
+			if ( ihigh > ilow ) { minaread = ilow; maxaread = ihigh-1; } else { minaread = 0; maxaread = -1; }
+		}
+	}
+	else if ( o.haveI ) { minaread = std::max(o.Ilo,minaread); maxaread = std::min(o.Ihi,maxaread); }
+	int64_t const toparead = maxaread >= 0 ? maxaread+1 : maxaread;
+	if ( o.V ) std::fprintf(stderr,"[V] minaread=%lld toparead=%lld\n",static_cast<long long>(minaread),static_cast<long long>(toparead));
+
+	dacc_params p; std::memset(&p,0,sizeof(p));
+	p.w = o.w; p.a = o.a; p.klow = o.klow; p.khigh = o.khigh; p.minfilterfreq = o.minff; p.maxfilterfreq = o.maxff; p.minwindowcov = o.m;
+	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = 0; p.verbose = o.V;
+	dacc_ctx * ctx = 0;
+	{ int const rc = dacc_create(&ctx,&p); if ( rc ) die("dacc_create failed (" + std::to_string(rc) + "): no usable HIP device or bad parameters"); }
+	if ( dacc_load_db(ctx,pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctx));
+
+	// batch of piles [b0,b1): load, top-D select per pile, shift B ids in two database mode
+	std::vector<dacc_overlap> sel; std::vector<dacc_pile> spiles; std::vector<dacc_overlap> tmp;
+	void const * trace = 0; uint64_t ntrace = 0;
+	auto loadBatch = [&](int64_t const b0, int64_t const b1, bool const lowest) -> void
+	{
+		dacc_pile const * piles = 0; uint64_t npiles = 0; dacc_overlap const * ovl = 0; uint64_t no = 0;
+		if ( dacc_las_piles(las,b0,b1,&piles,&npiles,&ovl,&no,&trace,&ntrace) ) die(std::string("las: ") + dacc_las_error(las));
+		sel.clear(); spiles.clear();
+		for ( uint64_t i = 0; i < npiles; ++i )
+		{
+			uint64_t const rl = prlen[piles[i].aread];
+			uint64_t const lmaxinput = o.vard ? std::max<uint64_t>(std::max<uint64_t>(2*o.vard,1),
+				static_cast<uint64_t>((2.0*static_cast<double>(o.vard)*static_cast<double>(rl)/static_cast<double>(avgrl))+0.5)) : o.D;
+			tmp.resize(std::max<uint64_t>(piles[i].novl,1)); uint64_t nout = 0;
+			int const rc = lowest ? dacc_pile_select_lowest(ovl+piles[i].first_ovl,piles[i].novl,tbytes,lmaxinput,tmp.data(),&nout)
+			                      : dacc_pile_select(ovl+piles[i].first_ovl,piles[i].novl,tbytes,lmaxinput,tmp.data(),&nout);
+			if ( rc ) die("pile selection failed");
+			dacc_pile q; q.aread = piles[i].aread; q.novl = nout; q.first_ovl = sel.size();
+			for ( uint64_t z = 0; z < nout; ++z ) { dacc_overlap v = tmp[z]; v.bread += nA; sel.push_back(v); }
+			spiles.push_back(q);
+		}
+	};
+
+	// error profile
+	double prof[3] = {0,0,0};
+	std::string const eproffn = o.E.empty() ? (lasfn + ".eprof") : o.E;
+	bool have = false;
+	if ( !o.eprof.empty() )
+	{
+		std::string s = o.eprof; for ( size_t i = 0; i < s.size(); ++i ) if ( s[i] == ',' ) s[i] = ' ';
+		std::istringstream is(s); if ( !(is >> prof[0] >> prof[1] >> prof[2]) ) die("--eprof needs three numbers: p_i,p_d,est_cor");
+		have = true;
+	}
+	else if ( readProfileText(eproffn,prof) ) have = true;
+	if ( !have )
+	{
+		// estimate from the first 1024 piles of the interval (daccord.cpp:1653-1878): k=8, w=40, a=5
+		int64_t const top = std::min<int64_t>(toparead,minaread+1024);
+		uint64_t counts[4] = {0,0,0,0}; uint64_t usable = 0, unusable = 0; double eavg = 0, edif = 0;
+		dacc_eprof * ep = 0;
+		if ( dacc_eprof_create(&ep,tspace,pbps,pboff,prlen,nreads,twodb ? 1 : 0) ) die("error profile estimation: out of memory");
+		unsigned int hw = std::thread::hardware_concurrency(); if ( !hw ) hw = 1; if ( hw > 64 ) hw = 64;
+		for ( int64_t b0 = minaread; b0 < top; b0 += 256 )
+		{
+			loadBatch(b0,std::min<int64_t>(top,b0+256),true);
+			if ( spiles.empty() ) continue;
+			if ( dacc_eprof_add(ep,spiles.data(),spiles.size(),sel.data(),sel.size(),trace,ntrace,tbytes,o.d,hw) ) die("error profile estimation: malformed overlap records");
+		}
+		if ( dacc_eprof_finish(ep,counts,&usable,&unusable,&eavg,&edif,prof) ) die("error profile estimation found no usable window; give --eprof<p_i,p_d,est_cor>");
+		dacc_eprof_destroy(ep);
+		std::fprintf(stderr,"usable=%llu unusable=%llu eavg=%g edif=%g\n",static_cast<unsigned long long>(usable),static_cast<unsigned long long>(unusable),eavg,edif);
+		std::fprintf(stderr,"AlignmentStatistics(matches=%llu,mismatches=%llu,insertions=%llu,deletions=%llu)\n",
+			static_cast<unsigned long long>(counts[0]),static_cast<unsigned long long>(counts[1]),static_cast<unsigned long long>(counts[2]),static_cast<unsigned long long>(counts[3]));
+		std::ofstream out(eproffn.c_str());
+		char buf[128]; std::snprintf(buf,sizeof(buf),"%.17g %.17g %.17g\n",prof[0],prof[1],prof[2]); out << buf;
+	}
+	if ( o.V ) std::fprintf(stderr,"[V] p_i=%.17g p_d=%.17g est_cor=%.17g\n",prof[0],prof[1],prof[2]);
+	if ( o.eprofonly ) { dacc_destroy(ctx); return EXIT_SUCCESS; }
+	if ( dacc_set_error_profile(ctx,prof[0],prof[1],prof[2]) ) die(std::string("error profile: ") + dacc_last_error(ctx));
+
+	uint64_t well = 0;
+	int64_t const batch = 2000;
+	std::string rec;
+	for ( int64_t b0 = minaread; b0 < toparead; b0 += batch )
+	{
+		loadBatch(b0,std::min(toparead,b0+batch),false);
+		if ( spiles.empty() ) continue;
+		if ( dacc_submit_piles(ctx,spiles.data(),spiles.size(),sel.data(),sel.size(),trace,ntrace,tbytes) )
+			die(std::string("batch failed: ") + dacc_last_error(ctx));
+		{ char const * pe = dacc_pile_errors(ctx); if ( pe && *pe ) std::fprintf(stderr,"[E] skipped reads:\n%s",pe); }
+		dacc_fragment const * fr = 0; uint64_t nf = 0; char const * bases = 0; uint64_t nb = 0;
+		if ( dacc_collect(ctx,&fr,&nf,&bases,&nb) ) die(std::string("collect: ") + dacc_last_error(ctx));
+		rec.clear();
+		for ( uint64_t i = 0; i < nf; ++i )
+		{
+			char hdr[160];
+			std::snprintf(hdr,sizeof(hdr),">%d/%llu/%u_%u A=[%u,%u]\n",fr[i].aread+1,static_cast<unsigned long long>(well++),fr[i].first,fr[i].first+fr[i].len,fr[i].first,fr[i].last);
+			rec += hdr;
+			for ( uint32_t q = 0; q < fr[i].len; q += 80 ) { rec.append(bases+fr[i].seq_off+q,std::min<uint32_t>(80,fr[i].len-q)); rec += '\n'; }
+		}
+		std::fwrite(rec.data(),1,rec.size(),stdout);
+		dacc_release(ctx);
+	}
+	std::fflush(stdout);
+	dacc_destroy(ctx);
+	dacc_las_close(las); dacc_db_close(A.h); if ( twodb ) dacc_db_close(B2.h);
+	return EXIT_SUCCESS;
+}

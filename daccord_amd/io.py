@@ -27,6 +27,11 @@ def lib():
         L.dacc_las_piles.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64),
                                      C.POINTER(vp), C.POINTER(C.c_uint64)]
         L.dacc_las_write.argtypes = [C.c_char_p, C.c_int32, vp, C.c_uint64, vp, C.c_uint64, C.c_int]
+        L.dacc_pile_select_lowest.argtypes = [vp, C.c_uint64, C.c_int, C.c_uint64, vp, vp]
+        L.dacc_eprof_create.argtypes = [C.POINTER(vp), C.c_int32, vp, vp, vp, C.c_uint64, C.c_int]
+        L.dacc_eprof_add.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
+        L.dacc_eprof_finish.argtypes = [vp] + [vp] * 6
+        L.dacc_eprof_destroy.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -100,3 +105,38 @@ def write_las(path, tspace, ovl, trace):
     rc = lib().dacc_las_write(path.encode(), tspace, _ptr(ovl), len(ovl), _ptr(trace), len(trace), tb)
     if rc:
         raise IOError("dacc_las_write(%s) failed: %d" % (path, rc))
+
+
+def select_lowest(ovl, piles, trace_bytes=1, maxinput=5000):
+    """The estimator's pile selection (include/daccord_hip.h: dacc_pile_select_lowest) for every pile."""
+    L = lib()
+    out = np.zeros(len(ovl), dtype=ovl.dtype); newp = piles.copy(); o = 0
+    for i, p in enumerate(piles):
+        n = C.c_uint64(0)
+        seg = np.ascontiguousarray(ovl[p["first_ovl"]:p["first_ovl"] + p["novl"]])
+        dst = np.zeros(max(len(seg), 1), dtype=ovl.dtype)
+        if L.dacc_pile_select_lowest(_ptr(seg), len(seg), trace_bytes, maxinput, _ptr(dst), C.byref(n)):
+            raise ValueError("dacc_pile_select_lowest")
+        out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value
+    return out[:o].copy(), newp
+
+
+def estimate_profile(bps, boff, rlen, tspace, piles, ovl, trace, trace_bytes=1, maxalign=2 ** 64 - 1, two_databases=False, nthreads=4):
+    """Error profile estimation on the host (include/daccord_hip.h: dacc_eprof_*).  Returns
+    (counts[matches,mismatches,insertions,deletions], usable, unusable, (p_i, p_d, est_cor))."""
+    L = lib(); h = C.c_void_p()
+    bps = np.ascontiguousarray(bps, np.uint8); boff = np.ascontiguousarray(boff, np.uint64); rlen = np.ascontiguousarray(rlen, np.uint32)
+    piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
+    if L.dacc_eprof_create(C.byref(h), tspace, _ptr(bps), _ptr(boff), _ptr(rlen), len(rlen), 1 if two_databases else 0):
+        raise MemoryError("dacc_eprof_create")
+    try:
+        rc = L.dacc_eprof_add(h, _ptr(piles), len(piles), _ptr(ovl), len(ovl), _ptr(trace), trace.nbytes // trace_bytes, trace_bytes, maxalign, nthreads)
+        if rc:
+            raise ValueError("dacc_eprof_add rc=%d" % rc)
+        counts = np.zeros(4, np.uint64); us = C.c_uint64(); un = C.c_uint64(); ea = C.c_double(); ed = C.c_double(); prof = np.zeros(3, np.float64)
+        rc = L.dacc_eprof_finish(h, _ptr(counts), C.byref(us), C.byref(un), C.byref(ea), C.byref(ed), _ptr(prof))
+        if rc:
+            raise ValueError("no usable window (rc=%d)" % rc)
+        return counts, us.value, un.value, tuple(float(x) for x in prof)
+    finally:
+        L.dacc_eprof_destroy(h)

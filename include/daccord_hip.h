@@ -124,6 +124,28 @@ const char *dacc_last_error(dacc_ctx *ctx);
 int  dacc_pile_select(const dacc_overlap *in, uint64_t n, int trace_bytes, uint64_t maxinput,
                       dacc_overlap *out, uint64_t *nout);
 
+/* ---- error profile estimation (host): replaces the sampling pass of src/daccord.cpp:1653-1878 ---- */
+
+/* The estimator's own pile selection (daccord.cpp:1705-1737): the maxinput overlaps with the LOWEST error score,
+ * sorted by abpos (the main path's selection, dacc_pile_select, has the reference's keep-the-worst quirk instead). */
+int  dacc_pile_select_lowest(const dacc_overlap *in, uint64_t n, int trace_bytes, uint64_t maxinput,
+                             dacc_overlap *out, uint64_t *nout);
+
+/* handleIndelEstimate<8> (daccord.cpp:271-631) over batches of piles: windows of 40 bases every 5, k = 8, k-mers seen
+ * at least twice, trivial traversal (DebruijnGraph.hpp:3794-3824), every window string aligned to the window consensus,
+ * alignment operations counted.  The read store (same layout as dacc_load_db) is borrowed until dacc_eprof_destroy;
+ * two_databases != 0: A and B reads come from different databases (the A window then joins the strings, :562-566).
+ * dacc_eprof_finish: counts = {matches, mismatches, insertions, deletions}, prof = {p_i, p_d, est_cor}
+ * (daccord.cpp:1867-1878); DACC_ENOTSUP if no window was usable. */
+typedef struct dacc_eprof dacc_eprof;
+int  dacc_eprof_create(dacc_eprof **e, int32_t tspace, const uint8_t *bps, const uint64_t *boff, const uint32_t *rlen,
+                       uint64_t nreads, int two_databases);
+int  dacc_eprof_add(dacc_eprof *e, const dacc_pile *piles, uint64_t npiles, const dacc_overlap *ovl, uint64_t novl,
+                    const void *trace, uint64_t ntrace, int trace_bytes, uint64_t maxalign, int nthreads);
+int  dacc_eprof_finish(dacc_eprof *e, uint64_t counts[4], uint64_t *usable, uint64_t *unusable,
+                       double *eavg, double *edif, double prof[3]);
+void dacc_eprof_destroy(dacc_eprof *e);
+
 /* ---- measurement hooks (bench.py / profiling; not part of the data path) ---- */
 
 /* Timings of the last dacc_submit_piles in milliseconds, measured with HIP events

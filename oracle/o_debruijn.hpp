@@ -665,6 +665,56 @@ struct DebruijnGraph
 		std::sort(prenodes.begin(),prenodes.begin()+numprenodes);
 	}
 
+	// DebruijnGraph.hpp:1256-1277
+	uint64_t maxForPos(uint64_t const q) const
+	{
+		uint64_t maxv = 0, maxc = 0;
+		for ( uint64_t i = 0; i < numnodes; ++i )
+		{
+			Node const & node = nodes[i];
+			uint64_t c = 0;
+			for ( uint64_t j = 0; j < node.freq; ++j )
+				if ( SP[node.spo+j].pos == q ) ++c;
+			if ( c > maxc ) { maxc = c; maxv = node.v; }
+		}
+		return maxv;
+	}
+	// DebruijnGraph.hpp:1329-1358
+	uint64_t maxLastWord() const
+	{
+		uint64_t maxv = 0, maxc = 0, l = 0;
+		while ( l < lastn )
+		{
+			uint64_t c = 1, h = l+1;
+			while ( h < lastn && (last[h]>>32) == (last[l]>>32) ) { ++c; ++h; }
+			if ( c > maxc ) { maxv = (last[l]>>32); maxc = c; }
+			l = h;
+		}
+		return maxv;
+	}
+	// DebruijnGraph.hpp:3794-3824 with the stretch part of prepareTraverse(false,false,first,last,0,0,false) (:3541-3566);
+	// the feasibility / enumeration part of that call does not touch the stretches
+	bool traverseTrivial()
+	{
+		conso = 0;
+		uint64_t const first = maxForPos(0);
+		uint64_t const lastw = maxLastWord();
+		computeStretches(false);
+		splitStretches(first);
+		splitStretches(lastw);
+		stretchesUnique();
+		for ( uint64_t i = 0; i < stretcho; ++i )
+			if ( stretches[i].first == first && stretches[i].last == lastw )
+			{
+				consPushWord(first,Acons,conso);
+				for ( uint64_t j = 1; j < stretches[i].len; ++j )
+					vpush(Acons,conso,remapChar(stretchLinks[stretches[i].stretchO+j]&3));
+				return true;
+			}
+		return false;
+	}
+	std::string getConsensus() const { return std::string(Acons.begin(),Acons.begin()+conso); }
+
 	// DebruijnGraph.hpp:1280-1304
 	uint64_t maxForPosList(uint64_t const q, std::vector< std::pair<uint64_t,uint64_t> > & PL) const
 	{

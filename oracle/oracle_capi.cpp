@@ -17,6 +17,7 @@
 #include <omp.h>
 #endif
 #include "o_handle.hpp"
+#include "o_eprof.hpp"
 
 using namespace oracle;
 
@@ -296,4 +297,56 @@ extern "C" int oracle_pile_select(dacc_overlap const * in, uint64_t n, int trace
 	std::sort(out,out+o,AbposComparator());
 	*nout = o;
 	return 0;
+
+}
+
+extern "C" {
+
+// src/daccord.cpp:1705-1737, 1755: the estimator's pile selection (lowest scores kept, slots reused, std::sort by abpos)
+struct PairFirstGreaterComp { bool operator()(std::pair<uint64_t,uint64_t> const & A, std::pair<uint64_t,uint64_t> const & B) const { return A.first > B.first; } };
+int oracle_pile_select_lowest(dacc_overlap const * in, uint64_t n, uint64_t lmaxinput, dacc_overlap * RO, uint64_t * nout)
+{
+	FiniteSizeHeap< std::pair<uint64_t,uint64_t>, PairFirstGreaterComp > RH(lmaxinput ? lmaxinput : 1);
+	uint64_t f = 0;
+	for ( uint64_t i = 0; i < n && lmaxinput; ++i )
+	{
+		uint64_t const score = static_cast<uint64_t>(ldexp((static_cast<double>(in[i].diffs) / static_cast<double>(in[i].aepos - in[i].abpos)),30));
+		if ( RH.f == lmaxinput )
+		{
+			if ( score > RH.top().first ) continue;
+			uint64_t const p = RH.top().second;
+			RH.popvoid();
+			RO[p] = in[i];
+			RH.push(std::pair<uint64_t,uint64_t>(score,p));
+		}
+		else { uint64_t const p = f++; RH.push(std::pair<uint64_t,uint64_t>(score,p)); RO[p] = in[i]; }
+	}
+	std::sort(RO,RO+f,[](dacc_overlap const & A, dacc_overlap const & B){ return A.abpos < B.abpos; });
+	*nout = f;
+	return 0;
+}
+
+// src/daccord.cpp:1653-1878: the sampling loop over piles and the derived rates
+int oracle_estimate_profile(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, void const * trace, int trace_bytes,
+	uint64_t maxalign, int twodb, uint64_t * counts, uint64_t * usable, uint64_t * unusable, double * prof)
+{
+	OracleCtx * c = static_cast<OracleCtx *>(v);
+	AlignmentStatistics GAS; uint64_t us = 0, un = 0;
+	for ( uint64_t i = 0; i < npiles; ++i )
+	{
+		AlignmentStatistics LGAS; uint64_t lu = 0, lun = 0;
+		c->db.clear();
+		handleIndelEstimate8(maxalign,ovl+piles[i].first_ovl,ovl+piles[i].first_ovl+piles[i].novl,40,5,c->db,twodb != 0,trace,trace_bytes,c->par.tspace,LGAS,lu,lun);
+		GAS += LGAS; us += lu; un += lun;
+	}
+	counts[0] = GAS.matches; counts[1] = GAS.mismatches; counts[2] = GAS.insertions; counts[3] = GAS.deletions;
+	*usable = us; *unusable = un;
+	uint64_t const len = GAS.matches + GAS.mismatches + GAS.deletions;
+	uint64_t const numerr = GAS.mismatches + GAS.deletions + GAS.insertions;
+	if ( !len ) return -1;
+	double const est_erate = static_cast<double>(numerr) / len;
+	prof[0] = static_cast<double>(GAS.insertions) / len; prof[1] = static_cast<double>(GAS.deletions) / len; prof[2] = 1.0 - est_erate;
+	return 0;
+}
+
 }

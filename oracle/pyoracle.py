@@ -49,6 +49,8 @@ def lib():
         L.oracle_pile_select.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
         L.oracle_window_consensus.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_char_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_pile_select_lowest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.oracle_estimate_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int] + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -75,6 +77,19 @@ def pile_select(ovl, piles, trace_bytes=1, maxinput=5000):
     return out[:o].copy(), newp
 
 
+def select_lowest(ovl, piles, maxinput=5000):
+    """The estimator's pile selection (src/daccord.cpp:1705-1755) for every pile."""
+    L = lib()
+    out = np.zeros(len(ovl), dtype=ovl.dtype); newp = piles.copy(); o = 0
+    for i, p in enumerate(piles):
+        n = C.c_uint64(0)
+        seg = np.ascontiguousarray(ovl[p["first_ovl"]:p["first_ovl"] + p["novl"]])
+        dst = np.zeros(max(len(seg), 1), dtype=ovl.dtype)
+        L.oracle_pile_select_lowest(_ptr(seg), len(seg), maxinput, _ptr(dst), C.byref(n))
+        out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value
+    return out[:o].copy(), newp
+
+
 class Oracle:
     def __init__(self, params):
         self.L = lib()
@@ -95,6 +110,16 @@ class Oracle:
     def load_db(self, bps, boff, rlen):
         self._keep = [np.ascontiguousarray(bps), np.ascontiguousarray(boff), np.ascontiguousarray(rlen)]
         self.L.oracle_load_db(self.h, _ptr(self._keep[0]), len(bps), _ptr(self._keep[1]), _ptr(self._keep[2]), len(rlen))
+
+    def estimate_profile(self, piles, ovl, trace, trace_bytes=1, maxalign=2 ** 64 - 1, two_databases=False):
+        """src/daccord.cpp:1653-1878 over the given (already selected) piles: (counts, usable, unusable, (p_i,p_d,est_cor))."""
+        piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
+        counts = np.zeros(4, np.uint64); us = C.c_uint64(); un = C.c_uint64(); prof = np.zeros(3, np.float64)
+        rc = self.L.oracle_estimate_profile(self.h, _ptr(piles), len(piles), _ptr(ovl), _ptr(trace), trace_bytes, maxalign,
+                                            1 if two_databases else 0, _ptr(counts), C.byref(us), C.byref(un), _ptr(prof))
+        if rc:
+            raise ValueError("no usable window")
+        return counts, us.value, un.value, tuple(float(x) for x in prof)
 
     def run(self, piles, ovl, trace, trace_bytes=1, nthreads=1, want_windows=False):
         piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)

@@ -1,0 +1,34 @@
+"""Error profile estimation: the product's host estimator (include/daccord_hip.h: dacc_eprof_*,
+daccord_amd/csrc/host_eprof.cpp) against the oracle's restatement of src/daccord.cpp:271-631, 1653-1878 -- counts and
+rates bit for bit -- and against the known error mix of the synthetic reads."""
+import numpy as np
+import pytest
+import pyoracle
+from daccord_amd import io as dio
+from daccord_amd._structs import default_params
+from daccord_amd.synth import SynthData
+
+
+@pytest.mark.parametrize("kw,twodb,maxalign", [(dict(seed=1), False, 2 ** 64 - 1), (dict(seed=7, ins_frac=1 / 3., del_frac=1 / 3., sub_frac=1 / 3.), True, 6),
+                                               (dict(seed=9, erate=0.08, tspace=64), False, 2 ** 64 - 1)])
+def test_estimator_matches_oracle(kw, twodb, maxalign):
+    d = SynthData(60000, 120, 3000, **kw)
+    tspace = kw.get("tspace", 100)
+    op, pp = pyoracle.select_lowest(d.ovl, d.piles), dio.select_lowest(d.ovl, d.piles)
+    assert (op[0] == pp[0]).all() and (op[1] == pp[1]).all()
+    ovl, piles = pp
+    n = 24
+    O = pyoracle.Oracle(default_params(k=8, tspace=tspace)); O.load_db(d.bps, d.boff, d.rlen)
+    co, uo, no, po = O.estimate_profile(piles[:n], ovl, d.trace, maxalign=maxalign, two_databases=twodb)
+    cx, ux, nx, px = dio.estimate_profile(d.bps, d.boff, d.rlen, tspace, piles[:n], ovl, d.trace, maxalign=maxalign, two_databases=twodb, nthreads=3)
+    assert list(co) == list(cx) and (uo, no) == (ux, nx)
+    assert po == px
+    assert ux > 100 and cx[0] > 10000
+
+
+def test_estimate_is_close_to_the_truth():
+    d = SynthData(100000, 200, 5000, seed=3)          # 15 % errors: ins 80 %, del 13.3 %, sub 6.7 %
+    ovl, piles = dio.select_lowest(d.ovl, d.piles)
+    c, us, un, (p_i, p_d, cor) = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:40], ovl, d.trace, nthreads=4)
+    t_i, t_d, t_cor = d.error_profile()
+    assert abs(p_i - t_i) < 0.03 and abs(p_d - t_d) < 0.02 and abs(cor - t_cor) < 0.04, ((p_i, p_d, cor), (t_i, t_d, t_cor))
