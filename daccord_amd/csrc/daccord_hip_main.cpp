@@ -16,7 +16,7 @@
  * -t and -T are accepted and ignored (no host worker threads, no temporary files).  The error profile comes from
  * --eprof<p_i,p_d,est_cor>, from -E<file> / <las>.eprof holding the three numbers as text (our own format: the binary
  * .eprof of the reference is a libmaus2 serialisation that is not in the reference tree), or is estimated from the
- * first 1024 piles like src/daccord.cpp:1653-1878 does (and written to <las>.eprof unless --eprofonly... see below).
+ * first 1024 piles like src/daccord.cpp:1653-1878 does and written to that file (--eprofonly: stop there; no GPU needed).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -194,13 +194,6 @@ int main(int argc, char ** argv)
 	int64_t const toparead = maxaread >= 0 ? maxaread+1 : maxaread;
 	if ( o.V ) std::fprintf(stderr,"[V] minaread=%lld toparead=%lld\n",static_cast<long long>(minaread),static_cast<long long>(toparead));
 
-	dacc_params p; std::memset(&p,0,sizeof(p));
-	p.w = o.w; p.a = o.a; p.klow = o.klow; p.khigh = o.khigh; p.minfilterfreq = o.minff; p.maxfilterfreq = o.maxff; p.minwindowcov = o.m;
-	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = 0; p.verbose = o.V;
-	dacc_ctx * ctx = 0;
-	{ int const rc = dacc_create(&ctx,&p); if ( rc ) die("dacc_create failed (" + std::to_string(rc) + "): no usable HIP device or bad parameters"); }
-	if ( dacc_load_db(ctx,pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctx));
-
 	// batch of piles [b0,b1): load, top-D select per pile, shift B ids in two database mode
 	std::vector<dacc_overlap> sel; std::vector<dacc_pile> spiles; std::vector<dacc_overlap> tmp;
 	void const * trace = 0; uint64_t ntrace = 0;
@@ -258,7 +251,15 @@ int main(int argc, char ** argv)
 		char buf[128]; std::snprintf(buf,sizeof(buf),"%.17g %.17g %.17g\n",prof[0],prof[1],prof[2]); out << buf;
 	}
 	if ( o.V ) std::fprintf(stderr,"[V] p_i=%.17g p_d=%.17g est_cor=%.17g\n",prof[0],prof[1],prof[2]);
-	if ( o.eprofonly ) { dacc_destroy(ctx); return EXIT_SUCCESS; }
+	if ( o.eprofonly ) return EXIT_SUCCESS;
+
+	dacc_params p; std::memset(&p,0,sizeof(p));
+	p.w = o.w; p.a = o.a; p.klow = o.klow; p.khigh = o.khigh; p.minfilterfreq = o.minff; p.maxfilterfreq = o.maxff; p.minwindowcov = o.m;
+	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = 0; p.verbose = o.V;
+	dacc_ctx * ctx = 0;
+	{ int const rc = dacc_create(&ctx,&p); if ( rc ) die("dacc_create failed (" + std::to_string(rc) + "): no usable HIP device or bad parameters"); }
+	if ( dacc_load_db(ctx,pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctx));
+
 	if ( dacc_set_error_profile(ctx,prof[0],prof[1],prof[2]) ) die(std::string("error profile: ") + dacc_last_error(ctx));
 
 	uint64_t well = 0;

@@ -1,34 +1,58 @@
-"""Option parsing of the daccord-compatible front end (flag and value joined, options before positionals:
-src/daccord.cpp:185-207, README.md:99)."""
+"""The C++ front end daccord_hip (daccord_amd/csrc/daccord_hip_main.cpp) without a GPU: option grammar (flag and value
+joined, options before positionals: src/daccord.cpp:185-207, README.md:99), read interval logic (:1156-1230) and the
+error profile estimation (--eprofonly needs no device)."""
+import re
+import numpy as np
 import pytest
-from daccord_amd import cli
+from daccord_amd import cli, io as dio
 
 
-def test_defaults_match_the_reference():
-    opt, pos = cli.parse_args(["a.las", "a.db"])
-    assert (opt["w"], opt["a"], opt["m"], opt["D"], opt["k"], opt["minfilterfreq"], opt["maxfilterfreq"], opt["l"]) == (40, 10, 3, 5000, "8", 0, 2, 0)
-    assert pos == ["a.las", "a.db"] and opt["f"] is False and opt["d"] is None and opt["e"] is None
+@pytest.fixture(scope="module")
+def files(tmp_path_factory):
+    from daccord_amd.synth import SynthData
+    d = SynthData(60000, 120, 3000, seed=1)
+    tmp = tmp_path_factory.mktemp("cli")
+    las, db = str(tmp / "reads.las"), str(tmp / "reads.db")
+    dio.write_db(db, d.bps, d.boff, d.rlen)
+    dio.write_las(las, 100, d.ovl, d.trace)
+    return d, las, db
 
 
-def test_joined_values_and_intervals():
-    opt, pos = cli.parse_args(["-w48", "-a12", "-k10,12", "-f", "-d30", "-e40", "-l500", "-D100", "-I5,20", "-J1,8", "-t16",
-                               "--minfilterfreq1", "--maxfilterfreq3", "x.las", "x.db", "y.db"])
-    assert (opt["w"], opt["a"], opt["k"], opt["f"], opt["d"], opt["e"], opt["l"], opt["D"]) == (48, 12, "10,12", True, 30, 40, 500, 100)
-    assert (opt["I"], opt["J"], opt["minfilterfreq"], opt["maxfilterfreq"]) == ("5,20", "1,8", 1, 3)
-    assert pos == ["x.las", "x.db", "y.db"]
+def _interval(stderr):
+    m = re.search(r"\[V\] minaread=(-?\d+) toparead=(-?\d+)", stderr)
+    return int(m.group(1)), int(m.group(2))
 
 
-def test_error_profile_sources(tmp_path):
-    opt, _ = cli.parse_args(["--eprof0.12,0.02,0.85", "a.las", "a.db"])
-    assert cli.load_eprof(opt, "a.las") == [0.12, 0.02, 0.85]
-    f = tmp_path / "x.las.eprof"; f.write_text("0.1 0.03 0.8\n")
-    opt, _ = cli.parse_args(["a.las", "a.db"])
-    assert cli.load_eprof(opt, str(tmp_path / "x.las")) == [0.1, 0.03, 0.8]
-    with pytest.raises(SystemExit):
-        cli.load_eprof(opt, str(tmp_path / "missing.las"))
+def test_usage_and_unknown_options_fail_loudly(files):
+    d, las, db = files
+    for bad in (["-Q3", las, db], ["--nosuchoption", las, db], [las], ["-I5", "--eprofonly", las, db], ["-J1,0", "--eprofonly", las, db]):
+        r = cli.run(bad)
+        assert r.returncode != 0 and (b"[E]" in r.stderr or b"usage" in r.stderr), bad
 
 
-def test_unknown_and_estimator_options_fail_loudly():
-    for bad in (["-Q3", "a.las", "a.db"], ["--eprofonly", "a.las", "a.db"], ["a.las"]):
-        with pytest.raises(SystemExit):
-            cli.parse_args(bad)
+def test_read_intervals_follow_the_reference(files):
+    d, las, db = files
+    lo, hi = int(d.ovl["aread"].min()), int(d.ovl["aread"].max())
+    ep = ["--eprof0.12,0.02,0.85", "--eprofonly"]
+    assert _interval(cli.run(ep + [las, db]).stderr.decode()) == (lo, hi + 1)
+    # -I: both ends inclusive (daccord.cpp:1225-1230)
+    assert _interval(cli.run(ep + ["-I3,9", las, db]).stderr.decode()) == (max(lo, 3), min(hi, 9) + 1)
+    # -J i,j: part i of j, partsize = ceil(span/j) (daccord.cpp:1156-1183); -J wins over -I (else if, :1185)
+    span = hi + 1 - lo; part = (span + 3) // 4
+    assert _interval(cli.run(ep + ["-J1,4", "-I0,1", las, db]).stderr.decode()) == (lo + part, min(lo + 2 * part, hi + 1))
+    assert _interval(cli.run(ep + ["-J7,4", las, db]).stderr.decode()) == (0, -1)
+
+
+def test_eprofonly_estimates_and_writes_the_profile(files, tmp_path):
+    d, las, db = files
+    ef = str(tmp_path / "x.eprof")
+    r = cli.run(["--eprofonly", "-E" + ef, "-w48", "-a12", "-k10,12", "-f", "-d30", "-t16", "--minfilterfreq1", las, db])
+    assert r.returncode == 0, r.stderr.decode()
+    got = [float(x) for x in open(ef).read().split()]
+    ovl, piles = dio.select_lowest(d.ovl, d.piles)
+    c, us, un, prof = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:1024], ovl, d.trace, maxalign=30, nthreads=4)
+    assert got == list(prof)
+    assert ("usable=%d unusable=%d" % (us, un)) in r.stderr.decode()
+    # an existing profile file is used as it is
+    r2 = cli.run(["--eprofonly", "-E" + ef, las, db])
+    assert ("p_i=%.17g" % prof[0]) in r2.stderr.decode() and "usable=" not in r2.stderr.decode()

@@ -124,8 +124,8 @@ def test_accuracy_vs_truth_larger():
 
 @pytest.mark.gpu
 def test_cli_from_las_and_db_files(small_data, tmp_path):
-    """daccord-compatible front end: .las + .db on disk -> FASTA identical to the oracle run on the in-memory piles."""
-    import io as _io
+    """The C++ front end daccord_hip: .las + .db on disk -> FASTA identical to the oracle run on the in-memory piles;
+    -I is inclusive at both ends (src/daccord.cpp:1225-1230)."""
     import pyoracle
     from daccord_amd import cli, io as dio
     d, ovl, piles = small_data
@@ -133,12 +133,48 @@ def test_cli_from_las_and_db_files(small_data, tmp_path):
     dio.write_db(db, d.bps, d.boff, d.rlen)
     dio.write_las(las, 100, d.ovl, d.trace)
     p_i, p_d, cor = d.error_profile()
-    buf = _io.StringIO()
-    assert cli.main(["-k8", "-I0,6", "--eprof%r,%r,%r" % (p_i, p_d, cor), las, db], out=buf) == 0
+    r = cli.run(["-k8", "-I0,6", "--eprof%r,%r,%r" % (p_i, p_d, cor), las, db])
+    assert r.returncode == 0, r.stderr.decode()
     O = pyoracle.Oracle(default_params(k=8)); O.set_error_profile(p_i, p_d, cor); O.load_db(d.bps, d.boff, d.rlen)
-    sel = piles[piles["aread"] < 6]
+    sel = piles[piles["aread"] <= 6]
     fo, bo = O.run(sel, ovl, d.trace, nthreads=4)
-    assert buf.getvalue() == pyoracle.fasta(fo, bo)
+    assert r.stdout.decode() == pyoracle.fasta(fo, bo)
+    # -J 1,3 = second third of the read range; --vard caps the depth per read (daccord.cpp:2120-2126)
+    lo, hi = int(d.ovl["aread"].min()), int(d.ovl["aread"].max()) + 1
+    part = (hi - lo + 2) // 3
+    r = cli.run(["-k8", "-J1,3", "-I0,3", "--vard4", "-f", "--eprof%r,%r,%r" % (p_i, p_d, cor), las, db])
+    assert r.returncode == 0, r.stderr.decode()
+    avg = int(d.rlen.astype(np.int64).sum() // len(d.rlen))
+    selp = d.piles[(d.piles["aread"] >= lo + part) & (d.piles["aread"] < min(hi, lo + 2 * part))]
+    oo, pp, o = [], selp.copy(), 0
+    for i, pl in enumerate(selp):
+        cap = max(8, 1, int(2.0 * 4 * float(d.rlen[pl["aread"]]) / float(avg) + 0.5))
+        so, sp = pyoracle.pile_select(d.ovl, selp[i:i + 1], maxinput=cap)
+        oo.append(so); pp[i]["first_ovl"] = o; pp[i]["novl"] = len(so); o += len(so)
+    O = pyoracle.Oracle(default_params(k=8, producefull=1)); O.set_error_profile(p_i, p_d, cor); O.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(pp, np.concatenate(oo), d.trace, nthreads=4)
+    assert r.stdout.decode() == pyoracle.fasta(fo, bo)
+
+
+def test_cli_two_databases_and_estimated_profile(small_data, tmp_path):
+    """Asymmetric mode (src/daccord.cpp:1337-1364): B reads from a second database (here a copy of the first, so the
+    output must equal the single database run); no --eprof: the profile is estimated (daccord.cpp:1653-1878) and
+    the run must equal an oracle run with the oracle's own estimate."""
+    import pyoracle
+    from daccord_amd import cli, io as dio
+    d, ovl, piles = small_data
+    las, db, db2 = str(tmp_path / "reads.las"), str(tmp_path / "reads.db"), str(tmp_path / "breads.db")
+    dio.write_db(db, d.bps, d.boff, d.rlen); dio.write_db(db2, d.bps, d.boff, d.rlen)
+    dio.write_las(las, 100, d.ovl, d.trace)
+    r = cli.run(["-k8", "-I0,5", las, db, db2])
+    assert r.returncode == 0, r.stderr.decode()
+    lo_ovl, lo_piles = pyoracle.select_lowest(d.ovl, d.piles)
+    O = pyoracle.Oracle(default_params(k=8)); O.load_db(d.bps, d.boff, d.rlen)
+    c, us, un, prof = O.estimate_profile(lo_piles[lo_piles["aread"] <= 5], lo_ovl, d.trace, two_databases=True)
+    assert [float(x) for x in open(las + ".eprof").read().split()] == list(prof)
+    O.set_error_profile(*prof)
+    fo, bo = O.run(piles[piles["aread"] <= 5], ovl, d.trace, nthreads=4)
+    assert r.stdout.decode() == pyoracle.fasta(fo, bo)
 
 
 def _random_configs(first, last, seed=20260921):
