@@ -198,6 +198,18 @@ def main():
             par.update({"piles_compared": n, "gpu_fasta_sha256": h, "oracle_fasta_sha256": G["fasta_sha256"], "identical": h == G["fasta_sha256"],
                         "oracle_source": "tests/golden/scale_cfg2.json (oracle run in the build container, tests/golden/make_golden_scale.py)"})
         res["parity"] = par
+        # ---- accuracy against the known truth of the synthetic reads (checkconsensus measurement, README.md:406-472):
+        # the only quality figure that does not depend on the oracle ----
+        try:
+            from daccord_amd import checkconsensus
+            nacc = min(len(allpiles), 200)
+            lim = int(allpiles[nacc - 1]["aread"])
+            _, acc = checkconsensus.check(allfr[allfr["aread"] <= lim], allba, d.genome, d.truth, d.rlen)
+            acc["sample"] = "first %d reads, every fragment aligned to the true sequence of its read interval" % nacc
+            acc["raw_read_erate"] = 0.15
+            res["accuracy"] = acc
+        except Exception as ex:      # the accuracy report must never cost the throughput line
+            res["accuracy"] = {"error": str(ex)}
         if world == 1 and not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle

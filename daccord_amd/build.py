@@ -46,10 +46,10 @@ def build_prof(force=False):
 def build_io(force=False):
     """Host-only library with the .db / .las readers and writers (include/daccord_io.h) and the pile selection;
     the same objects are also linked into libdaccord_hip.so."""
-    srcs = [os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_eprof.cpp"),
+    srcs = [os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_eprof.cpp"), os.path.join(CSRC, "host_check.cpp"),
             os.path.join(_HERE, "..", "include", "daccord_io.h"), os.path.join(_HERE, "..", "include", "daccord_hip.h")]
     if force or _newer(IOLIB, srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", IOLIB, srcs[0], srcs[1], srcs[2]])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", IOLIB] + srcs[:4])
     return IOLIB
 
 

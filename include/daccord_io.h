@@ -55,6 +55,14 @@ const char *dacc_las_error(dacc_las *las);
 int  dacc_las_write(const char *path, int32_t tspace, const dacc_overlap *ovl, uint64_t novl,
                     const void *trace, uint64_t ntrace, int trace_bytes);
 
+/* ---- truth-based accuracy check of a corrected fragment (the measurement of the package's checkconsensus tool,
+ * src/checkconsensus.cpp:730-1075): the fragment (ASCII) is aligned completely to a window of the true sequence with free
+ * ends, inside a band of +-band around the line from column c0 (fragment start) to c1 (fragment end).
+ * stats = {matches, mismatches, insertions (fragment only), deletions (truth only)}; [rfrom,rto) = the part of the window
+ * the fragment aligned to.  DACC_ENOTSUP: no alignment inside the band. ---- */
+int  dacc_check_fragment(const uint8_t *frag, uint64_t n, const uint8_t *ref, uint64_t m, uint64_t c0, uint64_t c1, uint64_t band,
+                         uint64_t *stats, uint64_t *rfrom, uint64_t *rto);
+
 #ifdef __cplusplus
 }
 #endif
