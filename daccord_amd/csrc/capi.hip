@@ -102,6 +102,26 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 }
 
 // safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
+// Before the LDS tiers: windows with a B string of more than 64 bases can only run in the generic engine, where one of
+// them costs as much as a few hundred thousand ordinary windows in the LDS path.  One thread per overlap scans its rows
+// of the window tables; such a window is flagged (the tiers skip it) and listed, and the generic engine starts on it on
+// the second stream right away instead of after the first tier.
+__global__ void k_prescan(DevOvl const * ovl, uint64_t novl, uint32_t const * ovl_pile, DevPile const * piles, uint32_t const * wt_b, uint32_t const * wt_e,
+	uint32_t * pregen, uint32_t * list)
+{
+	uint64_t const o = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+	if ( o >= novl ) return;
+	DevOvl const ov = ovl[o];
+	uint64_t const winbase = piles[ovl_pile[o]].winbase;
+	for ( uint32_t r = 0; r < ov.ny; ++r )
+		if ( wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r] > 64u )
+		{
+			uint64_t const w = winbase + ov.y0 + r;
+			uint32_t const bit = 1u << (w&31);
+			if ( !(atomicOr(pregen + (w>>5),bit) & bit) ) { uint32_t const q = atomicAdd(list,1u); list[1+q] = static_cast<uint32_t>(w); }
+		}
+}
+
 // after all engines: a window still marked as handed on is an internal error (errflag); a window the generic engine
 // could not hold even with grown scratch drops its pile (pilebad), the batch goes on
 __global__ void k_check_done(WindowOut const * wout, uint64_t n, uint32_t * errflag, DevPile const * piles, uint32_t npiles, uint8_t * pilebad)
@@ -315,7 +335,7 @@ struct dacc_ctx
 {
 	dacc_params par;
 	int device;
-	hipStream_t stream; hipStream_t stream2; hipEvent_t evFirstTier, evEarlyGeneric;   // stream2: generic engine for the windows no LDS tier can run, concurrent with tiers 2 and 3
+	hipStream_t stream; hipStream_t stream2; hipEvent_t evFirstTier, evEarlyGeneric, evPrescan;   // stream2: generic engine for the windows no LDS tier can run, concurrent with tiers 2 and 3
 	hipEvent_t ev[6]; hipEvent_t evtier[3];
 	std::string err;
 	bool haveprofile, havedb, havebatch;
@@ -331,7 +351,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly; DevBuf<uint8_t> d_arena2;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2;
 	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, trace_bytes, win_grid;
 	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
@@ -377,7 +397,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	}
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
 	{ int lo = 0, hi = 0; hipDeviceGetStreamPriorityRange(&lo,&hi); if ( hipStreamCreateWithPriority(&c->stream2,hipStreamNonBlocking,hi) != hipSuccess ) { delete c; return DACC_EHIP; } }
-	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming);
+	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming); hipEventCreateWithFlags(&c->evPrescan,hipEventDisableTiming);
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
 	for ( int i = 0; i < 3; ++i ) hipEventCreate(&c->evtier[i]);
 	*out = c;
@@ -388,14 +408,14 @@ void dacc_destroy(dacc_ctx * c)
 {
 	if ( !c ) return;
 	hipSetDevice(c->device);
-	hipStreamSynchronize(c->stream);
+	hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2);
 	c->d_dpnorm.release(); c->d_dpsq.release(); c->d_vs.release(); c->d_first.release(); c->d_size.release(); c->d_suplo.release(); c->d_suphi.release(); c->d_klim.release();
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_arena2.release();
+	c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
-	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric);
+	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
 	delete c;
 }
 
@@ -487,8 +507,22 @@ static int runDevice(dacc_ctx * c)
 		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
 		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
 		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = c->d_prof.p;
+		WB.pregen = 0;
 		if ( c->usefast )
 		{
+			// windows only the generic engine can run (a string longer than 64 bases): found by a scan of the window tables and
+			// started on the second stream now, concurrently with all LDS tiers
+			HIPCHK(hipMemsetAsync(c->d_pregen.p,0,((BP.nwindows+31)/32+1)*sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_pregenlist.p,0,sizeof(uint32_t),s));
+			if ( BP.ovl.size() )
+				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+255)/256),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
+			HIPCHK(hipEventRecord(c->evPrescan,s));
+			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
+			{
+				WindowBatch WE = WB; WE.arena = c->d_arena2.p; WE.prof = 0;
+				hipLaunchKernelGGL(k_window,dim3(c->early_grid),dim3(64),0,c->stream2,WE,c->d_err.p,static_cast<uint32_t const *>(c->d_pregenlist.p),static_cast<uint32_t *>(0));
+			}
+			WB.pregen = c->d_pregen.p;
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
 			bool early = false;
@@ -534,7 +568,9 @@ static int runDevice(dacc_ctx * c)
 			}
 			// what is left (rare shapes) goes through the generic engine
 			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0));
-			if ( early ) HIPCHK(hipStreamWaitEvent(s,c->evEarlyGeneric,0));
+			// everything the second stream ran (pre-scan list, first tier's generic-only windows) must be done before the vote
+			HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
+			HIPCHK(hipStreamWaitEvent(s,c->evEarlyGeneric,0));
 		}
 		else
 			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0)); }
@@ -581,7 +617,7 @@ static int runDevice(dacc_ctx * c)
 		c->retry_grid = g; c->win_grid = g; if ( c->early_grid > g ) c->early_grid = g;     // later launches of this batch use the grown arenas
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(g)*BP.caps.bytes));
 		if ( c->usefast ) HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
-		HIPCHK(c->d_gearly.ensure(BP.nwindows+2));
+		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2));
 		HIPCHK(hipMemsetAsync(c->d_err.p,0,4*sizeof(uint32_t),s));
 		HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
 		hipLaunchKernelGGL(k_collect_overflow,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_gearly.p);
@@ -703,7 +739,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		c->retry_grid = wg < 512 ? wg : 512;
 		c->win_grid = c->retry_grid;
 		c->early_grid = c->retry_grid < 64 ? c->retry_grid : 64;
-		HIPCHK(c->d_gearly.ensure(BP.nwindows+2));
+		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2));
 		HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
 		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));

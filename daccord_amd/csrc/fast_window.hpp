@@ -2417,6 +2417,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 #if defined(DACC_EMUL)
 	{ char const * pz = getenv("DACC_EMUL_POISON"); if ( pz ) __builtin_memset(static_cast<void *>(&E),atoi(pz),sizeof(E)); }   // debugging aid: no member may be read before it is set
 #endif
+	if ( B.pregen && ((B.pregen[widx>>5] >> (widx&31)) & 1) ) return FW_DONE;      // the generic engine has this window (a string longer than 64 bases)
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
 	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;

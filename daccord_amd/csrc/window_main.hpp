@@ -28,6 +28,7 @@ struct WindowBatch
 	WindowOut * wout;          // [nwindows]
 	uint8_t * arena;           // [gridDim][C.bytes]
 	uint64_t * prof;           // optional per-phase cycle counters (profiling builds)
+	uint32_t const * pregen;   // optional bit per window: already handed to the generic engine by the pre-scan (the LDS tiers skip it)
 };
 
 // base i of read r in the orientation the overlap uses (HandleContext.hpp:1910, 1952)

@@ -98,3 +98,47 @@ def test_gather_with_an_empty_rank_and_uneven_sizes():
         pr.join(timeout=60)
         assert pr.exitcode == 0
     assert ok
+
+
+def _worker_hip(rank, world, port, q):
+    """two ranks on the one GPU of the test box: each corrects its -J part with the HIP engine, gloo gather to rank 0"""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from daccord_amd import shard, engine
+    from daccord_amd._structs import default_params
+    from daccord_amd.synth import SynthData
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = SynthData(60000, 120, 3000, seed=5)
+    ovl, piles = engine.pile_select(d.ovl, d.piles)
+    piles = piles[:12]
+    p = default_params(k=8, device=0)
+    E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    mine = shard.shard_piles(piles, rank, world)
+    f, b = E(mine, ovl, d.trace)
+    F, B = shard.gather_fragments(f, b, device="cpu")
+    if rank == 0:
+        O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+        fo, bo = O.run(piles, ovl, d.trace, nthreads=4)
+        q.put((engine.fasta(F, B) == pyoracle.fasta(fo, bo), len(F), int(len(mine))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_hip_engine():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hip, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    same, n, nmine = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert same and n > 0 and 0 < nmine < 12
