@@ -103,17 +103,18 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 
 // safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
 // Before the LDS tiers: windows with a B string of more than 64 bases can only run in the generic engine, where one of
-// them costs as much as a few hundred thousand ordinary windows in the LDS path.  One thread per overlap scans its rows
+// them costs as much as a few hundred thousand ordinary windows in the LDS path.  One wavefront per overlap scans its rows
 // of the window tables; such a window is flagged (the tiers skip it) and listed, and the generic engine starts on it on
 // the second stream right away instead of after the first tier.
-__global__ void k_prescan(DevOvl const * ovl, uint64_t novl, uint32_t const * ovl_pile, DevPile const * piles, uint32_t const * wt_b, uint32_t const * wt_e,
+__global__ void __launch_bounds__(256) k_prescan(DevOvl const * ovl, uint64_t novl, uint32_t const * ovl_pile, DevPile const * piles, uint32_t const * wt_b, uint32_t const * wt_e,
 	uint32_t * pregen, uint32_t * list)
 {
-	uint64_t const o = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+	// one wavefront per overlap, lanes over its rows: coalesced reads of the two tables
+	uint64_t const o = static_cast<uint64_t>(blockIdx.x)*4 + (threadIdx.x>>6);
 	if ( o >= novl ) return;
 	DevOvl const ov = ovl[o];
 	uint64_t const winbase = piles[ovl_pile[o]].winbase;
-	for ( uint32_t r = 0; r < ov.ny; ++r )
+	for ( uint32_t r = threadIdx.x & 63; r < ov.ny; r += 64 )
 		if ( wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r] > 64u )
 		{
 			uint64_t const w = winbase + ov.y0 + r;
@@ -515,7 +516,7 @@ static int runDevice(dacc_ctx * c)
 			HIPCHK(hipMemsetAsync(c->d_pregen.p,0,((BP.nwindows+31)/32+1)*sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_pregenlist.p,0,sizeof(uint32_t),s));
 			if ( BP.ovl.size() )
-				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+255)/256),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
+				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
 			HIPCHK(hipEventRecord(c->evPrescan,s));
 			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
 			{
