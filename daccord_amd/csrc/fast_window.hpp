@@ -70,7 +70,7 @@ template<int TIER> struct FastTier;
 template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 640, fcap = 320, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
