@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <new>
+#include <stdexcept>
 #include "../../include/daccord_io.h"
 
 namespace {
@@ -140,42 +142,57 @@ int dacc_db_write(const char * path, const uint8_t * bps, uint64_t bps_bytes, co
 int dacc_las_open(const char * path, dacc_las ** out)
 {
 	if ( !path || !out ) return DACC_EINVAL;
-	dacc_las * las = new dacc_las; *out = las;
+	dacc_las * las = new (std::nothrow) dacc_las; *out = las;
+	if ( !las ) return DACC_ENOMEM;
 	las->novl = 0; las->tspace = 0; las->tbytes = 1; las->minaread = 0; las->maxaread = -1;
-	if ( !readFile(path,las->D,las->err) ) return DACC_EINVAL;
-	std::vector<uint8_t> const & D = las->D;
-	if ( D.size() < 12 ) { las->err = "overlap file too short"; return DACC_EINVAL; }
-	las->novl = get64(D.data()); las->tspace = get32(D.data()+8);
-	if ( las->novl < 0 || las->tspace <= 0 ) { las->err = "bad overlap file header"; return DACC_EINVAL; }
-	las->tbytes = las->tspace <= 125 ? 1 : 2;                                  // TRACE_XOVR of align.h
-	size_t p = 12;
-	las->ovl.reserve(las->novl);
-	int64_t prev = -1;
-	for ( int64_t i = 0; i < las->novl; ++i )
+	// one pass over the file with a bounded buffer: the records go straight into the overlap / trace arrays (the file
+	// itself is never held in memory); no exception leaves this function
+	try
 	{
-		if ( p + 40 > D.size() ) { las->err = "overlap file truncated"; return DACC_EINVAL; }
-		uint8_t const * r = D.data()+p;
-		dacc_overlap o; std::memset(&o,0,sizeof(o));
-		o.tlen = get32(r+0); o.diffs = get32(r+4); o.abpos = get32(r+8); o.bbpos = get32(r+12); o.aepos = get32(r+16); o.bepos = get32(r+20);
-		uint32_t fl; std::memcpy(&fl,r+24,4); o.flags = fl; o.aread = get32(r+28); o.bread = get32(r+32);
-		p += 40;
-		size_t const tb = static_cast<size_t>(o.tlen < 0 ? 0 : o.tlen)*las->tbytes;
-		if ( o.tlen < 0 || p + tb > D.size() ) { las->err = "overlap file truncated (trace)"; return DACC_EINVAL; }
-		o.trace_off = las->trace.size()/las->tbytes;
-		las->trace.insert(las->trace.end(),D.begin()+p,D.begin()+p+tb);
-		p += tb;
-		if ( o.aread < prev ) { las->err = "records are not sorted by A read"; return DACC_EINVAL; }
-		prev = o.aread;
-		las->ovl.push_back(o);
+		FILE * f = std::fopen(path,"rb");
+		if ( !f ) { las->err = std::string("cannot open ") + path; return DACC_EINVAL; }
+		struct Closer { FILE * f; ~Closer() { std::fclose(f); } } closer = { f };
+		std::vector<char> iobuf(1u<<22); std::setvbuf(f,iobuf.data(),_IOFBF,iobuf.size());
+		uint8_t hdr[12];
+		if ( std::fread(hdr,1,12,f) != 12 ) { las->err = "overlap file too short"; return DACC_EINVAL; }
+		las->novl = get64(hdr); las->tspace = get32(hdr+8);
+		std::fseek(f,0,SEEK_END); long const fsize = std::ftell(f); std::fseek(f,12,SEEK_SET);
+		if ( las->novl < 0 || las->tspace <= 0 || fsize < 12 || static_cast<uint64_t>(las->novl) > static_cast<uint64_t>(fsize-12)/40 )
+		{ las->err = "bad overlap file header"; return DACC_EINVAL; }
+		las->tbytes = las->tspace <= 125 ? 1 : 2;                                  // TRACE_XOVR of align.h
+		las->ovl.reserve(las->novl);
+		las->trace.reserve(static_cast<size_t>(fsize-12) - static_cast<size_t>(las->novl)*40);
+		int64_t prev = -1;
+		uint64_t left = static_cast<uint64_t>(fsize-12);
+		for ( int64_t i = 0; i < las->novl; ++i )
+		{
+			uint8_t r[40];
+			if ( left < 40 || std::fread(r,1,40,f) != 40 ) { las->err = "overlap file truncated"; return DACC_EINVAL; }
+			left -= 40;
+			dacc_overlap o; std::memset(&o,0,sizeof(o));
+			o.tlen = get32(r+0); o.diffs = get32(r+4); o.abpos = get32(r+8); o.bbpos = get32(r+12); o.aepos = get32(r+16); o.bepos = get32(r+20);
+			uint32_t fl; std::memcpy(&fl,r+24,4); o.flags = fl; o.aread = get32(r+28); o.bread = get32(r+32);
+			size_t const tb = static_cast<size_t>(o.tlen < 0 ? 0 : o.tlen)*las->tbytes;
+			if ( o.tlen < 0 || tb > left ) { las->err = "overlap file truncated (trace)"; return DACC_EINVAL; }
+			if ( o.aread < 0 || o.bread < 0 ) { las->err = "negative read id in an overlap record"; return DACC_EINVAL; }
+			o.trace_off = las->trace.size()/las->tbytes;
+			size_t const t0 = las->trace.size(); las->trace.resize(t0+tb);
+			if ( tb && std::fread(las->trace.data()+t0,1,tb,f) != tb ) { las->err = "overlap file truncated (trace)"; return DACC_EINVAL; }
+			left -= tb;
+			if ( o.aread < prev ) { las->err = "records are not sorted by A read"; return DACC_EINVAL; }
+			prev = o.aread;
+			las->ovl.push_back(o);
+		}
+		if ( las->novl )
+		{
+			las->minaread = las->ovl.front().aread; las->maxaread = las->ovl.back().aread;
+			las->afirst.assign(las->maxaread+2,las->ovl.size());
+			for ( size_t i = las->ovl.size(); i-- > 0; ) las->afirst[las->ovl[i].aread] = i;
+			for ( int64_t a = las->maxaread; a >= 0; --a ) if ( las->afirst[a] > las->afirst[a+1] ) las->afirst[a] = las->afirst[a+1];
+		}
 	}
-	if ( las->novl )
-	{
-		las->minaread = las->ovl.front().aread; las->maxaread = las->ovl.back().aread;
-		las->afirst.assign(las->maxaread+2,las->ovl.size());
-		for ( size_t i = las->ovl.size(); i-- > 0; ) las->afirst[las->ovl[i].aread] = i;
-		for ( int64_t a = las->maxaread; a >= 0; --a ) if ( las->afirst[a] > las->afirst[a+1] ) las->afirst[a] = las->afirst[a+1];
-	}
-	std::vector<uint8_t>().swap(las->D);
+	catch ( std::bad_alloc const & ) { las->err = "out of memory"; return DACC_ENOMEM; }
+	catch ( std::exception const & ex ) { las->err = ex.what(); return DACC_EINVAL; }
 	return DACC_OK;
 }
 void dacc_las_close(dacc_las * las) { delete las; }
@@ -191,6 +208,7 @@ int dacc_las_piles(dacc_las * las, int64_t afirst, int64_t alast, const dacc_pil
 	const dacc_overlap ** ovl, uint64_t * novl, const void ** trace, uint64_t * ntrace)
 {
 	if ( !las || !piles || !npiles || !ovl || !novl || !trace || !ntrace ) return DACC_EINVAL;
+	try {
 	las->opiles.clear(); las->oovl.clear(); las->otrace.clear();
 	if ( afirst < 0 ) afirst = 0;
 	if ( alast > las->maxaread+1 ) alast = las->maxaread+1;
@@ -212,6 +230,7 @@ int dacc_las_piles(dacc_las * las, int64_t afirst, int64_t alast, const dacc_pil
 	}
 	*piles = las->opiles.data(); *npiles = las->opiles.size(); *ovl = las->oovl.data(); *novl = las->oovl.size();
 	*trace = las->otrace.data(); *ntrace = las->otrace.size()/las->tbytes;
+	} catch ( std::bad_alloc const & ) { las->err = "out of memory"; return DACC_ENOMEM; }
 	return DACC_OK;
 }
 
