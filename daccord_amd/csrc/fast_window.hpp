@@ -422,11 +422,8 @@ struct FastEngine
 		uint32_t const lp2 = next_pow2(nlast < 2 ? 2 : nlast);
 		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk()[i] = ~0ull;
 		wv_sync();
-		PROFX(18)
 		wv_sort_keys<FastLds<CT>::keycap>(L.lastk(),nlast);
-		PROFX(19)
 		wv_sort_keys<CT::precap>(L.pre(),npre);
-		PROFX(20)
 	}
 
 	DEV void buildNodes(uint32_t const f)
@@ -655,37 +652,47 @@ struct FastEngine
 	}
 
 	// ================= stretches, once per activation state =================
+	// Active predecessor counts and the walking table of the stretches, both from the successor side: node u adds one to
+	// each of its active successors (LDS atomics on a scratch word array) instead of every node searching its four
+	// possible predecessors; stepT[z] = the node a walk continues with from z (exactly one active successor and one active
+	// predecessor), 0xFFFF where a stretch ends.  Both tables borrow the weight arrays, which are written much later.
+	DEV LDSQ uint16_t * stepTable() const { return reinterpret_cast<LDSQ uint16_t *>(L.base + ((FastLds<CT>::e_wR1_hi - 2u*CT::ncap) & ~7u)); }
 	DEV void computePredCounts()
 	{
-		uint32_t const shift = 2*(k-1);
+		static_assert(6u*CT::ncap + 16u <= FastLds<CT>::e_wR1_hi - FastLds<CT>::o_wF_lo,"scratch tables of the stretch walk must fit the weight arrays");
+		LDSQ uint32_t * const cnt32 = reinterpret_cast<LDSQ uint32_t *>(L.wF_lo());
+		LDSQ uint16_t * const stepT = stepTable();
+		for ( uint32_t z = lane; z < nn; z += WSZ ) cnt32[z] = 0;
+		wv_sync();
+		for ( uint32_t u = lane; u < nn; u += WSZ )
+		{
+			uint32_t const na = nsuccact(u);
+			uint32_t first = 0xFFFF;
+			for ( uint32_t i = 0; i < na; ++i ) { int32_t const v = succNode(u,i); wv_atomic_add(cnt32+v,1u); if ( i == 0 ) first = v; }
+			stepT[u] = (na == 1) ? first : 0xFFFF;
+		}
+		wv_sync();
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
-			uint32_t const v = L.nv()[z];
-			uint32_t const masked = v>>2, sym = v&3;
-			uint32_t cnt = 0;
-			for ( uint32_t s = 0; s < 4; ++s )
-			{
-				int32_t const u = findNode(masked | (s<<shift));
-				if ( u >= 0 )
-				{
-					uint32_t const info = L.sinfo()[u]; uint32_t const na = (info>>11)&7;
-					for ( uint32_t i = 0; i < na; ++i ) if ( ((info>>(2*i))&3) == sym ) { ++cnt; break; }
-				}
-			}
-			L.npred()[z] = cnt;
+			uint32_t const c = cnt32[z];
+			L.npred()[z] = c;
+			if ( c != 1 ) stepT[z] = 0xFFFF;
 		}
 		wv_sync();
 	}
 	// out (if given) receives the first `cap` nodes
 	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, LDSQ uint16_t * out, uint32_t & lastnode, uint32_t const cap = 0xFFFFFFFFu)
 	{
+		LDSQ uint16_t const * const stepT = stepTable();
 		int32_t cur = succNode(z,i);
 		uint32_t len = 2;
 		if ( out ) { out[0] = z; out[1] = cur; }
 		bool loop = (cur == static_cast<int32_t>(z));
-		while ( !loop && nsuccact(cur) == 1 && L.npred()[cur] == 1 )
+		while ( !loop )
 		{
-			cur = succNode(cur,0);
+			uint32_t const nx = stepT[cur];
+			if ( nx == 0xFFFF ) break;
+			cur = nx;
 			if ( out && len < cap ) out[len] = cur;
 			++len;
 			if ( cur == static_cast<int32_t>(z) ) loop = true;
@@ -723,7 +730,7 @@ struct FastEngine
 		// arrays and are compacted into `links` below; a stretch without a slot or longer than it is walked a second time
 		enum { WSLOT = 64 };
 		LDSQ uint16_t * const wtmp = reinterpret_cast<LDSQ uint16_t *>(L.wF_lo());
-		uint32_t const nslot = (FastLds<CT>::e_wR1_hi - FastLds<CT>::o_wF_lo) / (2*WSLOT);
+		uint32_t const nslot = (((FastLds<CT>::e_wR1_hi - 2u*CT::ncap) & ~7u) - FastLds<CT>::o_wF_lo) / (2*WSLOT);     // the walking table sits behind the slots
 		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
 			uint32_t ln;
@@ -806,15 +813,28 @@ struct FastEngine
 		// parents: lanes over base stretches.  An interior node has a unique active predecessor and successor, so it
 		// lies strictly inside at most one stretch; anything else goes to the generic engine
 		uint32_t multi = 0;
-		for ( uint32_t s = lane; s < n0; s += WSZ )
 		{
-			uint32_t const len = L.sslen()[s]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
-			for ( uint32_t i = 1; i+1 < len; ++i )
+			// node -> (stretch, index) for the interior nodes, in the not yet used weight arrays: one pass over the stretches
+			// (lane per stretch, indices downwards so that the first occurrence of a node stays), then one lookup per candidate
+			LDSQ uint16_t * const sid = reinterpret_cast<LDSQ uint16_t *>(L.wR_lo());
+			LDSQ uint8_t * const spos = reinterpret_cast<LDSQ uint8_t *>(L.wR1_lo());
+			static_assert(CT::wcap*4 >= CT::ncap*2,"interior node table must fit the weight array it borrows");
+			for ( uint32_t z = lane; z < nn; z += WSZ ) sid[z] = 0xFFFF;
+			wv_sync();
+			for ( uint32_t s = lane; s < n0; s += WSZ )
 			{
-				uint32_t const z = Lk[i];
-				for ( uint32_t c = 0; c < nF; ++c ) if ( L.fnode()[c] == z ) { if ( L.parF()[c] == FNOPAR ) { L.parF()[c] = s; L.posF()[c] = i; } else if ( L.parF()[c] != s ) multi = 1; }
-				for ( uint32_t c = 0; c < nL; ++c ) if ( L.lnode()[c] == z ) { if ( L.parL()[c] == FNOPAR ) { L.parL()[c] = s; L.posL()[c] = i; } else if ( L.parL()[c] != s ) multi = 1; }
+				uint32_t const len = L.sslen()[s]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+				for ( uint32_t i = len > 2 ? len-2 : 0; i >= 1; --i ) { uint32_t const z = Lk[i]; sid[z] = s; spos[z] = i; }
 			}
+			wv_sync();
+			// safety net: a node strictly inside two stretches cannot be modelled by one parent per candidate
+			for ( uint32_t s = lane; s < n0; s += WSZ )
+			{
+				uint32_t const len = L.sslen()[s]; LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
+				for ( uint32_t i = 1; i+1 < len; ++i ) if ( sid[Lk[i]] != s ) multi = 1;
+			}
+			for ( uint32_t c = lane; c < nF; c += WSZ ) { uint32_t const z = L.fnode()[c]; if ( z != 0xFFFF && sid[z] != 0xFFFF ) { L.parF()[c] = sid[z]; L.posF()[c] = spos[z]; } }
+			for ( uint32_t c = lane; c < nL; c += WSZ ) { uint32_t const z = L.lnode()[c]; if ( z != 0xFFFF && sid[z] != 0xFFFF ) { L.parL()[c] = sid[z]; L.posL()[c] = spos[z]; } }
 		}
 		if ( wv_any(multi) ) { over(32); return; }
 		wv_sync();
@@ -824,15 +844,29 @@ struct FastEngine
 			for ( uint32_t c = 0; c < nL; ++c ) cnt += (L.parL()[c] != FNOPAR);
 			if ( n0 + 2*cnt + 1 > CT::scap || n0 + 2*cnt + 1 > 250 ) { over(32); return; }
 		}
-		if ( lane == 0 )
 		{
+			// pieces of the candidates that split a stretch, one lane per candidate (first k-mers, then last k-mers): two
+			// pool ids each, numbered in candidate order
 			uint32_t id = n0;
-			for ( uint32_t c = 0; c < nF; ++c ) if ( L.parF()[c] != FNOPAR ) { L.pieF()[c] = id; makePiece(id,L.parF()[c],0,L.posF()[c]); makePiece(id+1,L.parF()[c],L.posF()[c],L.sslen()[L.parF()[c]]-1); id += 2; }
-			for ( uint32_t c = 0; c < nL; ++c ) if ( L.parL()[c] != FNOPAR ) { L.pieL()[c] = id; makePiece(id,L.parL()[c],0,L.posL()[c]); makePiece(id+1,L.parL()[c],L.posL()[c],L.sslen()[L.parL()[c]]-1); id += 2; }
+			for ( uint32_t c0 = 0; c0 < nF + nL; c0 += WSZ )
+			{
+				uint32_t const c = c0 + lane;
+				bool const isF = c < nF, act = c < nF + nL;
+				uint32_t const ci = isF ? c : c - nF;
+				uint32_t const par = act ? (isF ? L.parF()[ci] : L.parL()[ci]) : static_cast<uint32_t>(FNOPAR);
+				bool const has = act && par != FNOPAR;
+				uint32_t tot; uint32_t const pre = wv_scan_flag(has,tot);
+				if ( has )
+				{
+					uint32_t const pid = id + 2*pre, pos = isF ? L.posF()[ci] : L.posL()[ci];
+					if ( isF ) L.pieF()[ci] = pid; else L.pieL()[ci] = pid;
+					makePiece(pid,par,0,pos); makePiece(pid+1,par,pos,L.sslen()[par]-1);
+				}
+				id += 2*tot;
+			}
 			npool = id;
 		}
 		wv_sync();
-		npool = wv_bcast(npool,0);
 		for ( uint32_t id = n0 + lane; id < npool; id += WSZ ) L.ppos()[id] = basePos(id);
 		wv_sync();
 
@@ -944,6 +978,7 @@ struct FastEngine
 	// position.  The loads of a node (link -> node -> first instance -> table) run ahead of the table reads.
 	DEV void computeStretchFeasLanes(uint32_t const sfrom, uint32_t const sto)
 	{
+		PROFX_T0
 		uint32_t const ns = sto-sfrom, nu = 2*ns;          // units: forward stretches, then reverse stretches
 		uint32_t const stride = nrows+1;
 		uint32_t tbase = 0;
@@ -973,6 +1008,7 @@ struct FastEngine
 			if ( u < nu ) L.toff()[u] = tbase + pre;
 			tbase += tot;
 		}
+		PROFX(18)
 		if ( tbase > 0xFFFF ) { over(128); return; }
 		if ( lane == 0 ) L.toff()[nu] = tbase;
 		wv_sync();
@@ -1849,25 +1885,37 @@ struct FastEngine
 		return true;
 	}
 
+	// text: 8 byte aligned, readable up to the next multiple of 8 behind n (a row of consL).  The pattern masks and the
+	// text (eight symbols per load) are fetched up front, so the column loop runs from registers.
 	DEV uint32_t myersDistance(uint32_t const j, LDSQ uint8_t const * text, uint32_t const n) const
 	{
 		uint32_t const m = L.slen()[j];
 		if ( m == 0 ) return n;
 		LDSQ uint64_t const * PEQ = L.peq() + 4*j;
+		uint64_t const e0 = PEQ[0], e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
+		LDSQ uint64_t const * T8 = reinterpret_cast<LDSQ uint64_t const *>(text);
 		uint32_t score = m;
 		uint64_t Pv = ~0ull, Mv = 0;
 		uint64_t const top = 1ull<<(m-1);
-		for ( uint32_t c = 0; c < n; ++c )
+		uint64_t w = n ? T8[0] : 0ull;
+		for ( uint32_t c0 = 0; c0 < n; c0 += 8 )
 		{
-			uint64_t const Eq = PEQ[text[c]];
-			uint64_t const Xv = Eq | Mv;
-			uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-			uint64_t Ph = Mv | ~(Xh | Pv);
-			uint64_t Mh = Pv & Xh;
-			if ( Ph & top ) ++score; else if ( Mh & top ) --score;
-			Ph = (Ph<<1) | 1ull; Mh <<= 1;
-			Pv = Mh | ~(Xv | Ph);
-			Mv = Ph & Xv;
+			uint64_t const wn = (c0+8 < n) ? T8[(c0>>3)+1] : 0ull;      // next word, in flight during these eight columns
+			uint32_t const cnt = (n-c0 < 8) ? (n-c0) : 8u;
+			for ( uint32_t u = 0; u < cnt; ++u )
+			{
+				uint32_t const ch = static_cast<uint32_t>(w >> (8*u)) & 3u;
+				uint64_t const Eq = (ch & 2) ? ((ch & 1) ? e3 : e2) : ((ch & 1) ? e1 : e0);
+				uint64_t const Xv = Eq | Mv;
+				uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+				uint64_t Ph = Mv | ~(Xh | Pv);
+				uint64_t Mh = Pv & Xh;
+				if ( Ph & top ) ++score; else if ( Mh & top ) --score;
+				Ph = (Ph<<1) | 1ull; Mh <<= 1;
+				Pv = Mh | ~(Xv | Ph);
+				Mv = Ph & Xv;
+			}
+			w = wn;
 		}
 		return score;
 	}
@@ -2235,14 +2283,16 @@ struct FastEngine
 			L.canderr()[t] = myersDistance(j,L.consL() + L.acc()[c].o,L.acc()[c].l);
 		}
 		wv_sync();
+		// error sum of candidate c on lane c, then the stable insertion sort by error on lane 0
+		for ( uint32_t c = lane; c < nc; c += WSZ )
+		{
+			uint32_t s = 0;
+			for ( uint32_t j = 0; j < mao; ++j ) s += L.canderr()[c*mao+j];
+			L.accerr()[c] = s;
+		}
+		wv_sync();
 		if ( lane == 0 )
 		{
-			for ( uint32_t c = 0; c < nc; ++c )
-			{
-				uint32_t s = 0;
-				for ( uint32_t j = 0; j < mao; ++j ) s += L.canderr()[c*mao+j];
-				L.accerr()[c] = s;
-			}
 			for ( uint32_t i = 1; i < nc; ++i )
 			{
 				FCC const v = ldget(L.acc()+i); uint32_t const e = L.accerr()[i];
