@@ -537,6 +537,20 @@ struct FastEngine
 		}
 		wv_sync();
 	}
+	// after buildNodes: no first k-mer candidate, or none of the last k-mer candidates (count >= 3/4 of the best, :4774-4784)
+	// is a node of the filtered graph
+	DEV bool passIsDead() const
+	{
+		if ( nmfirst == 0 || nmlast == 0 ) return true;
+		uint32_t const lastthres = ((static_cast<uint32_t>((~L.mlast()[0])>>32))*3)/4;
+		uint32_t any = 0;
+		for ( uint32_t i = lane; i < nmlast; i += WSZ )
+		{
+			uint64_t const e = ~L.mlast()[i];
+			if ( static_cast<uint32_t>(e>>32) >= lastthres && findNode(static_cast<uint32_t>(e)) >= 0 ) any = 1;
+		}
+		return !wv_any(any);
+	}
 	DEV bool addNextFromHeap()
 	{
 		uint32_t best = 0;
@@ -2593,17 +2607,24 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh; ++k )
 		{
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
+			bool instvalid = false;
 			for ( int32_t ff = startff; ff >= B.P.minff; --ff )
 			{
 				curff = ff;
 				PROF_T0
-				E.buildInstances();
+				// the sorted instances of this k are still in place when the pass before ended without a traversal
+				if ( !instvalid ) E.buildInstances();
 				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only
 				PROF(E,2)
 				E.buildNodes(ff > 1 ? ff : 1);
 				E.flags = wv_or(E.flags);
 				if ( E.flags ) { FFAIL(7) }
 				PROF(E,3)
+				// A pass cannot produce a candidate if no node holds position 0 of a string (no first k-mer) or no last k-mer
+				// candidate is a node (every reverse enumeration is empty): its three traversals (:2270-2322) are skipped.  The
+				// traversal structures then never overwrite the instance array, which the next pass takes over.
+				instvalid = false;
+				if ( ff != 0 && E.passIsDead() ) { instvalid = true; continue; }
 				E.buildSuccessors(mao);
 				PROF(E,4)
 				if ( ff == 0 )
