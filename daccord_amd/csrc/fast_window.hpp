@@ -410,10 +410,10 @@ struct FastEngine
 			{
 				uint32_t const i = t - oj;
 				LDSQ uint8_t const * sp = L.str() + j*64 + i;
-				uint64_t v = 0;
+				uint32_t v = 0;
 				#pragma unroll
-				for ( uint32_t q = 0; q < 16; ++q ) { uint64_t const c = sp[q]; v = q < k ? ((v<<2) | c) : v; }
-				uint64_t const word = (v<<32) | (static_cast<uint64_t>(i)<<16) | j;
+				for ( uint32_t q = 0; q < 16; ++q ) { uint32_t const c = sp[q]; v = q < k ? ((v<<2) | c) : v; }
+				uint64_t const word = (static_cast<uint64_t>(v)<<32) | (static_cast<uint64_t>(i)<<16) | j;
 				L.pre()[t] = word;
 				if ( i + k == L.slen()[j] ) L.lastk()[lo-1] = word;
 			}
@@ -890,10 +890,13 @@ struct FastEngine
 	// clamped instead of branched on
 	DEV void loadTab()
 	{
-		for ( uint32_t i = lane; i < (nrows+1)*nsup; i += WSZ )
+		uint32_t const stride = nrows+1;
+		uint32_t pos = static_cast<uint32_t>(lane) / stride, row = static_cast<uint32_t>(lane) - pos*stride;     // the one division of the copy
+		uint32_t const dpos = WSZ / stride, drow = WSZ - dpos*stride;
+		for ( uint32_t i = lane; i < stride*nsup; i += WSZ )
 		{
-			uint32_t const pos = i / (nrows+1), row = i - pos*(nrows+1);
 			L.tab()[i] = row < nrows ? static_cast<uint32_t>(vst[pos*nrows+row]) : 0u;
+			pos += dpos; row += drow; if ( row >= stride ) { row -= stride; ++pos; }
 		}
 		wv_sync();
 	}
@@ -1597,7 +1600,16 @@ struct FastEngine
 				// members of the bucket among entries i0..i0+63 (loads only, so that they overlap), then the pushes in order
 				uint64_t mem = 0;
 				uint32_t const ie = (F.np-i0 < 64) ? (F.np-i0) : 64u;
-				for ( uint32_t i = 0; i < ie; ++i ) mem |= static_cast<uint64_t>(L.f_baselen()[clSlot<FCH>(F.C,i0+i)] == zz) << i;
+				// four consecutive entries lie in one chunk (FCH is a multiple of four): one chunk id and one 32 bit load of
+				// their base lengths
+				static_assert(FCH % 4 == 0,"entries per chunk");
+				for ( uint32_t i = 0; i < ie; i += 4 )
+				{
+					uint32_t const slot = clSlot<FCH>(F.C,i0+i);
+					uint32_t const b4 = *reinterpret_cast<LDSQ uint32_t const *>(L.f_baselen() + slot);
+					#pragma unroll
+					for ( uint32_t u = 0; u < 4; ++u ) if ( i+u < ie ) mem |= static_cast<uint64_t>(((b4 >> (8*u)) & 0xFF) == zz) << (i+u);
+				}
 				while ( mem )
 				{
 					uint32_t const i = __builtin_ctzll(mem); mem &= mem-1;
