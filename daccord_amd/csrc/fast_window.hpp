@@ -48,7 +48,6 @@
 namespace dacc {
 
 enum { WS_RETRY = 4 };
-enum { FNC = 40 };          // max first / last k-mer candidates on the fast path
 enum { FNOPAR = 0xFF };
 enum { FSUPCAP = 128 };
 enum { FSEQCAP = 48 };      // max stretches of one candidate path     // max width (read offsets) of the model table copy in LDS
@@ -67,10 +66,11 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
-// tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, idmax = 4000, rpstcap = 768, maxs = 96, precap = 2048, ncap = 1792, scap = 250, lcap = 2048, wcap = 2304, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, maxs = 64, precap = 1024, ncap = 896, scap = 232, lcap = 1024, wcap = 1056, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+// tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
+// too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -148,16 +148,16 @@ struct FastLds
 	FLD(lhead,uint8_t,CT::ncap,e_wR1_hi)
 	FLD(lord,uint32_t,CT::scap,e_lhead)
 	FLD(ppos,uint8_t,CT::scap,e_lord)      // pieces: number of base stretches sorting before them
-	FLD(fkmer,uint32_t,FNC,e_ppos)
-	FLD(lkmer,uint32_t,FNC,e_fkmer)
-	FLD(fnode,uint16_t,FNC,e_lkmer)
-	FLD(lnode,uint16_t,FNC,e_fnode)
-	FLD(parF,uint8_t,FNC,e_lnode)
-	FLD(posF,uint8_t,FNC,e_parF)
-	FLD(parL,uint8_t,FNC,e_posF)
-	FLD(posL,uint8_t,FNC,e_parL)
-	FLD(pieF,uint8_t,FNC,e_posL)      // first piece id of candidate i (second = +1), FNOPAR if none
-	FLD(pieL,uint8_t,FNC,e_pieF)
+	FLD(fkmer,uint32_t,CT::fnc,e_ppos)
+	FLD(lkmer,uint32_t,CT::fnc,e_fkmer)
+	FLD(fnode,uint16_t,CT::fnc,e_lkmer)
+	FLD(lnode,uint16_t,CT::fnc,e_fnode)
+	FLD(parF,uint8_t,CT::fnc,e_lnode)
+	FLD(posF,uint8_t,CT::fnc,e_parF)
+	FLD(parL,uint8_t,CT::fnc,e_posF)
+	FLD(posL,uint8_t,CT::fnc,e_parL)
+	FLD(pieF,uint8_t,CT::fnc,e_posL)      // first piece id of candidate i (second = +1), FNOPAR if none
+	FLD(pieL,uint8_t,CT::fnc,e_pieF)
 	FLD(bestL,uint8_t,MAXCONS,e_pieL)      // best consensus so far (survives the tries)
 	FLD(cdh,FCC,16,e_bestL)
 	FLD(cseq,uint8_t,18*FSEQCAP,e_cdh)      // stretch sequences of the kept candidates (16 slots) + current + previous
@@ -186,11 +186,11 @@ struct FastLds
 	FLD(rc_arw,typename CT::id_t,CT::rccap,e_rc_ord)
 	FLD(rc_sbl,uint8_t,CT::rccap,e_rc_arw)         // base length of the i-th entry in sorted order
 	FLD(rc_front,uint32_t,CT::rccap,e_rc_sbl)      // front k-mer of the i-th entry in sorted order
-	FLD(rbase,uint16_t,FNC+1,e_rc_front)
-	FLD(rn,uint16_t,FNC+1,e_rbase)
-	FLD(rmaxw,uint64_t,FNC+1,e_rn)
-	FLD(rtmask,uint64_t,FNC+1,e_rmaxw)
-	FLD(rfmask,uint64_t,FNC+1,e_rtmask)    // one bit per front k-mer (value mod 64) of the accepted reverse paths
+	FLD(rbase,uint16_t,CT::fnc+1,e_rc_front)
+	FLD(rn,uint16_t,CT::fnc+1,e_rbase)
+	FLD(rmaxw,uint64_t,CT::fnc+1,e_rn)
+	FLD(rtmask,uint64_t,CT::fnc+1,e_rmaxw)
+	FLD(rfmask,uint64_t,CT::fnc+1,e_rtmask)    // one bit per front k-mer (value mod 64) of the accepted reverse paths
 	// forward pool: paths by pool id
 	FLD(f_w,uint64_t,CT::fcap,e_rfmask)
 	FLD(f_parent,typename CT::id_t,CT::fcap,e_f_w)
@@ -205,20 +205,20 @@ struct FastLds
 	FLD(fp_front,uint32_t,CT::fcap,e_fp_cl)
 	FLD(fp_adj,uint64_t,CT::fcap,e_fp_front)
 	// per first k-mer candidate: chunk list of its tree, popped paths, junction k-mer bits, scan target bits, heaviest path
-	FLD(fchb,uint8_t,8*CT::fnw*(FNC+1),e_fp_adj)   // chunk ids of the forward trees: 8*fnw per first k-mer candidate (+ one exact tree)
-	FLD(fnp,uint16_t,FNC+1,e_fchb)
-	FLD(ffm,uint64_t,FNC+1,e_fnp)
-	FLD(ftm,uint64_t,FNC+1,e_ffm)
-	FLD(fmx,uint64_t,FNC+1,e_ftm)
+	FLD(fchb,uint8_t,8*CT::fnw*(CT::fnc+1),e_fp_adj)   // chunk ids of the forward trees: 8*fnw per first k-mer candidate (+ one exact tree)
+	FLD(fnp,uint16_t,CT::fnc+1,e_fchb)
+	FLD(ffm,uint64_t,CT::fnc+1,e_fnp)
+	FLD(ftm,uint64_t,CT::fnc+1,e_ffm)
+	FLD(fmx,uint64_t,CT::fnc+1,e_ftm)
 	// recorded (path, entry) sequences of the pairs of a round
 	FLD(pout,typename CT::id_t,32*32,e_fmx)
 	FLD(poutn,uint8_t,32,e_pout)
 	FLD(ctr,uint32_t,4,e_poutn)
 	FLD(rchx,uint8_t,32,e_ctr)              // chunk ids of a reverse enumeration on lane 0 alone
 	static constexpr uint32_t upool = e_rchx;
-	// chunk ids of the reverse enumerations of all last k-mers (32 per lane, lanes < FNC): over the per first k-mer tables, which are
+	// chunk ids of the reverse enumerations of all last k-mers (32 per lane, lanes < min(fnc,64)): over the per first k-mer tables, which are
 	// written after those enumerations have been copied to their blocks
-	FLD(rchb,uint8_t,FNC*32,o_fchb)
+	FLD(rchb,uint8_t,(CT::fnc < 64 ? CT::fnc : 64u)*32,o_fchb)
 	static_assert(e_rchb <= o_pout,"reverse chunk lists must fit the per first k-mer tables");
 	// raw stretches (overlay of the caches)
 	FLD(tfirst,uint16_t,CT::scap,pbase)
@@ -819,10 +819,28 @@ struct FastEngine
 		uint32_t cf = 0, cl = 0;
 		while ( cf < nmfirst && static_cast<uint32_t>((~L.mfirst()[cf])>>32) >= firstthres ) ++cf;
 		while ( cl < nmlast && static_cast<uint32_t>((~L.mlast()[cl])>>32) >= lastthres ) ++cl;
-		nF = cf; nL = cl; npool = n0;
-		if ( nF > FNC || nL > FNC ) { over(8); return; }
+		nF = cf; npool = n0;
+		if ( nF > FNC ) { nL = cl; over(8); return; }
 		for ( uint32_t i = lane; i < nF; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mfirst()[i]); L.fkmer()[i] = km; int32_t const z = findNode(km); L.fnode()[i] = z < 0 ? 0xFFFF : z; L.parF()[i] = FNOPAR; L.pieF()[i] = FNOPAR; }
-		for ( uint32_t i = lane; i < nL; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mlast()[i]); L.lkmer()[i] = km; int32_t const z = findNode(km); L.lnode()[i] = z < 0 ? 0xFFFF : z; L.parL()[i] = FNOPAR; L.pieL()[i] = FNOPAR; }
+		// Last k-mer candidates that are not nodes of the (filtered) graph are left out: their reverse enumeration is empty
+		// (prepareTraverse starts from the node of `last`), so none of their pairs can offer a candidate, and the pairs of
+		// the others keep their relative order.  In deep piles most strings end in a k-mer of their own, the list of
+		// candidates with a count of at least 3/4 of a small best count is then as long as the pile is deep.
+		{
+			uint32_t nl = 0;
+			for ( uint32_t c = 0; c < cl; c += WSZ )
+			{
+				uint32_t const i = c + lane;
+				uint32_t const km = i < cl ? static_cast<uint32_t>(~L.mlast()[i]) : 0u;
+				int32_t const z = i < cl ? findNode(km) : -1;
+				uint32_t tot; uint32_t const pre = wv_scan_flag(z >= 0,tot);
+				uint32_t const o = nl + pre;
+				if ( z >= 0 && o < FNC ) { L.lkmer()[o] = km; L.lnode()[o] = z; L.parL()[o] = FNOPAR; L.pieL()[o] = FNOPAR; }
+				nl += tot;
+			}
+			nL = nl;
+		}
+		if ( nL > FNC ) { over(8); return; }
 		wv_sync();
 		// parents: lanes over base stretches.  An interior node has a unique active predecessor and successor, so it
 		// lies strictly inside at most one stretch; anything else goes to the generic engine
@@ -1323,7 +1341,7 @@ struct FastEngine
 	// the same routines run on lane 0 alone for the rare pair that needs its exact stretch set.  Paths live in shared
 	// pools (rc_* / f_*, indexed by a pool-wide id); a lane takes pool entries in chunks of RCH / FCH through an LDS
 	// counter and keeps its chunk list in registers (entry i of an enumeration -> clSlot).
-	enum { RCH = CT::rch, RNW = 4, FCH = CT::fch, FNW = CT::fnw };         // entries per chunk, 64 bit words of chunk ids (8 per word)
+	enum { RCH = CT::rch, RNW = 4, FCH = CT::fch, FNW = CT::fnw, FNC = CT::fnc };         // entries per chunk, 64 bit words of chunk ids (8 per word)
 	// The chunk ids of an enumeration are a row of bytes in LDS (a register array indexed at run time would end up in
 	// scratch memory): NW*8 chunks per enumeration.
 	template<int NW> struct ChunkList { LDSQ uint8_t * ids; uint32_t n; };
@@ -1764,6 +1782,7 @@ struct FastEngine
 	DEV bool offerCandidate(uint64_t const weight, uint32_t const path, uint32_t const rp, uint32_t & pn)
 	{
 		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
+		FSTAT_ADD(18,1);
 		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
 		uint32_t conslen = 0;
 		uint32_t const n = buildSeq(path,rp,cur,conslen);
@@ -1779,6 +1798,7 @@ struct FastEngine
 		for ( uint32_t i = 0; i < n; ++i ) { uint8_t const c = cur[i]; prev[i] = c; dst[i] = c; }
 		pn = n;
 		FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
+		FSTAT_ADD(19,1);
 		spush<FCC,true>(L.cdh(),ncdh,cc);
 		return true;
 	}
@@ -1900,12 +1920,13 @@ struct FastEngine
 	DEV bool replayPair(ChunkList<FNW> const & FC, uint32_t const sbase, LDSQ id_t const * out, uint32_t const cnt, uint32_t & pn)
 	{
 		pn = ~0u;
+		FSTAT_ADD(16,1); FSTAT_ADD(17,cnt);
 		for ( uint32_t e = 0; e < cnt; ++e )
 		{
 			uint32_t const o = clSlot<FCH>(FC,out[2*e]);
 			uint32_t const rp = L.rc_ord()[sbase+out[2*e+1]];
 			uint64_t const w = L.fp_adj()[o] + L.rc_w()[rp];
-			if ( ncdh == 16 && w <= L.cdh()[0].w ) return false;
+			if ( ncdh == 16 && w <= L.cdh()[0].w ) { if ( e == 0 ) FSTAT_ADD(20,1); return false; }
 			if ( !offerCandidate(w,L.fp_id()[o],rp,pn) ) return false;
 		}
 		return true;
@@ -2021,13 +2042,14 @@ struct FastEngine
 		for ( ; q < n; ++q )
 		{
 			uint32_t const mode = L.poutn()[q];
-			if ( mode == PM_SKIP ) continue;
+			FSTAT_ADD(13,1);
+			if ( mode == PM_SKIP ) { FSTAT_ADD(14,1); continue; }
 			uint32_t const p = p0+q;
 			uint32_t const fi = fstart + p/nL, li = p%nL;
 			if ( mode < 0x40 || mode == PM_SERIAL )
 			{
 				// no candidate of this pair can beat the lightest kept candidate: score <= path weight + reverse weight
-				if ( ncdh == 16 && L.fmx()[fi] + L.rmaxw()[li] <= L.cdh()[0].w ) continue;
+				if ( ncdh == 16 && L.fmx()[fi] + L.rmaxw()[li] <= L.cdh()[0].w ) { FSTAT_ADD(15,1); continue; }
 				ChunkList<FNW> FC; forwardTreeLoad(FC,fi);
 				if ( mode < 0x40 )
 				{
