@@ -52,13 +52,15 @@ struct BatchPlan
 	ArenaCaps caps;
 	enum { NTIER = 3 };
 	FastCaps ftier[NTIER];    // LDS fast path capacity tiers: 3, 2, 1 wavefronts per CU
+	uint64_t ndeepwin;        // windows with more strings / k-mer instances than the first tier of shallow batches holds
+	bool deep;                // most windows are deep: the first tier is FastTier<4> (many strings, small graph) instead of FastTier<1>
 
 	int plan(dacc_params const & par, dacc_pile const * P, uint64_t const np, dacc_overlap const * O, uint64_t const no,
 		void const * trace, uint64_t const ntrace, int const trace_bytes, uint32_t const * rlen, uint64_t const nreads, std::string & err,
 		uint32_t const tab_nrows = 0, uint32_t const tab_nsup = 0)
 	{
 		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear(); pile_status.assign(np,DACC_OK); pile_errors.clear();
-		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0;
+		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0; ndeepwin = 0; deep = false;
 		if ( trace_bytes != 1 && trace_bytes != 2 ) { err = "trace values are 1 byte (tspace <= 125) or 2 bytes"; return DACC_EINVAL; }
 		if ( par.tspace <= 0 || par.tspace > 128 ) { err = "tspace must be in [1,128] (128-bit column vectors of the trace kernel)"; return DACC_ENOTSUP; }
 		uint8_t const * tr8 = static_cast<uint8_t const *>(trace); uint16_t const * tr16 = static_cast<uint16_t const *>(trace);
@@ -147,7 +149,15 @@ struct BatchPlan
 				ovl.push_back(v); ovl_pile.push_back(pi);
 			}
 			int32_t cur = 0;
-			for ( uint32_t y = 0; y < d.nwin; ++y ) { cur += diff[y]; if ( static_cast<uint32_t>(cur) > maxdepth ) maxdepth = cur; }
+			for ( uint32_t y = 0; y < d.nwin; ++y )
+			{
+				cur += diff[y]; if ( static_cast<uint32_t>(cur) > maxdepth ) maxdepth = cur;
+				// strings of the window (A + active overlaps, capped by -d) against what FastTier<1> holds
+				uint64_t const nb = par.maxalign > 0 ? static_cast<uint64_t>(par.maxalign-1) : 0;
+				uint64_t const mao = 1 + std::min<uint64_t>(static_cast<uint64_t>(cur),nb);
+				uint64_t const perstr = par.w >= par.klow ? static_cast<uint64_t>(par.w-par.klow+1) : 1;
+				if ( mao > FastTier<1>::maxs || mao*perstr > FastTier<1>::precap ) ++ndeepwin;
+			}
 			nwindows += d.nwin; npos += pilepos;
 			fragbase.push_back(nfragslots); nfragslots += pilepos/100 + 2;
 			piles.push_back(d);
@@ -167,7 +177,9 @@ struct BatchPlan
 		caps.conscap = 32768 + MAXCONS;
 		caps.pad = 0; caps.bytes = 0;
 		// LDS fast path capacity tiers (compile time, fast_window.hpp); windows beyond them are re-run by the generic engine
-		ftier[0] = fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
+		// A batch whose windows are mostly too deep for tier 1 (coverage of 40x and more) starts in the deep tier instead
+		deep = 2*ndeepwin > nwindows;
+		ftier[0] = deep ? fastCapsOf< FastTier<4> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
 		ftier[1] = fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup);
 		ftier[2] = fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;

@@ -540,7 +540,8 @@ static int runDevice(dacc_ctx * c)
 					// the ordinary hand-over chain to the generic kernel at the end
 					FB.gearly = early ? static_cast<uint32_t *>(0) : c->d_gearly.p;
 					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
-					if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					if ( t == 0 && BP.deep ) hipLaunchKernelGGL(k_window_fast<4>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					list = c->d_retry[t].p;
@@ -734,7 +735,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			c->tier_grid[t] = fg;
 			HIPCHK(c->d_retry[t].ensure(BP.nwindows+2));
 		}
-		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
+		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
 		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = wg < 512 ? wg : 512;

@@ -1203,6 +1203,9 @@ struct WindowEngine
 				uint32_t const firstk = static_cast<uint32_t>(fkey), lastk = static_cast<uint32_t>(lkey);
 				int32_t const firstnode = findNode(firstk);
 				int32_t const lastnode = findNode(lastk);
+				// a last k-mer that is not a node of the (filtered) graph has an empty reverse enumeration (it starts from the
+				// node of `last`, :3582-3600): no score interval, no candidate, nothing of this pair is kept
+				if ( lastnode < 0 ) continue;
 				// prepareTraverse (:3541-3787)
 				PROF_T0
 				computeStretches(firstnode,lastnode);

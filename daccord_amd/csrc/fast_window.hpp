@@ -72,6 +72,11 @@ template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4,
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
 template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
+// tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
+// small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
+// has about a hundred nodes, while the 55 strings of a window carry 1500 k-mer instances.
+template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
@@ -160,6 +165,7 @@ struct FastLds
 	FLD(pieL,uint8_t,CT::fnc,e_pieF)
 	FLD(bestL,uint8_t,MAXCONS,e_pieL)      // best consensus so far (survives the tries)
 	FLD(cdh,FCC,16,e_bestL)
+	static_assert(uA <= o_cdh,"the model table copy (from o_cdh on) is loaded for gap filling while the instance array is live");
 	FLD(cseq,uint8_t,18*FSEQCAP,e_cdh)      // stretch sequences of the kept candidates (16 slots) + current + previous
 	// dead until the kept candidates are decoded: shared with the lane scratch of the enumerations (lscr: per lane a
 	// heap of 32 path ids / of 12 path ids / of PSIQ score intervals; all of it for an enumeration on lane 0 alone)

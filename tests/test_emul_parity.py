@@ -121,3 +121,24 @@ def test_64_lane_wavefront_emulation(small_data, kw):
     fe, be = E.run(piles[3:5], ovl, d.trace)
     assert windows_equal(O.windows(), E.windows()) == []
     assert frags_equal(fo, bo, fe, be)
+
+
+@pytest.mark.parametrize("lanes", [1, 64])
+def test_deep_batch_starts_in_the_deep_tier(lanes):
+    """50x piles at the default window parameters: the plan finds most windows too deep for tier 1 (more than 40 strings
+    or 1024 k-mer instances) and starts the batch in the deep tier (FastTier<4>: 96 strings, 2048 instances, small
+    graph, three wavefronts per CU); what does not fit there goes on through tiers 2 and 3 as usual.  Same bits as the
+    oracle, and no window needs the generic engine only because the pile is deep."""
+    d = SynthData(30000, 300, 5000, seed=7)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    p = default_params(k=14)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p, lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[10:11], ovl, d.trace, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[10:11], ovl, d.trace)
+    wo = O.windows()
+    assert (wo["mao"] > 40).mean() > 0.5
+    t1, t2, t3, gen = E.counts()
+    assert t1 > 0.7 * len(wo) and gen <= 1, (t1, t2, t3, gen, len(wo))
+    assert windows_equal(wo, E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)
