@@ -1290,55 +1290,78 @@ struct FastEngine
 	}
 	// ---- heaps (same sift algorithm as oracle/o_heap.hpp) ----
 	template<bool MINHEAP> DEV static bool hless(uint64_t a, uint64_t b) { return MINHEAP ? (a < b) : (a > b); }
+	// the id that moves and its weight stay in registers (same comparisons and final arrangement as swapping level by level)
 	template<bool MINHEAP>
 	DEV void ipush(LDSQ id_t * H, uint32_t & f, id_t const id, LDSQ uint64_t const * W)
 	{
-		uint32_t i = f++; H[i] = id;
+		uint32_t i = f++;
+		uint64_t const w = W[id];
 		while ( i )
 		{
 			uint32_t const p = (i-1)>>1;
-			if ( hless<MINHEAP>(W[H[i]],W[H[p]]) ) { id_t const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
+			id_t const hp = H[p];
+			if ( hless<MINHEAP>(w,W[hp]) ) { H[i] = hp; i = p; }
 			else break;
 		}
+		H[i] = id;
 	}
 	template<bool MINHEAP>
 	DEV void ipop(LDSQ id_t * H, uint32_t & f, LDSQ uint64_t const * W)
 	{
-		H[0] = H[--f];
+		id_t const id = H[--f];
+		uint64_t const w = W[id];
 		uint32_t i = 0, r;
 		while ( (r = 2*i+2) < f )
 		{
-			uint32_t const m = hless<MINHEAP>(W[H[r-1]],W[H[r]]) ? (r-1) : r;
-			if ( hless<MINHEAP>(W[H[i]],W[H[m]]) ) return;
-			id_t const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
+			id_t const ha = H[r-1], hb = H[r];
+			uint64_t const wa = W[ha], wb = W[hb];
+			bool const pa = hless<MINHEAP>(wa,wb);
+			if ( hless<MINHEAP>(w,pa ? wa : wb) ) { H[i] = id; return; }
+			if ( pa ) { H[i] = ha; i = r-1; } else { H[i] = hb; i = r; }
 		}
 		uint32_t const l = 2*i+1;
-		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { id_t const t = H[i]; H[i] = H[l]; H[l] = t; }
+		if ( l < f )
+		{
+			id_t const hl = H[l];
+			if ( !hless<MINHEAP>(w,W[hl]) ) { H[i] = hl; i = l; }
+		}
+		H[i] = id;
 	}
+	// The record that moves stays in registers and the records it passes are shifted (same comparisons and the same final
+	// arrangement as swapping level by level): one LDS round trip per level.
 	template<typename TT, bool MINHEAP>
 	DEV void spush(LDSQ TT * H, uint32_t & f, TT const & e)
 	{
-		uint32_t i = f++; ldput(H+i,e);
+		uint32_t i = f++;
 		while ( i )
 		{
 			uint32_t const p = (i-1)>>1;
-			if ( hless<MINHEAP>(H[i].w,H[p].w) ) { ldswap(H+i,H+p); i = p; }
+			TT const ep = ldget(H+p);
+			if ( hless<MINHEAP>(e.w,ep.w) ) { ldput(H+i,ep); i = p; }
 			else break;
 		}
+		ldput(H+i,e);
 	}
 	template<typename TT, bool MINHEAP>
 	DEV void spop(LDSQ TT * H, uint32_t & f)
 	{
-		--f; ldput(H,ldget(H+f));
+		--f; TT const e = ldget(H+f);
 		uint32_t i = 0, r;
 		while ( (r = 2*i+2) < f )
 		{
-			uint32_t const m = hless<MINHEAP>(H[r-1].w,H[r].w) ? (r-1) : r;
-			if ( hless<MINHEAP>(H[i].w,H[m].w) ) return;
-			ldswap(H+i,H+m); i = m;
+			TT const a = ldget(H+r-1), b = ldget(H+r);
+			bool const pa = hless<MINHEAP>(a.w,b.w);
+			uint64_t const wm = pa ? a.w : b.w;
+			if ( hless<MINHEAP>(e.w,wm) ) { ldput(H+i,e); return; }
+			if ( pa ) { ldput(H+i,a); i = r-1; } else { ldput(H+i,b); i = r; }
 		}
 		uint32_t const l = 2*i+1;
-		if ( l < f && !hless<MINHEAP>(H[i].w,H[l].w) ) ldswap(H+i,H+l);
+		if ( l < f )
+		{
+			TT const el = ldget(H+l);
+			if ( !hless<MINHEAP>(e.w,el.w) ) { ldput(H+i,el); i = l; }
+		}
+		ldput(H+i,e);
 	}
 
 	// ================= per-lane path enumerations =================
@@ -1730,10 +1753,15 @@ struct FastEngine
 		if ( nf + nr > FSEQCAP ) { over(4096); return ~0u; }
 		conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[rp];
 		if ( conslen > MAXCONS ) { over(4096); return ~0u; }
-		uint32_t i = nf;
-		for ( uint32_t q = path; i; q = L.f_parent()[q] ) dst[--i] = L.f_stretch()[q];
-		i = nf;
-		for ( uint32_t q = rp; L.rc_len()[q]; q = L.rc_parent()[q] ) dst[i++] = L.rc_stretch()[q];
+		// the two parent chains are walked in one loop, so that their dependent loads are in flight together (rc_len drops
+		// by one per step and is zero at the root: the reverse chain has nr steps)
+		uint32_t qf = path, qr = rp;
+		uint32_t const ns = nf > nr ? nf : nr;
+		for ( uint32_t t = 0; t < ns; ++t )
+		{
+			if ( t < nf ) { dst[nf-1-t] = L.f_stretch()[qf]; qf = L.f_parent()[qf]; }
+			if ( t < nr ) { dst[nf+t] = L.rc_stretch()[qr]; qr = L.rc_parent()[qr]; }
+		}
 		return nf+nr;
 	}
 	DEV uint32_t decodeSeq(LDSQ uint8_t const * seq, uint32_t const n, LDSQ uint8_t * dst) const
@@ -1793,15 +1821,25 @@ struct FastEngine
 		uint32_t conslen = 0;
 		uint32_t const n = buildSeq(path,rp,cur,conslen);
 		if ( n == ~0u ) return false;
+		// sequences are compared and copied as six 64 bit words (the slots are 48 bytes, 8 byte aligned; bytes behind a
+		// sequence's length are never looked at): one round of loads instead of one per stretch
+		static_assert(FSEQCAP == 48 && (FastLds<CT>::o_cseq & 7) == 0,"candidate sequences are moved as six 64 bit words");
+		LDSQ uint64_t const * cur8 = reinterpret_cast<LDSQ uint64_t const *>(cur);
+		LDSQ uint64_t * prev8 = reinterpret_cast<LDSQ uint64_t *>(prev);
+		uint64_t const c0 = cur8[0], c1 = cur8[1], c2 = cur8[2], c3 = cur8[3], c4 = cur8[4], c5 = cur8[5];
 		if ( n == pn )
 		{
-			bool eq = true;
-			for ( uint32_t i = 0; i < n; ++i ) if ( prev[i] != cur[i] ) { eq = false; break; }
-			if ( eq ) return true;
+			uint64_t const p0 = prev8[0], p1 = prev8[1], p2 = prev8[2], p3 = prev8[3], p4 = prev8[4], p5 = prev8[5];
+			// bytes [0,n) equal <=> the xor of every word, cut to the bytes below n, is zero
+			#define DACC_SEQDIFF(q_,c_,p_) ( n > 8*(q_) ? ( ((c_)^(p_)) & ( n >= 8*(q_)+8 ? ~0ull : ((1ull << (8*(n-8*(q_))))-1) ) ) : 0ull )
+			uint64_t const diff = DACC_SEQDIFF(0,c0,p0) | DACC_SEQDIFF(1,c1,p1) | DACC_SEQDIFF(2,c2,p2) | DACC_SEQDIFF(3,c3,p3) | DACC_SEQDIFF(4,c4,p4) | DACC_SEQDIFF(5,c5,p5);
+			#undef DACC_SEQDIFF
+			if ( diff == 0 ) return true;
 		}
 		uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
-		LDSQ uint8_t * dst = L.cseq() + FSEQCAP*slot;
-		for ( uint32_t i = 0; i < n; ++i ) { uint8_t const c = cur[i]; prev[i] = c; dst[i] = c; }
+		LDSQ uint64_t * dst8 = reinterpret_cast<LDSQ uint64_t *>(L.cseq() + FSEQCAP*slot);
+		prev8[0] = c0; prev8[1] = c1; prev8[2] = c2; prev8[3] = c3; prev8[4] = c4; prev8[5] = c5;
+		dst8[0] = c0; dst8[1] = c1; dst8[2] = c2; dst8[3] = c3; dst8[4] = c4; dst8[5] = c5;
 		pn = n;
 		FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
 		FSTAT_ADD(19,1);
@@ -1867,16 +1905,17 @@ struct FastEngine
 			{
 				if ( n >= PSIQ || sup > 255 && sizeof(id_t) == 1 ) return 0xFF;
 				PSI e; e.path = pi; e.current = mi; e.left = sub; e.right = sup;
-				// FiniteSizeHeap push (max heap on the weight)
-				uint32_t i = n++; H[i] = e;
+				// FiniteSizeHeap push (max heap on the weight); the entry that moves stays in registers
+				uint32_t i = n++;
 				uint64_t const we = psiW(e,FC,sbase);
 				while ( i )
 				{
 					uint32_t const p = (i-1)>>1;
 					PSI const ep = H[p];
-					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; i = p; }
 					else break;
 				}
+				H[i] = e;
 			}
 		}
 		uint32_t cnt = 0;
@@ -1888,34 +1927,39 @@ struct FastEngine
 			if ( prune && psiW(top,FC,sbase) <= T0 ) return cnt | 0x20;
 			// pop
 			{
-				--n; PSI const last = H[n]; H[0] = last;
+				// the last entry sifts down from the root: its weight is evaluated once, the children's once per level
+				--n; PSI const last = H[n];
+				uint64_t const wl = psiW(last,FC,sbase);
 				uint32_t i = 0, r;
 				while ( (r = 2*i+2) < n )
 				{
-					uint32_t const m = psiW(H[r-1],FC,sbase) > psiW(H[r],FC,sbase) ? (r-1) : r;
-					PSI const em = H[m], ei = H[i];
-					if ( psiW(ei,FC,sbase) > psiW(em,FC,sbase) ) break;
-					H[i] = em; H[m] = ei; i = m;
+					PSI const ea = H[r-1], eb = H[r];
+					uint64_t const wa = psiW(ea,FC,sbase), wb = psiW(eb,FC,sbase);
+					bool const pa = wa > wb;
+					if ( wl > (pa ? wa : wb) ) break;
+					if ( pa ) { H[i] = ea; i = r-1; } else { H[i] = eb; i = r; }
 				}
 				if ( r >= n )
 				{
 					uint32_t const l = 2*i+1;
-					if ( l < n ) { PSI const el = H[l], ei = H[i]; if ( !(psiW(ei,FC,sbase) > psiW(el,FC,sbase)) ) { H[i] = el; H[l] = ei; } }
+					if ( l < n ) { PSI const el = H[l]; if ( !(wl > psiW(el,FC,sbase)) ) { H[i] = el; i = l; } }
 				}
+				H[i] = last;
 			}
 			uint32_t bi;
 			if ( scoreNext(sbase,top.left,top.right,top.current,bi) )
 			{
 				PSI e = top; e.current = bi;
-				uint32_t i = n++; H[i] = e;
+				uint32_t i = n++;
 				uint64_t const we = psiW(e,FC,sbase);
 				while ( i )
 				{
 					uint32_t const p = (i-1)>>1;
 					PSI const ep = H[p];
-					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; i = p; }
 					else break;
 				}
+				H[i] = e;
 			}
 			out[2*cnt] = top.path; out[2*cnt+1] = top.current; ++cnt;
 		}
