@@ -96,6 +96,7 @@ struct FastLds
 	LDSQ uint8_t * base;
 	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
 	static_assert((CT::precap & (CT::precap-1)) == 0,"precap must be a power of two: the bitonic sorts pad to one");
+	static_assert(sizeof(typename CT::id_t) > 1 || (CT::fcap <= 256 && CT::rccap <= 256),"pool slots are recorded as id_t (pout)");
 	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
 	// ---- live during the whole window ----
 	FLD(str,uint8_t,CT::maxs*64,0)
@@ -1884,8 +1885,8 @@ struct FastEngine
 			if ( !offerCandidate(si.w,L.fp_id()[clSlot<FCH>(FC,si.path)],L.rc_ord()[sbase+si.current],pn) ) return;
 		}
 	}
-	// lane form: the same pops without the candidate heap; the (path, entry) sequence goes to `out` (at most 16 pairs of
-	// ids) and is offered to the candidate heap later, in pair order (replayPair).  The lane's heap holds the intervals
+	// lane form: the same pops without the candidate heap; the (forward pool slot, reverse pool id) sequence goes to `out`
+	// (at most 16 pairs of ids) and is offered to the candidate heap later, in pair order (replayPair).  The lane's heap holds the intervals
 	// as (path, current, left, right); weights are recomputed from the tables.  Returns the count or 0xFF if the heap
 	// is too small (the pair is then combined serially).
 	struct PSI { id_t path, current, left, right; };
@@ -1961,7 +1962,8 @@ struct FastEngine
 				}
 				H[i] = e;
 			}
-			out[2*cnt] = top.path; out[2*cnt+1] = top.current; ++cnt;
+			// recorded resolved: pool slot of the popped forward path and pool id of the reverse path (both fit id_t)
+			out[2*cnt] = static_cast<id_t>(clSlot<FCH>(FC,top.path)); out[2*cnt+1] = L.rc_ord()[sbase+top.current]; ++cnt;
 		}
 		return cnt;
 	}
@@ -1973,8 +1975,8 @@ struct FastEngine
 		FSTAT_ADD(16,1); FSTAT_ADD(17,cnt);
 		for ( uint32_t e = 0; e < cnt; ++e )
 		{
-			uint32_t const o = clSlot<FCH>(FC,out[2*e]);
-			uint32_t const rp = L.rc_ord()[sbase+out[2*e+1]];
+			uint32_t const o = out[2*e];
+			uint32_t const rp = out[2*e+1];
 			uint64_t const w = L.fp_adj()[o] + L.rc_w()[rp];
 			if ( ncdh == 16 && w <= L.cdh()[0].w ) { if ( e == 0 ) FSTAT_ADD(20,1); return false; }
 			if ( !offerCandidate(w,L.fp_id()[o],rp,pn) ) return false;
@@ -2087,10 +2089,15 @@ struct FastEngine
 	// returns 0 when the round is done, 1 when pair q needs the middle piece [pl_midA,pl_midB] of stretch pl_midpar,
 	// 2 when the forward tree of the exact pair q found no pool space next to the trees of the batch (alone: the batch
 	// holds the tree of this first k-mer only)
-	DEV uint32_t replayRound(uint32_t & q, uint32_t const n, uint32_t const p0, uint32_t const fstart, int64_t const lmin, int64_t const lmax, bool const alone)
+	// live: bit q set for the pairs of the round that are not PM_SKIP (most pairs share no junction k-mer and are skipped:
+	// lane 0 walks the set bits instead of reading every pair's mode)
+	DEV uint32_t replayRound(uint32_t & q, uint32_t const n, uint32_t const p0, uint32_t const fstart, int64_t const lmin, int64_t const lmax, bool const alone, uint64_t const live)
 	{
 		for ( ; q < n; ++q )
 		{
+			uint64_t const rest = live >> q;
+			if ( !rest ) { q = n; break; }
+			q += static_cast<uint32_t>(__builtin_ctzll(rest));
 			uint32_t const mode = L.poutn()[q];
 			FSTAT_ADD(13,1);
 			if ( mode == PM_SKIP ) { FSTAT_ADD(14,1); continue; }
@@ -2306,6 +2313,8 @@ struct FastEngine
 				uint32_t const nround = (npairs-p0 < NPL) ? (npairs-p0) : static_cast<uint32_t>(NPL);
 				bool const cfull = wv_bcast(ncdh == 16 ? 1u : 0u,0) != 0;
 				roundT0 = cfull ? L.cdh()[0].w : 0ull;
+				uint64_t live = 0;
+				static_assert(NPL <= 64,"one bit per pair of a round");
 				for ( uint32_t t = lane; t < nround; t += WSZ )
 				{
 					uint32_t const p = p0 + t;
@@ -2322,7 +2331,9 @@ struct FastEngine
 						mode = cnt == 0xFF ? static_cast<uint32_t>(PM_SERIAL) : (cnt ? cnt : static_cast<uint32_t>(PM_SKIP));
 					}
 					L.poutn()[t] = mode;
+					if ( mode != PM_SKIP ) live |= 1ull << t;
 				}
+				live = wv_or64(live);
 				wv_sync();
 				PROF(*this,5)
 				if ( lane == 0 ) pcount(27,1);
@@ -2330,7 +2341,7 @@ struct FastEngine
 				while ( true )
 				{
 					uint32_t req = 0;
-					if ( lane == 0 ) req = replayRound(q,nround,p0,fstart,lmin,lmax,nb == 1);
+					if ( lane == 0 ) req = replayRound(q,nround,p0,fstart,lmin,lmax,nb == 1,live);
 					wv_sync();
 					flags = wv_bcast(flags,0); if ( flags ) return false;
 					req = wv_bcast(req,0);
