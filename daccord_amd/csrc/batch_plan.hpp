@@ -62,7 +62,7 @@ struct BatchPlan
 		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear(); pile_status.assign(np,DACC_OK); pile_errors.clear();
 		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0; ndeepwin = 0; deep = false;
 		if ( trace_bytes != 1 && trace_bytes != 2 ) { err = "trace values are 1 byte (tspace <= 125) or 2 bytes"; return DACC_EINVAL; }
-		if ( par.tspace <= 0 || par.tspace > 128 ) { err = "tspace must be in [1,128] (128-bit column vectors of the trace kernel)"; return DACC_ENOTSUP; }
+		if ( par.tspace <= 0 || par.tspace > 512 ) { err = "tspace must be in [1,512] (column vectors of the trace kernels: 2, 4 or 8 64-bit words)"; return DACC_ENOTSUP; }
 		uint8_t const * tr8 = static_cast<uint8_t const *>(trace); uint16_t const * tr16 = static_cast<uint16_t const *>(trace);
 		auto const tv = [&](uint64_t const i) -> uint32_t { return trace_bytes == 2 ? tr16[i] : tr8[i]; };
 		std::vector<int32_t> diff;

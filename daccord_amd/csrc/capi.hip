@@ -54,6 +54,20 @@ __global__ void __launch_bounds__(64) k_trace(TraceBatch B)
 		traceBlock(B,task,st);
 }
 
+// tspace in (128, 64*NW]: NW words per column vector; the first nl lanes of the wavefront take blocks (nl = 64, 32, 16 or 8:
+// as many as have room for their column checkpoints in LDS)
+template<int NW>
+__global__ void __launch_bounds__(64) k_trace_wide(TraceBatch B, uint32_t const nl)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_trace[];
+	uint32_t const slots = traceSlots(B.maxcols);
+	TraceStoreW<NW> st;
+	st.w = (LDSQ uint64_t *)lds_trace; st.sc = (LDSQ uint16_t *)(lds_trace + static_cast<size_t>(slots)*(2*NW)*nl*8); st.lane = threadIdx.x; st.nl = nl;
+	if ( threadIdx.x < nl )
+		for ( uint64_t task = static_cast<uint64_t>(blockIdx.x)*nl + threadIdx.x; task < B.nblocks; task += static_cast<uint64_t>(gridDim.x)*nl )
+			traceBlockWide<NW>(B,task,st);
+}
+
 // Work distribution of the window kernels.  Windows differ in cost by orders of magnitude, so workgroups pull indices
 // from counters; workgroup b runs on XCD b%8 (observed placement), and the windows of one pile share its overlaps and
 // reads, so every XCD first drains its own contiguous eighth of the index range (its L2 keeps the pile's data) and
@@ -354,7 +368,7 @@ struct dacc_ctx
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
 	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2;
 	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
-	uint32_t tr_grid, tr_lds, trace_bytes, win_grid;
+	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
 	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
@@ -499,7 +513,9 @@ static int runDevice(dacc_ctx * c)
 		TB.piles = c->d_piles.p; TB.ovl = c->d_ovl.p; TB.ovl_pile = c->d_ovl_pile.p; TB.trace = c->d_trace.p;
 		TB.blk_ovl = c->d_blk_ovl.p; TB.blk_b0 = c->d_blk_b0.p; TB.nblocks = BP.nblocks; TB.wt_b = c->d_wt_b.p; TB.wt_e = c->d_wt_e.p;
 		TB.maxcols = BP.maxcols; TB.trace_bytes = c->trace_bytes; TB.errflag = c->d_err.p + 2;
-		hipLaunchKernelGGL(k_trace,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB);
+		if ( c->tr_words == 2 ) hipLaunchKernelGGL(k_trace,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB);
+		else if ( c->tr_words == 4 ) hipLaunchKernelGGL(k_trace_wide<4>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
+		else hipLaunchKernelGGL(k_trace_wide<8>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
 	}
 	HIPCHK(hipEventRecord(c->ev[1],s));
 	if ( BP.nwindows )
@@ -645,7 +661,7 @@ static int runDevice(dacc_ctx * c)
 	}
 	if ( herr[3] ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
 	if ( herr[1] ) { c->err = "vote kernel capacity exceeded"; return DACC_ENOTSUP; }
-	if ( herr[2] ) { c->err = "trace kernel capacity exceeded (tspace block longer than 128 or B span > 255)"; return DACC_ENOTSUP; }
+	if ( herr[2] ) { c->err = "trace kernel capacity exceeded (a tspace block longer than the column vectors or a B span beyond the column store)"; return DACC_ENOTSUP; }
 	c->frags.clear(); c->bases.clear();
 	uint64_t nbases = 0;
 	for ( uint64_t pi = 0; pi < BP.piles.size(); ++pi )
@@ -697,11 +713,25 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	// a few rounds of blocks per workgroup
 	{
 		c->trace_bytes = trace_bytes;
-		c->tr_lds = traceSlots(BP.maxcols)*64u*34u;
+		c->tr_words = c->par.tspace <= 128 ? 2 : (c->par.tspace <= 256 ? 4 : 8);
+		c->tr_lanes = 64;
+		if ( c->tr_words == 2 ) c->tr_lds = traceSlots(BP.maxcols)*64u*34u;
+		else
+		{
+			// wide blocks: as many lanes per wavefront as have room for their column checkpoints
+			uint32_t const perlane = c->tr_words == 4 ? traceWideBytesPerLane<4>(BP.maxcols) : traceWideBytesPerLane<8>(BP.maxcols);
+			while ( c->tr_lanes > 8 && static_cast<uint64_t>(c->tr_lanes)*perlane > 160*1024 ) c->tr_lanes >>= 1;
+			c->tr_lds = c->tr_lanes*perlane;
+		}
 		if ( c->tr_lds > 160*1024 ) { c->err = "a trace block spans too many B bases for the trace kernel's LDS column store"; return DACC_ENOTSUP; }
-		if ( c->tr_lds > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
+		if ( c->tr_lds > 64*1024 )
+		{
+			if ( c->tr_words == 2 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
+			else if ( c->tr_words == 4 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_wide<4>),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
+			else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_wide<8>),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
+		}
 		uint64_t percu = (160*1024) / (c->tr_lds ? c->tr_lds : 1); if ( percu > 8 ) percu = 8; if ( percu < 1 ) percu = 1;
-		uint64_t g = (BP.nblocks+63)/64, gmax = 256*percu*4;
+		uint64_t g = (BP.nblocks+c->tr_lanes-1)/c->tr_lanes, gmax = 256*percu*4;
 		if ( g > gmax ) g = gmax;
 		if ( g < 1 ) g = 1;
 		c->tr_grid = g;

@@ -253,5 +253,194 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 	if ( a0 == static_cast<uint32_t>(o.abpos) ) emitBoundary(B,pile,o,a0,b0);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide blocks: tspace in (128, 64*NW].  The reference takes whatever trace spacing the LAS file has (daccord.cpp:1375);
+// DALIGNER writes two byte trace values from tspace 126 on.  Same algorithm as traceBlock with NW 64-bit words per column
+// vector (block-wise Myers: the horizontal deltas of the top row of a word are the carries of the word below); kept apart
+// from the two word version above, which is the one every default run uses.  The column store is interleaved over the
+// `nl` lanes of the workgroup that take blocks (fewer than 64 when 64 lanes' checkpoints would not fit LDS).
+template<int NW> struct TColW { uint64_t pv[NW], mv[NW]; uint32_t score; };
+template<int NW>
+struct TraceStoreW
+{
+	LDSQ uint64_t * w; LDSQ uint16_t * sc; uint32_t lane, nl;
+	DEV void put(uint32_t const e, TColW<NW> const & c) const
+	{
+		LDSQ uint64_t * p = w + static_cast<size_t>(e)*(2*NW)*nl + lane;
+		#pragma unroll
+		for ( int q = 0; q < NW; ++q ) { p[(2*q)*nl] = c.pv[q]; p[(2*q+1)*nl] = c.mv[q]; }
+		sc[e*nl+lane] = static_cast<uint16_t>(c.score);
+	}
+	DEV TColW<NW> get(uint32_t const e) const
+	{
+		LDSQ uint64_t const * p = w + static_cast<size_t>(e)*(2*NW)*nl + lane;
+		TColW<NW> c;
+		#pragma unroll
+		for ( int q = 0; q < NW; ++q ) { c.pv[q] = p[(2*q)*nl]; c.mv[q] = p[(2*q+1)*nl]; }
+		c.score = sc[e*nl+lane]; return c;
+	}
+};
+template<int NW> HDEV uint32_t traceWideBytesPerLane(uint32_t const maxcols) { return traceSlots(maxcols)*(16u*NW+2u); }
+// word `idx` (run time) of a register array: a select chain over the compile time indices (no scratch)
+template<int NW> DEV uint64_t traceWord(uint64_t const (&a)[NW], uint32_t const idx)
+{
+	uint64_t r = 0;
+	#pragma unroll
+	for ( int q = 0; q < NW; ++q ) r = (idx == static_cast<uint32_t>(q)) ? a[q] : r;
+	return r;
+}
+template<int NW> struct TracePeqW { uint64_t e0[NW], e1[NW], e2[NW], e3[NW]; };
+template<int NW> DEV uint64_t tracePeqWord(TracePeqW<NW> const & Q, uint32_t const c, int const q)
+{
+	// masks instead of selects: a select chain over the four arrays is turned back into an indexed load from a copy of Q in
+	// scratch memory by the compiler
+	uint64_t const m0 = 0ull - static_cast<uint64_t>(c == 0), m1 = 0ull - static_cast<uint64_t>(c == 1), m2 = 0ull - static_cast<uint64_t>(c == 2), m3 = 0ull - static_cast<uint64_t>(c == 3);
+	return (Q.e0[q] & m0) | (Q.e1[q] & m1) | (Q.e2[q] & m2) | (Q.e3[q] & m3);
+}
+template<int NW>
+DEV void traceStepW(TracePeqW<NW> const & Q, uint32_t const tc, TColW<NW> & C, uint64_t const (&mask)[NW], uint32_t const topblk, uint64_t const top)
+{
+	uint64_t phc = 1, mhc = 0;      // word 0: the top row of the matrix has horizontal delta +1 (global alignment)
+	#pragma unroll
+	for ( int q = 0; q < NW; ++q )
+	{
+		uint64_t const Eq = tracePeqWord<NW>(Q,tc,q);
+		uint64_t const Eqc = Eq | mhc;
+		uint64_t const Xv = Eq | C.mv[q];
+		uint64_t const Xh = (((Eqc & C.pv[q]) + C.pv[q]) ^ C.pv[q]) | Eqc;
+		uint64_t Ph = C.mv[q] | ~(Xh | C.pv[q]);
+		uint64_t Mh = C.pv[q] & Xh;
+		if ( static_cast<uint32_t>(q) == topblk ) { if ( Ph & top ) ++C.score; else if ( Mh & top ) --C.score; }
+		uint64_t const nphc = Ph>>63, nmhc = Mh>>63;
+		Ph = (Ph<<1) | phc; Mh = (Mh<<1) | mhc;
+		C.pv[q] = (Mh | ~(Xv | Ph)) & mask[q];
+		C.mv[q] = (Ph & Xv) & mask[q];
+		phc = nphc; mhc = nmhc;
+	}
+}
+
+template<int NW, typename ST>
+DEV void traceBlockWide(TraceBatch const & B, uint64_t const task, ST const & st)
+{
+	uint32_t const oi = B.blk_ovl[task];
+	DevOvl const o = B.ovl[oi];
+	DevPile const pile = B.piles[B.ovl_pile[oi]];
+	uint32_t const bi = static_cast<uint32_t>(task - o.blk0);
+	int32_t const ts = B.P.tspace;
+	int32_t const ai = (o.abpos/ts)*ts + static_cast<int32_t>(bi)*ts;
+	uint32_t const a0 = ai > o.abpos ? ai : o.abpos;
+	uint32_t const a1 = (ai+ts) < o.aepos ? (ai+ts) : o.aepos;
+	uint32_t const m = a1-a0;
+	uint32_t const b0 = B.blk_b0[task];
+	uint32_t const n = B.trace_bytes == 2 ? reinterpret_cast<uint16_t const *>(B.trace)[o.trace_off + 2*bi + 1] : B.trace[o.trace_off + 2*bi + 1];
+	if ( m > 64u*NW || n > B.maxcols || m == 0 ) { if ( m ) atomicOrFlag(B.errflag); return; }
+
+	uint64_t const aoff = B.boff[pile.aread]; uint32_t const arl = B.rlen[pile.aread];
+	uint64_t const boffs = B.boff[o.bread]; uint32_t const brl = B.rlen[o.bread];
+	bool const inv = o.flags & 1;
+
+	TracePeqW<NW> Q; uint64_t mask[NW];
+	#pragma unroll
+	for ( int q = 0; q < NW; ++q )
+	{
+		Q.e0[q] = Q.e1[q] = Q.e2[q] = Q.e3[q] = 0;
+		uint32_t const lo = 64u*q;
+		mask[q] = m > lo ? ( m >= lo+64 ? ~0ull : ((1ull << (m-lo))-1) ) : 0ull;
+	}
+	// pattern masks: the word of a base is picked by selects over the compile time word indices (a run time index into
+	// the register arrays would put them into scratch memory)
+	for ( uint32_t i = 0; i < m; ++i )
+	{
+		uint32_t const c = readBase(B.bps,aoff,arl,false,a0+i); uint64_t const bit = 1ull << (i&63); uint32_t const wi = i>>6;
+		#pragma unroll
+		for ( int q = 0; q < NW; ++q )
+		{
+			uint64_t const b = (wi == static_cast<uint32_t>(q)) ? bit : 0ull;
+			Q.e0[q] |= (c == 0) ? b : 0ull; Q.e1[q] |= (c == 1) ? b : 0ull; Q.e2[q] |= (c == 2) ? b : 0ull; Q.e3[q] |= (c == 3) ? b : 0ull;
+		}
+	}
+	uint32_t const topblk = (m-1)>>6; uint64_t const top = 1ull << ((m-1)&63);
+	uint32_t const ncp = B.maxcols/TRS + 1;
+	TColW<NW> C;
+	#pragma unroll
+	for ( int q = 0; q < NW; ++q ) { C.pv[q] = mask[q]; C.mv[q] = 0; }
+	C.score = m;
+	st.put(0,C);
+	#define DACC_LOADB(c0_,cnt_,dst_) { dst_ = 0; _Pragma("unroll") for ( uint32_t u = 0; u < TRS; ++u ) if ( u < (cnt_) ) dst_ |= static_cast<uint32_t>(readBase(B.bps,boffs,brl,inv,b0+(c0_)+u)) << (2*u); }
+	for ( uint32_t c0 = 0; c0 < n; c0 += TRS )
+	{
+		uint32_t const cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
+		uint32_t bb; DACC_LOADB(c0,cnt,bb)
+		for ( uint32_t u = 0; u < cnt; ++u ) traceStepW<NW>(Q,(bb>>(2*u))&3,C,mask,topblk,top);
+		if ( cnt == TRS ) st.put(c0/TRS+1,C);
+	}
+	uint32_t const wa = B.P.w % B.P.a, lw = pile.l >= B.P.w ? pile.l - B.P.w : 0xFFFFFFFFu;
+	uint32_t xa = (a0+m) % B.P.a;
+	#define DACC_EMIT(x_,b_) { uint32_t const xx_ = (x_); if ( xa == 0 || xa == wa || xx_ == lw || xx_ == pile.l ) emitBoundary(B,pile,o,xx_,b_); }
+	#define DACC_XDEC { xa = xa ? xa-1 : B.P.a-1; }
+	uint32_t i = m, j = n, d = C.score;
+	for ( int32_t g = static_cast<int32_t>((B.maxcols ? B.maxcols-1 : 0)/TRS); g >= 0; --g )
+	{
+		if ( !(i && j && (j-1)/TRS == static_cast<uint32_t>(g)) ) continue;
+		uint32_t bseg;
+		{
+			TColW<NW> R = st.get(g);
+			uint32_t const c0 = g*TRS, cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
+			DACC_LOADB(c0,cnt,bseg)
+			for ( uint32_t u = 0; u < cnt; ++u )
+			{
+				traceStepW<NW>(Q,(bseg>>(2*u))&3,R,mask,topblk,top);
+				st.put(ncp + u,R);
+			}
+		}
+		while ( i && j && (j-1)/TRS == static_cast<uint32_t>(g) )
+		{
+			bool done = false;
+			{
+				// D[i-1][j-1] = bottom(j-1) - sum of the vertical deltas of rows i..m in column j-1
+				TColW<NW> const q = st.get(((j-1) % TRS) ? (ncp + (j-2) % TRS) : ((j-1)/TRS));
+				uint32_t const sh = i-1, shw = sh>>6, shb = sh&63;
+				int32_t sum = 0;
+				#pragma unroll
+				for ( int b = 0; b < NW; ++b )
+				{
+					uint64_t const pvb = static_cast<uint32_t>(b) < shw ? 0ull : ( static_cast<uint32_t>(b) == shw ? (q.pv[b] >> shb) : q.pv[b] );
+					uint64_t const mvb = static_cast<uint32_t>(b) < shw ? 0ull : ( static_cast<uint32_t>(b) == shw ? (q.mv[b] >> shb) : q.mv[b] );
+					sum += dacc_popc64(pvb) - dacc_popc64(mvb);
+				}
+				uint32_t const dd = q.score - sum;
+				uint32_t const cb = (bseg >> (2*((j-1) - g*TRS))) & 3;
+				uint64_t pw = 0;
+				#pragma unroll
+				for ( int b = 0; b < NW; ++b ) pw = (static_cast<uint32_t>(b) == shw) ? tracePeqWord<NW>(Q,cb,b) : pw;
+				uint32_t const neq = ((pw >> shb) & 1) ? 0u : 1u;
+				if ( dd + neq == d )
+				{
+					DACC_EMIT(a0+i,b0+j)
+					--i; --j; d = dd; done = true; DACC_XDEC
+				}
+			}
+			if ( !done )
+			{
+				uint32_t const r = i-1;
+				TColW<NW> const cj = st.get((j % TRS) ? (ncp + (j-1) % TRS) : (j/TRS));
+				bool const plus = (traceWord<NW>(cj.pv,r>>6) >> (r&63)) & 1;
+				if ( plus )
+				{
+					DACC_EMIT(a0+i,b0+j)
+					--i; d = d-1; done = true; DACC_XDEC
+				}
+			}
+			if ( !done ) { --j; d = d-1; }
+		}
+	}
+	while ( i ) { DACC_EMIT(a0+i,b0) --i; DACC_XDEC }
+	#undef DACC_EMIT
+	#undef DACC_XDEC
+	#undef DACC_LOADB
+	if ( a0 == static_cast<uint32_t>(o.abpos) ) emitBoundary(B,pile,o,a0,b0);
+}
+
 }
 #endif

@@ -64,8 +64,14 @@ class SynthData:
         self.boff = arr(boff, nr.value, np.uint64)
         self.rlen = arr(rlen, nr.value, np.uint32)
         self.ovl = arr(ovl, novl.value, np.dtype(DaccOverlap))
-        self.trace = arr(tr, ntr.value + 8, np.uint8)
-        self.ntrace = ntr.value
+        # trace values: uint8 up to tspace 125, uint16 beyond (DALIGNER's rule); trace_off counts values
+        self.trace_bytes = 2 if tspace > 125 else 1
+        if self.trace_bytes == 2:
+            self.trace = arr(tr, ntr.value // 2 + 8, np.uint16)
+            self.ntrace = ntr.value // 2
+        else:
+            self.trace = arr(tr, ntr.value + 8, np.uint8)
+            self.ntrace = ntr.value
         self.piles = arr(piles, npiles.value, np.dtype(DaccPile))
         self.genome = arr(genome, genome_len, np.uint8)
         self.truth = arr(truth, 3 * nr.value, np.int64).reshape(-1, 3)

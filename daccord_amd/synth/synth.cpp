@@ -133,7 +133,9 @@ void * synth_generate(synth_params const * P)
 	for ( uint32_t i = 0; i < P->nreads; ++i ) rank[order[i]] = i;
 
 	std::vector< std::vector<dacc_overlap> > PO(P->nreads);
-	std::vector< std::vector<uint8_t> > PT(P->nreads);
+	// trace values: one byte each up to tspace 125, two bytes (little endian) beyond, as DALIGNER writes them
+	bool const wide = P->tspace > 125; uint32_t const tvmax = wide ? 65535u : 255u;
+	std::vector< std::vector<uint16_t> > PT(P->nreads);
 	int const nth = P->nthreads > 0 ? P->nthreads : 1;
 	int64_t const ts = P->tspace;
 	#ifdef _OPENMP
@@ -230,7 +232,7 @@ void * synth_generate(synth_params const * P)
 				if ( (op & 1) && apos == blockend )
 				{
 					// next A base opens a new block: close the current one
-					if ( diffs > 255 || blen > 255 ) bad = true;
+					if ( diffs > tvmax || blen > tvmax ) bad = true;
 					PT[a].push_back(diffs); PT[a].push_back(blen);
 					totaldiffs += diffs; diffs = 0; blen = 0;
 					blockend = std::min<int64_t>(blockend+ts,aepos);
@@ -239,7 +241,7 @@ void * synth_generate(synth_params const * P)
 				if ( op & 2 ) ++blen;
 				if ( op & 1 ) ++apos;
 			}
-			if ( diffs > 255 || blen > 255 ) bad = true;
+			if ( diffs > tvmax || blen > tvmax ) bad = true;
 			PT[a].push_back(diffs); PT[a].push_back(blen); totaldiffs += diffs;
 			if ( bad ) { PT[a].resize(O.trace_off); continue; }
 			O.diffs = totaldiffs;
@@ -250,17 +252,21 @@ void * synth_generate(synth_params const * P)
 	for ( uint32_t a = 0; a < P->nreads; ++a )
 	{
 		dacc_pile pile; pile.aread = a; pile.novl = PO[a].size(); pile.first_ovl = S->ovl.size();
-		uint64_t const tbase = S->trace.size();
+		uint64_t const tbase = wide ? S->trace.size()/2 : S->trace.size();      // offsets count trace values
 		for ( uint64_t i = 0; i < PO[a].size(); ++i )
 		{
 			dacc_overlap O = PO[a][i];
 			O.trace_off += tbase;
 			S->ovl.push_back(O);
 		}
-		S->trace.insert(S->trace.end(),PT[a].begin(),PT[a].end());
+		for ( uint64_t i = 0; i < PT[a].size(); ++i )
+		{
+			S->trace.push_back(static_cast<uint8_t>(PT[a][i] & 0xFF));
+			if ( wide ) S->trace.push_back(static_cast<uint8_t>(PT[a][i] >> 8));
+		}
 		S->piles.push_back(pile);
 	}
-	S->trace.resize(S->trace.size()+8,0);
+	S->trace.resize(S->trace.size()+16,0);
 	return S;
 }
 
@@ -273,7 +279,7 @@ void synth_get(void * v,
 {
 	Synth * S = static_cast<Synth *>(v);
 	*bps = S->bps.data(); *bps_bytes = S->bps.size(); *boff = S->boff.data(); *rlen = S->rlen.data(); *nreads = S->rlen.size();
-	*ovl = S->ovl.data(); *novl = S->ovl.size(); *trace = S->trace.data(); *ntrace = S->trace.size()-8;
+	*ovl = S->ovl.data(); *novl = S->ovl.size(); *trace = S->trace.data(); *ntrace = S->trace.size()-16;      /* bytes */
 	*piles = S->piles.data(); *npiles = S->piles.size(); *genome = S->genome.data(); *truth = S->truth.data();
 }
 

@@ -113,7 +113,24 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		std::vector<uint64_t> colw(traceSlots(BP.maxcols)*4); std::vector<uint16_t> colsc(traceSlots(BP.maxcols));
 		TraceStoreMem st; st.w = colw.data(); st.sc = colsc.data();
 		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag;
-		for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);
+		if ( P.tspace <= 128 ) for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);
+		else
+		{
+			// wide blocks: the device's lane-interleaved column store over a host buffer (16 lanes, block t on lane t % 16)
+			uint32_t const nl = 16, slots = traceSlots(BP.maxcols);
+			if ( P.tspace <= 256 )
+			{
+				std::vector<uint64_t> ww(static_cast<size_t>(slots)*8*nl); std::vector<uint16_t> ws(static_cast<size_t>(slots)*nl);
+				TraceStoreW<4> sw; sw.w = ww.data(); sw.sc = ws.data(); sw.nl = nl;
+				for ( uint64_t t = 0; t < BP.nblocks; ++t ) { sw.lane = t % nl; traceBlockWide<4>(TB,t,sw); }
+			}
+			else
+			{
+				std::vector<uint64_t> ww(static_cast<size_t>(slots)*16*nl); std::vector<uint16_t> ws(static_cast<size_t>(slots)*nl);
+				TraceStoreW<8> sw; sw.w = ww.data(); sw.sc = ws.data(); sw.nl = nl;
+				for ( uint64_t t = 0; t < BP.nblocks; ++t ) { sw.lane = t % nl; traceBlockWide<8>(TB,t,sw); }
+			}
+		}
 	}
 	if ( errflag ) { c->err = "trace kernel capacity exceeded"; return DACC_ENOTSUP; }
 	for ( uint64_t i = 0; i < BP.nwt; ++i ) if ( wt_b[i] == 0xDEADBEEF || wt_e[i] == 0xDEADBEEF ) { c->err = "window table entry not written"; return DACC_EHIP; }

@@ -142,3 +142,20 @@ def test_deep_batch_starts_in_the_deep_tier(lanes):
     assert t1 > 0.7 * len(wo) and gen <= 1, (t1, t2, t3, gen, len(wo))
     assert windows_equal(wo, E.windows()) == []
     assert frags_equal(fo, bo, fe, be)
+
+
+@pytest.mark.parametrize("tspace", [126, 200, 300])
+def test_wide_trace_spacing(tspace):
+    """tspace > 125: two byte trace values; > 128: the trace kernel's wide column vectors (4 words up to 256, 8 up to
+    512), the reference takes any spacing (daccord.cpp:1375).  Window boundaries, windows and fragments as the oracle's."""
+    d = SynthData(60000, 150, 4000, seed=21, tspace=tspace)
+    assert d.trace_bytes == 2
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    p = default_params(k=8, tspace=tspace)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[0:3], ovl, d.trace, trace_bytes=2, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[0:3], ovl, d.trace, trace_bytes=2)
+    assert len(bo) > 3000
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)

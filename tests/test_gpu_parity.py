@@ -70,6 +70,33 @@ def test_high_error_gap_filling_and_failures():
     assert frags_equal(fo, bo, fx, bx)
 
 
+@pytest.mark.parametrize("tspace", [126, 200, 300])
+def test_wide_trace_spacing(tspace):
+    """tspace > 125: two byte trace values; > 128: k_trace_wide<4> (up to 256) / <8> (up to 512)."""
+    d = SynthData(60000, 150, 4000, seed=21, tspace=tspace)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E = _pair(d, k=8, tspace=tspace)
+    fo, bo = O.run(piles[:6], ovl, d.trace, trace_bytes=2, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:6], ovl, d.trace, trace_bytes=2)
+    assert len(bo) > 6000
+    assert windows_equal(O.windows(), E.debug_windows()) == []
+    assert frags_equal(fo, bo, fx, bx)
+
+
+def test_deep_batch_starts_in_the_deep_tier():
+    """50x piles: the batch starts in the deep tier (k_window_fast<4>), same bits as the oracle."""
+    d = SynthData(30000, 300, 5000, seed=7)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E = _pair(d, k=14)
+    fo, bo = O.run(piles[10:14], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[10:14], ovl, d.trace)
+    wo = O.windows()
+    t = E.timing()
+    assert (wo["mao"] > 40).mean() > 0.5 and t.tier_out[0] < 0.3 * len(wo), list(t.tier_out)
+    assert windows_equal(wo, E.debug_windows()) == []
+    assert frags_equal(fo, bo, fx, bx)
+
+
 def test_ont_like_profile_k_sweep():
     d = SynthData(60000, 150, 3000, erate=0.15, ins_frac=1 / 3, del_frac=1 / 3, sub_frac=1 / 3, seed=5)
     ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
