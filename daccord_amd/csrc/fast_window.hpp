@@ -2369,11 +2369,33 @@ struct FastEngine
 			fstart += nb; pskip = 0;
 		}
 		PROF(*this,12)
-		if ( lane == 0 )
+		// CDH -> CH -> ACC (:5099-5136) leaves the kept candidates in descending weight order.  With pairwise distinct
+		// weights that order does not depend on the heaps: one lane per candidate counts the heavier ones and stores its
+		// candidate at that rank.  Equal weights (rare) take the two heaps, whose mechanics decide their order.
+		wv_sync();
+		uint32_t const nkept = wv_bcast(ncdh,0);
 		{
-			uint32_t nch = 0;
-			while ( ncdh ) { FCC const c = ldget(L.cdh()); spop<FCC,true>(L.cdh(),ncdh); spush<FCC,false>(L.ch(),nch,c); }
-			while ( nch ) { ldput(L.acc()+nacc,ldget(L.ch())); ++nacc; spop<FCC,false>(L.ch(),nch); }
+			uint32_t tie = 0;
+			for ( uint32_t c = lane; c < nkept; c += WSZ )
+			{
+				FCC const e = ldget(L.cdh()+c);
+				uint32_t rank = 0;
+				for ( uint32_t j = 0; j < nkept; ++j ) { uint64_t const wj = L.cdh()[j].w; rank += (wj > e.w) ? 1u : 0u; tie |= (wj == e.w && j != c) ? 1u : 0u; }
+				ldput(L.acc()+rank,e);
+			}
+			tie = wv_any(tie);
+			FSTAT_ADD(21,tie ? 1u : 0u); FSTAT_ADD(22,nkept ? 1u : 0u);
+			wv_sync();
+			if ( lane == 0 )
+			{
+				if ( tie )
+				{
+					uint32_t nch = 0;
+					while ( ncdh ) { FCC const c = ldget(L.cdh()); spop<FCC,true>(L.cdh(),ncdh); spush<FCC,false>(L.ch(),nch,c); }
+					while ( nch ) { ldput(L.acc()+nacc,ldget(L.ch())); ++nacc; spop<FCC,false>(L.ch(),nch); }
+				}
+				else { nacc = nkept; ncdh = 0; }
+			}
 		}
 		wv_sync();
 		uint32_t const nc = wv_bcast(nacc,0);
@@ -2400,23 +2422,22 @@ struct FastEngine
 			L.accerr()[c] = s;
 		}
 		wv_sync();
-		if ( lane == 0 )
+		// std::sort of at most 16 candidates by error (:5156) = insertion sort = a stable sort: candidate c goes to the
+		// number of candidates with a smaller error or the same error and a smaller index (through CH, which is free now;
+		// the error sums travel in the bytes of canderr, which have been summed up)
 		{
-			for ( uint32_t i = 1; i < nc; ++i )
+			LDSQ uint32_t * const serr = reinterpret_cast<LDSQ uint32_t *>(L.canderr());
+			static_assert(16*CT::maxs >= 64 && (FastLds<CT>::o_canderr & 3) == 0,"sorted error sums borrow the candidate error bytes");
+			for ( uint32_t c = lane; c < nc; c += WSZ )
 			{
-				FCC const v = ldget(L.acc()+i); uint32_t const e = L.accerr()[i];
-				if ( e < L.accerr()[0] )
-				{
-					for ( uint32_t q = i; q > 0; --q ) { ldput(L.acc()+q,ldget(L.acc()+q-1)); L.accerr()[q] = L.accerr()[q-1]; }
-					ldput(L.acc(),v); L.accerr()[0] = e;
-				}
-				else
-				{
-					uint32_t q = i;
-					while ( e < L.accerr()[q-1] ) { ldput(L.acc()+q,ldget(L.acc()+q-1)); L.accerr()[q] = L.accerr()[q-1]; --q; }
-					ldput(L.acc()+q,v); L.accerr()[q] = e;
-				}
+				uint32_t const e = L.accerr()[c];
+				uint32_t rank = 0;
+				for ( uint32_t j = 0; j < nc; ++j ) { uint32_t const ej = L.accerr()[j]; rank += (ej < e || (ej == e && j < c)) ? 1u : 0u; }
+				ldput(L.ch()+rank,ldget(L.acc()+c));
+				serr[rank] = e;
 			}
+			wv_sync();
+			for ( uint32_t c = lane; c < nc; c += WSZ ) { ldput(L.acc()+c,ldget(L.ch()+c)); L.accerr()[c] = serr[c]; }
 		}
 		wv_sync();
 		PROF(*this,13)
