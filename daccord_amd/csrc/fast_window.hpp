@@ -2529,61 +2529,104 @@ struct FastEngine
 		return maxvprodindex;
 	}
 
-	DEV void alignAndEmit(LDSQ uint8_t const * cons, uint32_t const n, uint8_t * rec)
+	// lane 0: alignment of the consensus to the A window; returns the number of steps of the edit script left in alops.
+	// cons is 8 byte aligned and readable up to the next multiple of 8 behind n (bestL).  The pattern masks of the A window
+	// and the consensus (2 bits per symbol) stay in registers: the forward pass only stores its columns, the traceback
+	// loads a column when it moves to it (A[i-1] == cons[j-1] <=> bit i-1 of the pattern mask of cons[j-1]).
+	DEV uint32_t alignAndEmit(LDSQ uint8_t const * cons, uint32_t const n)
 	{
 		uint32_t const m = P.w;
-		LDSQ uint8_t const * a = L.str();
 		LDSQ uint64_t const * PEQ = L.peq();
+		uint64_t const e0 = PEQ[0], e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
+		LDSQ uint64_t const * T8 = reinterpret_cast<LDSQ uint64_t const *>(cons);
+		static_assert(MAXCONS <= 96 && (FastLds<CT>::o_bestL & 7) == 0,"consensus packed into three 64 bit words");
 		uint64_t const mask = (m == 64) ? ~0ull : ((1ull<<m)-1);
 		uint64_t Pv = mask, Mv = 0; uint32_t score = m;
 		L.alpv()[0] = Pv; L.almv()[0] = Mv; L.albot()[0] = m;
 		uint64_t const top = 1ull<<(m-1);
-		for ( uint32_t c = 0; c < n; ++c )
+		uint64_t ck0 = 0, ck1 = 0, ck2 = 0;      // consensus symbols 0-31, 32-63, 64-95
+		uint64_t w = n ? T8[0] : 0ull;
+		for ( uint32_t c0 = 0; c0 < n; c0 += 8 )
 		{
-			uint64_t const Eq = PEQ[cons[c]];
-			uint64_t const Xv = Eq | Mv;
-			uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-			uint64_t Ph = Mv | ~(Xh | Pv);
-			uint64_t Mh = Pv & Xh;
-			if ( Ph & top ) ++score; else if ( Mh & top ) --score;
-			Ph = (Ph<<1) | 1ull; Mh <<= 1;
-			Pv = (Mh | ~(Xv | Ph)) & mask;
-			Mv = (Ph & Xv) & mask;
-			L.alpv()[c+1] = Pv; L.almv()[c+1] = Mv; L.albot()[c+1] = score;
+			uint64_t const wn = (c0+8 < n) ? T8[(c0>>3)+1] : 0ull;
+			uint32_t const cnt = (n-c0 < 8) ? (n-c0) : 8u;
+			for ( uint32_t u = 0; u < cnt; ++u )
+			{
+				uint32_t const c = c0+u;
+				uint64_t const ch = (w >> (8*u)) & 3u;
+				uint64_t const cs = ch << (2*(c&31));
+				ck0 |= c < 32 ? cs : 0ull; ck1 |= (c >= 32 && c < 64) ? cs : 0ull; ck2 |= c >= 64 ? cs : 0ull;
+				uint64_t const Eq = (ch & 2) ? ((ch & 1) ? e3 : e2) : ((ch & 1) ? e1 : e0);
+				uint64_t const Xv = Eq | Mv;
+				uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+				uint64_t Ph = Mv | ~(Xh | Pv);
+				uint64_t Mh = Pv & Xh;
+				if ( Ph & top ) ++score; else if ( Mh & top ) --score;
+				Ph = (Ph<<1) | 1ull; Mh <<= 1;
+				Pv = (Mh | ~(Xv | Ph)) & mask;
+				Mv = (Ph & Xv) & mask;
+				L.alpv()[c+1] = Pv; L.almv()[c+1] = Mv; L.albot()[c+1] = score;
+			}
+			w = wn;
 		}
 		uint32_t i = m, j = n; uint32_t d = score; uint32_t nops = 0;
+		// column j (its Pv) and column j-1 (Pv, Mv, bottom score) in registers
+		uint64_t pvj = Pv, pv1 = 0, mv1 = 0; uint32_t bot1 = 0;
+		if ( j ) { pv1 = L.alpv()[j-1]; mv1 = L.almv()[j-1]; bot1 = L.albot()[j-1]; }
 		while ( i || j )
 		{
-			uint32_t op = 2; bool done = false;
+			uint32_t op = 2; bool done = false; bool left = false;
 			if ( i && j )
 			{
 				uint64_t const sh = i-1;
-				uint32_t const dd = L.albot()[j-1] - dacc_popc64(L.alpv()[j-1]>>sh) + dacc_popc64(L.almv()[j-1]>>sh);
-				uint32_t const neq = (a[i-1] != cons[j-1]);
-				if ( dd + neq == d ) { op = neq ? 1 : 0; --i; --j; d = dd; done = true; }
+				uint32_t const dd = bot1 - dacc_popc64(pv1>>sh) + dacc_popc64(mv1>>sh);
+				uint32_t const jj = j-1;
+				uint64_t const ckw = jj < 32 ? ck0 : (jj < 64 ? ck1 : ck2);
+				uint32_t const ch = static_cast<uint32_t>(ckw >> (2*(jj&31))) & 3u;
+				uint64_t const Eq = (ch & 2) ? ((ch & 1) ? e3 : e2) : ((ch & 1) ? e1 : e0);
+				uint32_t const neq = ((Eq >> sh) & 1) ? 0u : 1u;
+				if ( dd + neq == d ) { op = neq ? 1 : 0; --i; --j; d = dd; done = true; left = true; }
 			}
 			if ( !done && i )
 			{
 				uint64_t const bit = 1ull<<(i-1);
-				if ( L.alpv()[j] & bit ) { op = 3; --i; d = d-1; done = true; }
+				if ( pvj & bit ) { op = 3; --i; d = d-1; done = true; }
 			}
-			if ( !done ) { op = 2; --j; d = d-1; }
+			if ( !done ) { op = 2; --j; d = d-1; left = true; }
+			if ( left )
+			{
+				pvj = pv1;
+				if ( j ) { pv1 = L.alpv()[j-1]; mv1 = L.almv()[j-1]; bot1 = L.albot()[j-1]; }
+			}
 			L.alops()[nops++] = op;
 		}
+		return nops;
+	}
+	// window record from the edit script alops[0..nops) (traceback order: last step first), all lanes.  Every step emits
+	// exactly one symbol (INS / MATCH / MISMATCH: the next consensus symbol, DEL: 'D' = 4), so symbol q belongs to step q
+	// in forward order; off[r] = number of symbols before the group of A column r = index behind the (r-1)-th step that
+	// consumes an A symbol (HandleContext.hpp:2448-2489)
+	DEV void emitRecord(LDSQ uint8_t const * cons, uint32_t const nops, uint8_t * rec)
+	{
+		uint32_t const m = P.w;
 		uint8_t * off = rec+1; uint8_t * sym = rec + 1 + (m+2);
-		rec[0] = 1;
-		uint32_t so = 0, cpos = 0, t = nops;
-		for ( uint32_t r = 0; r <= m; ++r )
+		if ( lane == 0 ) { rec[0] = 1; off[0] = 0; off[m+1] = nops; }
+		uint32_t cbase = 0, abase = 0;
+		for ( uint32_t c0 = 0; c0 < nops; c0 += WSZ )
 		{
-			off[r] = so;
-			while ( t && L.alops()[t-1] == 2 ) { sym[so++] = cons[cpos++]; --t; }
-			if ( r < m )
+			uint32_t const q = c0 + lane;
+			bool const act = q < nops;
+			uint32_t const op = act ? L.alops()[nops-1-q] : 2u;
+			uint32_t ctot, atot;
+			uint32_t const cpos = cbase + wv_scan_flag(act && op != 3,ctot);
+			uint32_t const arank = abase + wv_scan_flag(act && op != 2,atot);
+			if ( act )
 			{
-				uint32_t const op = L.alops()[--t];
-				sym[so++] = (op == 3) ? 4 : cons[cpos++];
+				sym[q] = (op == 3) ? 4 : cons[cpos];
+				if ( op != 2 ) off[arank+1] = q+1;
 			}
+			cbase += ctot; abase += atot;
 		}
-		off[m+1] = so;
 	}
 };
 
@@ -2792,7 +2835,11 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 		{
 			out.status = WS_OK; out.conslen = bestlen; out.minrate = minrate;
 			PROF_T0
-			if ( lane == 0 ) E.alignAndEmit(best,bestlen,rec);
+			uint32_t nops = 0;
+			if ( lane == 0 ) nops = E.alignAndEmit(best,bestlen);
+			wv_sync();
+			nops = wv_bcast(nops,0);
+			E.emitRecord(best,nops,rec);
 			PROF(E,14)
 		}
 		else out.status = WS_FAILED;
