@@ -1291,42 +1291,32 @@ struct FastEngine
 	}
 	// ---- heaps (same sift algorithm as oracle/o_heap.hpp) ----
 	template<bool MINHEAP> DEV static bool hless(uint64_t a, uint64_t b) { return MINHEAP ? (a < b) : (a > b); }
-	// the id that moves and its weight stay in registers (same comparisons and final arrangement as swapping level by level)
+	// (id heaps: a version that keeps the moving id and its weight in registers measured 7 % slower in the forward trees --
+	// the re-read of W[H[i]] is in flight together with the children's weights, it costs no round trip)
 	template<bool MINHEAP>
 	DEV void ipush(LDSQ id_t * H, uint32_t & f, id_t const id, LDSQ uint64_t const * W)
 	{
-		uint32_t i = f++;
-		uint64_t const w = W[id];
+		uint32_t i = f++; H[i] = id;
 		while ( i )
 		{
 			uint32_t const p = (i-1)>>1;
-			id_t const hp = H[p];
-			if ( hless<MINHEAP>(w,W[hp]) ) { H[i] = hp; i = p; }
+			if ( hless<MINHEAP>(W[H[i]],W[H[p]]) ) { id_t const t = H[i]; H[i] = H[p]; H[p] = t; i = p; }
 			else break;
 		}
-		H[i] = id;
 	}
 	template<bool MINHEAP>
 	DEV void ipop(LDSQ id_t * H, uint32_t & f, LDSQ uint64_t const * W)
 	{
-		id_t const id = H[--f];
-		uint64_t const w = W[id];
+		H[0] = H[--f];
 		uint32_t i = 0, r;
 		while ( (r = 2*i+2) < f )
 		{
-			id_t const ha = H[r-1], hb = H[r];
-			uint64_t const wa = W[ha], wb = W[hb];
-			bool const pa = hless<MINHEAP>(wa,wb);
-			if ( hless<MINHEAP>(w,pa ? wa : wb) ) { H[i] = id; return; }
-			if ( pa ) { H[i] = ha; i = r-1; } else { H[i] = hb; i = r; }
+			uint32_t const m = hless<MINHEAP>(W[H[r-1]],W[H[r]]) ? (r-1) : r;
+			if ( hless<MINHEAP>(W[H[i]],W[H[m]]) ) return;
+			id_t const t = H[i]; H[i] = H[m]; H[m] = t; i = m;
 		}
 		uint32_t const l = 2*i+1;
-		if ( l < f )
-		{
-			id_t const hl = H[l];
-			if ( !hless<MINHEAP>(w,W[hl]) ) { H[i] = hl; i = l; }
-		}
-		H[i] = id;
+		if ( l < f && !hless<MINHEAP>(W[H[i]],W[H[l]]) ) { id_t const t = H[i]; H[i] = H[l]; H[l] = t; }
 	}
 	// The record that moves stays in registers and the records it passes are shifted (same comparisons and the same final
 	// arrangement as swapping level by level): one LDS round trip per level.
@@ -1906,17 +1896,16 @@ struct FastEngine
 			{
 				if ( n >= PSIQ || sup > 255 && sizeof(id_t) == 1 ) return 0xFF;
 				PSI e; e.path = pi; e.current = mi; e.left = sub; e.right = sup;
-				// FiniteSizeHeap push (max heap on the weight); the entry that moves stays in registers
-				uint32_t i = n++;
+				// FiniteSizeHeap push (max heap on the weight)
+				uint32_t i = n++; H[i] = e;
 				uint64_t const we = psiW(e,FC,sbase);
 				while ( i )
 				{
 					uint32_t const p = (i-1)>>1;
 					PSI const ep = H[p];
-					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; i = p; }
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
 					else break;
 				}
-				H[i] = e;
 			}
 		}
 		uint32_t cnt = 0;
@@ -1928,41 +1917,35 @@ struct FastEngine
 			if ( prune && psiW(top,FC,sbase) <= T0 ) return cnt | 0x20;
 			// pop
 			{
-				// the last entry sifts down from the root: its weight is evaluated once, the children's once per level
-				--n; PSI const last = H[n];
-				uint64_t const wl = psiW(last,FC,sbase);
+				--n; PSI const last = H[n]; H[0] = last;
 				uint32_t i = 0, r;
 				while ( (r = 2*i+2) < n )
 				{
-					PSI const ea = H[r-1], eb = H[r];
-					uint64_t const wa = psiW(ea,FC,sbase), wb = psiW(eb,FC,sbase);
-					bool const pa = wa > wb;
-					if ( wl > (pa ? wa : wb) ) break;
-					if ( pa ) { H[i] = ea; i = r-1; } else { H[i] = eb; i = r; }
+					uint32_t const m = psiW(H[r-1],FC,sbase) > psiW(H[r],FC,sbase) ? (r-1) : r;
+					PSI const em = H[m], ei = H[i];
+					if ( psiW(ei,FC,sbase) > psiW(em,FC,sbase) ) break;
+					H[i] = em; H[m] = ei; i = m;
 				}
 				if ( r >= n )
 				{
 					uint32_t const l = 2*i+1;
-					if ( l < n ) { PSI const el = H[l]; if ( !(wl > psiW(el,FC,sbase)) ) { H[i] = el; i = l; } }
+					if ( l < n ) { PSI const el = H[l], ei = H[i]; if ( !(psiW(ei,FC,sbase) > psiW(el,FC,sbase)) ) { H[i] = el; H[l] = ei; } }
 				}
-				H[i] = last;
 			}
 			uint32_t bi;
 			if ( scoreNext(sbase,top.left,top.right,top.current,bi) )
 			{
 				PSI e = top; e.current = bi;
-				uint32_t i = n++;
+				uint32_t i = n++; H[i] = e;
 				uint64_t const we = psiW(e,FC,sbase);
 				while ( i )
 				{
 					uint32_t const p = (i-1)>>1;
 					PSI const ep = H[p];
-					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; i = p; }
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
 					else break;
 				}
-				H[i] = e;
 			}
-			// recorded resolved: pool slot of the popped forward path and pool id of the reverse path (both fit id_t)
 			out[2*cnt] = static_cast<id_t>(clSlot<FCH>(FC,top.path)); out[2*cnt+1] = L.rc_ord()[sbase+top.current]; ++cnt;
 		}
 		return cnt;

@@ -52,7 +52,7 @@ typedef struct dacc_params {
 	uint64_t eminrate;       /* -e max window error       (default UINT64_MAX) */
 	uint64_t minlen;         /* -l min output length      (default 0) */
 	int32_t  producefull;    /* -f                        (default 0) */
-	int32_t  tspace;         /* trace point spacing of the .las (AlignmentFile::getTSpace, daccord.cpp:1375) */
+	int32_t  tspace;         /* trace point spacing of the .las (AlignmentFile::getTSpace, daccord.cpp:1375), 1..512 */
 	int32_t  device;         /* HIP device ordinal */
 	int32_t  verbose;
 } dacc_params;
