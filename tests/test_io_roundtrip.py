@@ -72,6 +72,27 @@ def test_las_roundtrip_and_layout(tmp_path):
     assert set(sub_p["aread"].tolist()) <= {5, 6, 7, 8} and np.all((sub_o["aread"] >= 5) & (sub_o["aread"] < 9))
 
 
+def test_las_roundtrip_two_byte_trace_values(tmp_path):
+    """tspace > 125: two bytes per trace value in the file (TRACE_XOVR of DALIGNER's align.h), little endian."""
+    from daccord_amd.synth import SynthData
+    d = SynthData(40000, 80, 4000, seed=9, tspace=300)
+    assert d.trace.dtype == np.uint16 and d.trace_bytes == 2 and len(d.ovl) > 50
+    p = str(tmp_path / "ovl300.las")
+    dio.write_las(p, 300, d.ovl, d.trace[:d.ntrace])
+    raw = open(p, "rb").read()
+    o0 = d.ovl[0]
+    tlen = int(o0["tlen"])
+    assert raw[12 + 40:12 + 40 + 2 * tlen] == d.trace[int(o0["trace_off"]):int(o0["trace_off"]) + tlen].astype("<u2").tobytes()
+    las = dio.LasFile(p)
+    assert (las.novl, las.tspace, las.trace_bytes) == (len(d.ovl), 300, 2)
+    piles, ovl, trace = las.piles()
+    assert trace.dtype == np.uint16 and (trace > 255).any()
+    for i in (0, len(ovl) // 2, len(ovl) - 1):
+        a = trace[int(ovl[i]["trace_off"]):int(ovl[i]["trace_off"]) + int(ovl[i]["tlen"])]
+        b = d.trace[int(d.ovl[i]["trace_off"]):int(d.ovl[i]["trace_off"]) + int(d.ovl[i]["tlen"])]
+        assert np.array_equal(a, b)
+
+
 def test_las_rejects_garbage(tmp_path):
     p = str(tmp_path / "bad.las")
     open(p, "wb").write(b"\x05\x00\x00\x00\x00\x00\x00\x00\x64\x00\x00\x00" + b"\x00" * 17)
