@@ -1,6 +1,6 @@
 """Randomized parity runs: kernel logic (1-lane emulation, tests/emul) vs the CPU oracle over random run parameters
 (w, a, k ranges, filter frequencies, -d, -m, -f, -l, -e), error profiles and coverages.
-usage: python scripts/fuzz_emul_vs_oracle.py <seed> <rounds>      (found the -f / empty pile and the scratch overflow bugs)"""
+usage: python scripts/fuzz_emul_vs_oracle.py <seed> <rounds> [--wide] [--lanes64]      (found the -f / empty pile and the scratch overflow bugs)"""
 import sys, os, time, random, collections
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,21 +8,21 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 from daccord_amd.synth import SynthData
 from daccord_amd._structs import default_params
 import pyoracle, emul_lib
-seed0=int(sys.argv[1]); nrounds=int(sys.argv[2])
+seed0=int(sys.argv[1]); nrounds=int(sys.argv[2]); wide = '--wide' in sys.argv; lanes = 64 if '--lanes64' in sys.argv else 1
 rng=random.Random(seed0)
 bad=0
-from common import random_run_config
+from common import random_run_config, random_run_config_wide
 for r in range(nrounds):
-    kw, data, maxin, nplc = random_run_config(rng)
+    kw, data, maxin, nplc = (random_run_config_wide if wide else random_run_config)(rng)
     try:
         d=SynthData(data['genome_len'],data['nreads'],data['read_len'],**{k:v for k,v in data.items() if k not in ('genome_len','nreads','read_len')})
         ovl,piles=pyoracle.pile_select(d.ovl,d.piles,maxinput=maxin)
         npl=min(len(piles),nplc)
         p=default_params(**kw)
         O=pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps,d.boff,d.rlen)
-        E=emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps,d.boff,d.rlen)
-        fo,bo=O.run(piles[:npl],ovl,d.trace,want_windows=True,nthreads=1); wo=O.windows()
-        fe,be=E.run(piles[:npl],ovl,d.trace); we=E.windows()
+        E=emul_lib.Emul(p,lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps,d.boff,d.rlen)
+        fo,bo=O.run(piles[:npl],ovl,d.trace,trace_bytes=d.trace_bytes,want_windows=True,nthreads=4); wo=O.windows()
+        fe,be=E.run(piles[:npl],ovl,d.trace,trace_bytes=d.trace_bytes); we=E.windows()
         nb=0
         for x,y in zip(wo,we):
             same = x['status']==y['status'] and x['mao']==y['mao'] and x['elength']==y['elength'] and (x['status']!=1 or (bytes(x['cons'])==bytes(y['cons']) and x['minrate']==y['minrate'] and x['filterfreq']==y['filterfreq'] and x['k']==y['k']))

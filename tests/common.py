@@ -67,3 +67,24 @@ def random_run_config(rng):
     data = dict(genome_len=glen, nreads=nreads, read_len=rlen, erate=erate, seed=seed, ins_frac=mix[0], del_frac=mix[1], sub_frac=mix[2],
                 tspace=tspace, min_overlap=minovl)
     return kw, data, rng.choice([5000, 5000, 10]), rng.choice([2, 3, 4])
+
+
+def random_run_config_wide(rng):
+    """random_run_config plus what the second half of round 2 added: deep piles (coverage up to 60x: deep tier, tier 2/3
+    with 2048 / 4096 k-mer instances, many first / last k-mer candidates) and trace spacings beyond 125 / 128 (two byte
+    trace values, k_trace_wide).  Used by the CPU fuzzing (scripts/fuzz_emul_vs_oracle.py --wide)."""
+    kw, data, maxin, npl = random_run_config(rng)
+    r = rng.random()
+    if r < 0.4:
+        # deep: short genome, many reads; larger k and the default window (the oracle enumerates every (first, last)
+        # pair from scratch: dense graphs of deep piles at small k take it minutes per pile)
+        data["read_len"] = 2000; data["nreads"] = rng.choice([300, 400, 600])
+        data["genome_len"] = int(data["nreads"] * data["read_len"] / rng.choice([35, 45, 60]))
+        data["erate"] = rng.choice([0.12, 0.15, 0.15])
+        kw["w"] = 40; kw["a"] = rng.choice([10, 20]); kw["klow"] = rng.choice([12, 14, 14]); kw["khigh"] = kw["klow"]
+        kw.pop("minfilterfreq", None); kw.pop("maxfilterfreq", None)
+        npl = 1
+    if rng.random() < 0.4:
+        ts = rng.choice([126, 128, 150, 200, 256, 300])
+        kw["tspace"] = ts; data["tspace"] = ts
+    return kw, data, maxin, npl
