@@ -754,7 +754,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		for ( int t = 0; t < 3; ++t )
 		{
 			FastCaps const & F = BP.ftier[t];
-			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= F.tabcap) && F.ldsbytes <= 160*1024;
+			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= F.tabcap) && F.ldsbytes <= 160*1024;
 			if ( !((c->env_tiers>>t)&1) ) c->tier_ok[t] = 0;
 			uint64_t percu = (160*1024) / (F.ldsbytes ? F.ldsbytes : 1);
 			if ( percu > 8 ) percu = 8;

@@ -460,7 +460,11 @@ struct FastEngine
 		for ( uint32_t i = lane; i < npre; i += WSZ )
 		{
 			uint32_t const pos = (L.pre()[i]>>16)&0xFFFF, seq = L.pre()[i]&0xFFFF;
-			L.ipos()[i] = pos; L.irpos()[i] = L.slen()[seq]-pos-k;
+			// positions behind the support of the model table (a string much longer than the error profile makes likely)
+			// carry no weight (`pos < first+size`, getKmerPositionWeight :3826-3864): they are stored as nsup, the all-zero
+			// row behind the table copy, and count as "beyond the support" in the range lookups below
+			uint32_t const rpos = L.slen()[seq]-pos-k;
+			L.ipos()[i] = pos < nsup ? pos : nsup; L.irpos()[i] = rpos < nsup ? rpos : nsup;
 		}
 		wv_sync();
 		if ( lane == 0 ) L.nps()[nn] = npre;
@@ -912,22 +916,22 @@ struct FastEngine
 	}
 
 	// copy of the model table in LDS, row stride nrows+1: the extra row is zero so that positions beyond the table can be
-	// clamped instead of branched on
+	// clamped instead of branched on; one more all-zero position (nsup) for read positions behind the support
 	DEV void loadTab()
 	{
 		uint32_t const stride = nrows+1;
 		uint32_t pos = static_cast<uint32_t>(lane) / stride, row = static_cast<uint32_t>(lane) - pos*stride;     // the one division of the copy
 		uint32_t const dpos = WSZ / stride, drow = WSZ - dpos*stride;
-		for ( uint32_t i = lane; i < stride*nsup; i += WSZ )
+		for ( uint32_t i = lane; i < stride*(nsup+1); i += WSZ )
 		{
-			L.tab()[i] = row < nrows ? static_cast<uint32_t>(vst[pos*nrows+row]) : 0u;
+			L.tab()[i] = (row < nrows && pos < nsup) ? static_cast<uint32_t>(vst[pos*nrows+row]) : 0u;
 			pos += dpos; row += drow; if ( row >= stride ) { row -= stride; ++pos; }
 		}
 		wv_sync();
 	}
 	template<bool GT> DEV uint32_t tabAt(uint32_t const pos, uint32_t const pc, uint32_t const stride) const
 	{
-		if ( GT ) return pc < nrows ? static_cast<uint32_t>(vst[pos*nrows+pc]) : 0u;
+		if ( GT ) return (pc < nrows && pos < nsup) ? static_cast<uint32_t>(vst[pos*nrows+pc]) : 0u;
 		else return L.tab()[pos*stride+pc];
 	}
 	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions; GT: read the table from HBM

@@ -155,7 +155,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		{
 			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].retry = 0; FB[t].gearly = 0;
 			lds[t].resize(BP.ftier[t].ldsbytes+64);
-			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*c->H.nsup <= BP.ftier[t].tabcap;
+			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftier[t].tabcap;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
 		c->nretry = 0; c->glist.clear();

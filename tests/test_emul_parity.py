@@ -159,3 +159,23 @@ def test_wide_trace_spacing(tspace):
     assert len(bo) > 3000
     assert windows_equal(O.windows(), E.windows()) == []
     assert frags_equal(fo, bo, fe, be)
+
+
+def test_read_positions_behind_the_table_support(monkeypatch):
+    """An error profile much narrower than the data (estimated on clean reads, applied to noisy ones): strings longer than
+    the support of the model table put k-mer instances at positions the table has no row for.  They carry no weight
+    (getKmerPositionWeight, DebruijnGraph.hpp:3826-3864: `pos < first + size`); the LDS engine used to read whatever lay
+    behind its table copy for them.  With a poisoned LDS image the windows must still equal the oracle's."""
+    monkeypatch.setenv("DACC_EMUL_POISON", "171")
+    d = SynthData(60000, 200, 4000, erate=0.30, seed=32, ins_frac=0.9, del_frac=0.05, sub_frac=0.05)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    prof = (0.01, 0.002, 0.98)
+    p = default_params(k=8)
+    O = pyoracle.Oracle(p); O.set_error_profile(*prof); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p); E.set_error_profile(*prof); E.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[0:2], ovl, d.trace, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[0:2], ovl, d.trace)
+    wo = O.windows()
+    assert (wo["status"] == 1).sum() > 500
+    assert windows_equal(wo, E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)
