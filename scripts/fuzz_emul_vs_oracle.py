@@ -15,12 +15,13 @@ from common import random_run_config, random_run_config_wide
 for r in range(nrounds):
     kw, data, maxin, nplc = (random_run_config_wide if wide else random_run_config)(rng)
     try:
-        d=SynthData(data['genome_len'],data['nreads'],data['read_len'],**{k:v for k,v in data.items() if k not in ('genome_len','nreads','read_len')})
+        d=SynthData(data['genome_len'],data['nreads'],data['read_len'],**{k:v for k,v in data.items() if k not in ('genome_len','nreads','read_len','profile')})
+        prof=data.get('profile') or d.error_profile()
         ovl,piles=pyoracle.pile_select(d.ovl,d.piles,maxinput=maxin)
         npl=min(len(piles),nplc)
         p=default_params(**kw)
-        O=pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps,d.boff,d.rlen)
-        E=emul_lib.Emul(p,lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps,d.boff,d.rlen)
+        O=pyoracle.Oracle(p); O.set_error_profile(*prof); O.load_db(d.bps,d.boff,d.rlen)
+        E=emul_lib.Emul(p,lanes=lanes); E.set_error_profile(*prof); E.load_db(d.bps,d.boff,d.rlen)
         fo,bo=O.run(piles[:npl],ovl,d.trace,trace_bytes=d.trace_bytes,want_windows=True,nthreads=4); wo=O.windows()
         fe,be=E.run(piles[:npl],ovl,d.trace,trace_bytes=d.trace_bytes); we=E.windows()
         nb=0

@@ -87,4 +87,7 @@ def random_run_config_wide(rng):
     if rng.random() < 0.4:
         ts = rng.choice([126, 128, 150, 200, 256, 300])
         kw["tspace"] = ts; data["tspace"] = ts
+    if rng.random() < 0.25:
+        # an error profile that is not the data's (an estimate from other reads): narrow or wide model tables
+        data["profile"] = rng.choice([(0.01, 0.002, 0.98), (0.03, 0.01, 0.95), (0.2, 0.05, 0.7), (0.05, 0.05, 0.85)])
     return kw, data, maxin, npl
