@@ -52,6 +52,7 @@ struct BatchPlan
 	ArenaCaps caps;
 	enum { NTIER = 3 };
 	FastCaps ftier[NTIER];    // LDS fast path capacity tiers: 3, 2, 1 wavefronts per CU
+	FastCaps ftierL;          // tier 5: windows with a string of 65..128 bases (second stream, before the generic engine)
 	uint64_t ndeepwin;        // windows with more strings / k-mer instances than the first tier of shallow batches holds
 	bool deep;                // most windows are deep: the first tier is FastTier<4> (many strings, small graph) instead of FastTier<1>
 
@@ -181,6 +182,7 @@ struct BatchPlan
 		deep = 2*ndeepwin > nwindows;
 		ftier[0] = deep ? fastCapsOf< FastTier<4> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
 		ftier[1] = fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup);
+		ftierL = fastCapsOf< FastTier<5> >(tab_nrows,tab_nsup);
 		ftier[2] = fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;
 	}

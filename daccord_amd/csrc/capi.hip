@@ -115,6 +115,36 @@ __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag
 	}
 }
 
+// Second stream: the windows the pre-scan (a B string of more than 64 bases) or the first tier (no LDS tier can run the
+// shape) set aside.  One wavefront per workgroup tries tier 5 (FastTier<5>: strings of up to 128 bases, LDS of a whole CU)
+// and runs the generic engine right here for what tier 5 cannot hold.  FB.F.ldsbytes == 0: tier 5 is not usable with this
+// model table (then this is the generic engine alone).  Static striding over the list, like the generic launch it replaces.
+__global__ void __launch_bounds__(64) k_window_long(FastBatch FB, uint32_t * errflag, uint32_t const * list)
+{
+	typedef FastTier<5> CT;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
+	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
+	bool const tier = FB.F.ldsbytes != 0;
+	if ( tier ) { FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
+	uint8_t * arena = FB.W.arena + static_cast<uint64_t>(blockIdx.x)*FB.W.C.bytes;
+	uint64_t const n = list[0];
+	for ( uint32_t it = 0; ; ++it )
+	{
+		uint64_t const i = static_cast<uint64_t>(it)*gridDim.x + blockIdx.x;
+		if ( i >= n ) break;
+		uint64_t const w = list[1+i];
+		int rc = FW_NEXT;
+		if ( tier ) rc = processWindowFast<CT>(FB,w,lds,false);
+		__syncthreads();
+		if ( rc != FW_DONE )
+		{
+			processWindow(FB.W,w,arena);
+			if ( threadIdx.x == 0 && FB.W.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
+		}
+		__syncthreads();
+	}
+}
+
 // safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
 // Before the LDS tiers: windows with a B string of more than 64 bases can only run in the generic engine, where one of
 // them costs as much as a few hundred thousand ordinary windows in the LDS path.  One wavefront per overlap scans its rows
@@ -367,7 +397,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
 	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2;
-	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int usefast; int sched; uint32_t tier_out[3];
+	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
 	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
@@ -535,10 +565,9 @@ static int runDevice(dacc_ctx * c)
 				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
 			HIPCHK(hipEventRecord(c->evPrescan,s));
 			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
-			{
-				WindowBatch WE = WB; WE.arena = c->d_arena2.p; WE.prof = 0;
-				hipLaunchKernelGGL(k_window,dim3(c->early_grid),dim3(64),0,c->stream2,WE,c->d_err.p,static_cast<uint32_t const *>(c->d_pregenlist.p),static_cast<uint32_t *>(0));
-			}
+			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0;
+			if ( !c->tierL_ok ) FL.F.ldsbytes = 0;
+			hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,static_cast<uint32_t const *>(c->d_pregenlist.p));
 			WB.pregen = c->d_pregen.p;
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
@@ -568,8 +597,7 @@ static int runDevice(dacc_ctx * c)
 						early = true;
 						HIPCHK(hipEventRecord(c->evFirstTier,s));
 						HIPCHK(hipStreamWaitEvent(c->stream2,c->evFirstTier,0));
-						WindowBatch WE = WB; WE.arena = c->d_arena2.p; WE.prof = 0;
-						hipLaunchKernelGGL(k_window,dim3(c->early_grid),dim3(64),0,c->stream2,WE,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p),static_cast<uint32_t *>(0));
+						hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p));
 						HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
 					}
 				}
@@ -766,6 +794,8 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			HIPCHK(c->d_retry[t].ensure(BP.nwindows+2));
 		}
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
+		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);
+		if ( c->tierL_ok && BP.ftierL.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_long),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftierL.ldsbytes));
 		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
 		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = wg < 512 ? wg : 512;

@@ -66,16 +66,21 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = 992, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = 992, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
 // small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
 // has about a hundred nodes, while the 55 strings of a window carry 1500 k-mer instances.
-template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+
+// tier 5 (one wavefront per CU, only for the windows the pre-scan found): B strings of up to 128 bases (string stride 128,
+// two words per pattern mask); everything else as tier 3 with 64 strings.  Window strings of more than 64 bases are rare
+// at the default window (about ten per million windows of config 2) but each of them costs the generic engine seconds.
+template<> struct FastTier<5> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -99,9 +104,11 @@ struct FastLds
 	static_assert(sizeof(typename CT::id_t) > 1 || (CT::fcap <= 256 && CT::rccap <= 256),"pool slots are recorded as id_t (pout)");
 	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
 	// ---- live during the whole window ----
-	FLD(str,uint8_t,CT::maxs*64,0)
+	static_assert(CT::lstr == 64 || CT::lstr == 128,"string stride: one or two 64 bit words per pattern mask");
+	static constexpr uint32_t pw = CT::lstr/64;      // words per pattern mask
+	FLD(str,uint8_t,CT::maxs*CT::lstr,0)
 	FLD(slen,uint8_t,CT::maxs,e_str)
-	FLD(peq,uint64_t,CT::maxs*4,e_slen)
+	FLD(peq,uint64_t,CT::maxs*4*pw,e_slen)      // pattern masks of string j: words 4*pw*j + pw*symbol + word
 	FLD(ipos,uint8_t,CT::precap,e_peq)
 	FLD(irpos,uint8_t,CT::precap,e_ipos)
 	FLD(nv,uint32_t,CT::ncap,e_irpos)
@@ -416,7 +423,7 @@ struct FastEngine
 			if ( t < npre )
 			{
 				uint32_t const i = t - oj;
-				LDSQ uint8_t const * sp = L.str() + j*64 + i;
+				LDSQ uint8_t const * sp = L.str() + j*CT::lstr + i;
 				uint32_t v = 0;
 				#pragma unroll
 				for ( uint32_t q = 0; q < 16; ++q ) { uint32_t const c = sp[q]; v = q < k ? ((v<<2) | c) : v; }
@@ -1977,6 +1984,7 @@ struct FastEngine
 	{
 		uint32_t const m = L.slen()[j];
 		if ( m == 0 ) return n;
+		if ( FastLds<CT>::pw == 2 ) return myersDistance2(j,text,n,m);
 		LDSQ uint64_t const * PEQ = L.peq() + 4*j;
 		uint64_t const e0 = PEQ[0], e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
 		LDSQ uint64_t const * T8 = reinterpret_cast<LDSQ uint64_t const *>(text);
@@ -2005,19 +2013,72 @@ struct FastEngine
 		}
 		return score;
 	}
+	// the same for strings of up to 128 bases (tier 5): two words per pattern mask, block-wise Myers (the horizontal deltas
+	// of the top row of word 0 are the carries into word 1), the score follows bit m-1
+	DEV uint32_t myersDistance2(uint32_t const j, LDSQ uint8_t const * text, uint32_t const n, uint32_t const m) const
+	{
+		LDSQ uint64_t const * PEQ = L.peq() + 8*j;
+		uint64_t const a0 = PEQ[0], a1 = PEQ[1], c0_ = PEQ[2], c1_ = PEQ[3], g0 = PEQ[4], g1 = PEQ[5], t0 = PEQ[6], t1 = PEQ[7];
+		LDSQ uint64_t const * T8 = reinterpret_cast<LDSQ uint64_t const *>(text);
+		bool const two = m > 64;
+		uint64_t const top = two ? (1ull<<(m-65)) : (1ull<<(m-1));
+		uint32_t score = m;
+		uint64_t Pv0 = ~0ull, Mv0 = 0, Pv1 = ~0ull, Mv1 = 0;
+		uint64_t w = n ? T8[0] : 0ull;
+		for ( uint32_t c0 = 0; c0 < n; c0 += 8 )
+		{
+			uint64_t const wn = (c0+8 < n) ? T8[(c0>>3)+1] : 0ull;
+			uint32_t const cnt = (n-c0 < 8) ? (n-c0) : 8u;
+			for ( uint32_t u = 0; u < cnt; ++u )
+			{
+				uint32_t const ch = static_cast<uint32_t>(w >> (8*u)) & 3u;
+				uint64_t const Eq0 = (ch & 2) ? ((ch & 1) ? t0 : g0) : ((ch & 1) ? c0_ : a0);
+				uint64_t const Eq1 = (ch & 2) ? ((ch & 1) ? t1 : g1) : ((ch & 1) ? c1_ : a1);
+				uint64_t const Xv0 = Eq0 | Mv0;
+				uint64_t const Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
+				uint64_t Ph0 = Mv0 | ~(Xh0 | Pv0);
+				uint64_t Mh0 = Pv0 & Xh0;
+				uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
+				if ( !two ) { if ( Ph0 & top ) ++score; else if ( Mh0 & top ) --score; }
+				Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
+				Pv0 = Mh0 | ~(Xv0 | Ph0);
+				Mv0 = Ph0 & Xv0;
+				if ( two )
+				{
+					uint64_t const Eq1c = Eq1 | mhc;
+					uint64_t const Xv1 = Eq1 | Mv1;
+					uint64_t const Xh1 = (((Eq1c & Pv1) + Pv1) ^ Pv1) | Eq1c;
+					uint64_t Ph1 = Mv1 | ~(Xh1 | Pv1);
+					uint64_t Mh1 = Pv1 & Xh1;
+					if ( Ph1 & top ) ++score; else if ( Mh1 & top ) --score;
+					Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
+					Pv1 = Mh1 | ~(Xv1 | Ph1);
+					Mv1 = Ph1 & Xv1;
+				}
+			}
+			w = wn;
+		}
+		return score;
+	}
 	DEV void buildPeq()
 	{
 		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
-			uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 			uint32_t const m = L.slen()[j];
-			LDSQ uint8_t const * s = L.str() + j*64;
-			for ( uint32_t i = 0; i < m; ++i )
+			LDSQ uint8_t const * s = L.str() + j*CT::lstr;
+			enum { PW = FastLds<CT>::pw };
+			#pragma unroll
+			for ( uint32_t wq = 0; wq < PW; ++wq )
 			{
-				uint32_t const c = s[i]; uint64_t const b = 1ull<<i;
-				e0 |= (c == 0) ? b : 0; e1 |= (c == 1) ? b : 0; e2 |= (c == 2) ? b : 0; e3 |= (c == 3) ? b : 0;
+				uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+				uint32_t const lo = 64*wq, hi = m < lo+64 ? m : lo+64;
+				for ( uint32_t i = lo; i < hi; ++i )
+				{
+					uint32_t const c = s[i]; uint64_t const b = 1ull<<(i-lo);
+					e0 |= (c == 0) ? b : 0; e1 |= (c == 1) ? b : 0; e2 |= (c == 2) ? b : 0; e3 |= (c == 3) ? b : 0;
+				}
+				L.peq()[4*PW*j+0*PW+wq] = e0; L.peq()[4*PW*j+1*PW+wq] = e1; L.peq()[4*PW*j+2*PW+wq] = e2; L.peq()[4*PW*j+3*PW+wq] = e3;
 			}
-			L.peq()[4*j+0] = e0; L.peq()[4*j+1] = e1; L.peq()[4*j+2] = e2; L.peq()[4*j+3] = e3;
 		}
 		wv_sync();
 	}
@@ -2524,7 +2585,8 @@ struct FastEngine
 	{
 		uint32_t const m = P.w;
 		LDSQ uint64_t const * PEQ = L.peq();
-		uint64_t const e0 = PEQ[0], e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
+		enum { PW = FastLds<CT>::pw };      // the A window has at most 63 bases: word 0 of every symbol
+		uint64_t const e0 = PEQ[0*PW], e1 = PEQ[1*PW], e2 = PEQ[2*PW], e3 = PEQ[3*PW];
 		LDSQ uint64_t const * T8 = reinterpret_cast<LDSQ uint64_t const *>(cons);
 		static_assert(MAXCONS <= 96 && (FastLds<CT>::o_bestL & 7) == 0,"consensus packed into three 64 bit words");
 		uint64_t const mask = (m == 64) ? ~0ull : ((1ull<<m)-1);
@@ -2705,7 +2767,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				bs = B.wt_b[row]; len = B.wt_e[row]-bs;
 				off = B.boff[o.bread]; rl = B.rlen[o.bread]; inv = o.flags & 1;
 			}
-			if ( len > 64 ) { toolong = 1; len = 0; }
+			if ( len > CT::lstr ) { toolong = 1; len = 0; }
 			L.slen()[j] = len;
 			L.mfirst()[j] = bs | (static_cast<uint64_t>(rl)<<32);
 			L.mlast()[j] = off | (static_cast<uint64_t>(inv ? 1 : 0)<<63);
@@ -2714,7 +2776,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 		wv_sync();
 		// bases: lane p of string j; four strings per round so that their loads are in flight together
 		for ( uint32_t j0 = 0; j0 < mao; j0 += 4 )
-			for ( uint32_t p = lane; p < 64; p += WSZ )
+			for ( uint32_t p = lane; p < CT::lstr; p += WSZ )
 			{
 				uint8_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
 				bool const a0 = p < L.slen()[j0], a1 = j0+1 < mao && p < L.slen()[j0+1], a2 = j0+2 < mao && p < L.slen()[j0+2], a3 = j0+3 < mao && p < L.slen()[j0+3];
@@ -2724,10 +2786,10 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				if ( a2 ) DACC_LB(2)
 				if ( a3 ) DACC_LB(3)
 				#undef DACC_LB
-				if ( a0 ) L.str()[(j0+0)*64+p] = v0;
-				if ( a1 ) L.str()[(j0+1)*64+p] = v1;
-				if ( a2 ) L.str()[(j0+2)*64+p] = v2;
-				if ( a3 ) L.str()[(j0+3)*64+p] = v3;
+				if ( a0 ) L.str()[(j0+0)*CT::lstr+p] = v0;
+				if ( a1 ) L.str()[(j0+1)*CT::lstr+p] = v1;
+				if ( a2 ) L.str()[(j0+2)*CT::lstr+p] = v2;
+				if ( a3 ) L.str()[(j0+3)*CT::lstr+p] = v3;
 			}
 	}
 	wv_sync();

@@ -29,7 +29,7 @@ struct EmulCtx
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<dacc_window_result> windows;
 	std::string err;
-	bool usefast; uint64_t ntier[3], nretry;
+	bool usefast; uint64_t ntier[3], nretry, nlong;
 	std::vector<uint64_t> glist;   // windows that went to the generic engine: index, flags of the last tier
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
@@ -48,13 +48,14 @@ static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 
 extern "C" {
 
-void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; return c; }
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; return c; }
 void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
 void emul_reasons_tier(void * v, int t, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasonsT[t][i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbitsT[t][i]; }
 void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,1,r,fb); }
 void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,0,r,fb); }
 void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
 uint64_t emul_generic_list(void * v, uint64_t * out, uint64_t cap) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( uint64_t i = 0; i < c->glist.size() && i < cap; ++i ) out[i] = c->glist[i]; return c->glist.size(); }
+uint64_t emul_count_long(void * v) { return static_cast<EmulCtx *>(v)->nlong; }
 void emul_counts4(void * v, uint64_t * n) { EmulCtx * c = static_cast<EmulCtx *>(v); n[0] = c->ntier[0]; n[1] = c->ntier[1]; n[2] = c->ntier[2]; n[3] = c->nretry; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
@@ -210,7 +211,25 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			cur.swap(next); haveList = true;
 			if ( !early ) { early = true; earlysnap = gearly; }       // the early generic kernel reads its list here
 		}
-		for ( size_t i = 0; i < earlysnap.size(); ++i ) { ++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); wave_run([&]() { processWindow(WB,earlysnap[i],arena.data()); }); }
+		// the library's launch on the second stream (k_window_long): tier 5 (strings of up to 128 bases) first, the generic
+		// engine for what it cannot hold
+		FastBatch FBL; FBL.W = WB; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0;
+		std::vector<uint8_t> ldsL(BP.ftierL.ldsbytes+64);
+		bool const longok = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap;
+		auto loadTablesL = [&]() { wave_run([&]() { FastLds< FastTier<5> > L; L.base = ldsL.data(); fast_load_tables(L,BP.ftierL.nrows,BP.ftierL.nsup,T,c->H.dpsq_vst.data()); }); };
+		if ( longok ) loadTablesL();
+		c->nlong = 0;
+		for ( size_t i = 0; i < earlysnap.size(); ++i )
+		{
+			int rc = FW_NEXT;
+			if ( longok )
+			{
+				if ( getenv("DACC_EMUL_POISON") ) { std::memset(ldsL.data(),atoi(getenv("DACC_EMUL_POISON")),ldsL.size()); loadTablesL(); }
+				wave_run([&]() { int const r = processWindowFast< FastTier<5> >(FBL,earlysnap[i],ldsL.data(),false); if ( wv_lane() == 0 ) rc = r; });
+			}
+			if ( rc == FW_DONE ) { ++c->nlong; continue; }
+			++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); wave_run([&]() { processWindow(WB,earlysnap[i],arena.data()); });
+		}
 		{
 			uint64_t const n = haveList ? cur.size() : BP.nwindows;
 			for ( uint64_t i = 0; i < n; ++i )

@@ -52,6 +52,8 @@ def lib(lanes=1):
         L.emul_set_fast.argtypes = [C.c_void_p, C.c_int]
         L.emul_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.emul_counts4.argtypes = [C.c_void_p, C.c_void_p]
+        L.emul_count_long.restype = C.c_uint64
+        L.emul_count_long.argtypes = [C.c_void_p]
         _libs[lanes] = L
     return _libs[lanes]
 
@@ -77,6 +79,10 @@ class Emul:
         n = (C.c_uint64 * 4)()
         self.L.emul_counts4(self.h, n)
         return tuple(int(x) for x in n)
+
+    def count_long(self):
+        """windows finished by tier 5 (strings of 65..128 bases)"""
+        return int(self.L.emul_count_long(self.h))
 
     def set_error_profile(self, p_i, p_d, est_cor):
         self.L.emul_set_error_profile(self.h, p_i, p_d, est_cor)

@@ -179,3 +179,20 @@ def test_read_positions_behind_the_table_support(monkeypatch):
     assert (wo["status"] == 1).sum() > 500
     assert windows_equal(wo, E.windows()) == []
     assert frags_equal(fo, bo, fe, be)
+
+
+@pytest.mark.parametrize("lanes", [1, 64])
+def test_windows_with_long_strings_run_in_tier5(lanes):
+    """B window strings of 65..128 bases (w = 56, insertion-rich reads): tier 5 (string stride 128, two-word pattern
+    masks) takes them on the library's second stream; only what tier 5 cannot hold is left to the generic engine."""
+    d = SynthData(100000, 200, 5000, erate=0.25, seed=77, ins_frac=0.9, del_frac=0.05, sub_frac=0.05)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    p = default_params(k=10, w=56, a=14)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p, lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    sel = slice(0, 2 if lanes == 1 else 1)
+    fo, bo = O.run(piles[sel], ovl, d.trace, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[sel], ovl, d.trace)
+    assert E.count_long() > 20 and E.counts()[3] <= E.count_long() // 10
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be)

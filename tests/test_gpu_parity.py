@@ -97,6 +97,18 @@ def test_deep_batch_starts_in_the_deep_tier():
     assert frags_equal(fo, bo, fx, bx)
 
 
+def test_windows_with_long_strings():
+    """w = 56 on insertion-rich reads: a quarter of the windows have a B string of more than 64 bases (k_window_long:
+    tier 5, then the generic engine)."""
+    d = SynthData(100000, 200, 5000, erate=0.25, seed=77, ins_frac=0.9, del_frac=0.05, sub_frac=0.05)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E = _pair(d, k=10, w=56, a=14)
+    fo, bo = O.run(piles[:3], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:3], ovl, d.trace)
+    assert windows_equal(O.windows(), E.debug_windows()) == []
+    assert frags_equal(fo, bo, fx, bx)
+
+
 def test_ont_like_profile_k_sweep():
     d = SynthData(60000, 150, 3000, erate=0.15, ins_frac=1 / 3, del_frac=1 / 3, sub_frac=1 / 3, seed=5)
     ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
