@@ -30,13 +30,14 @@
  *  - stretches are looked up by first / last node through small index arrays, the weights of a feasible (stretch,
  *    position) entry carry the weights of its end nodes, candidates are kept as stretch sequences and decoded once.
  *
- * The same code is instantiated for three capacity tiers (FastTier<1..3>: 3, 2 and 1 wavefronts per CU; the layout
+ * The same code is instantiated for five capacity tiers (FastTier<1..3>: 3, 2 and 1 wavefronts per CU; <4>: deep piles,
+ * 3 per CU; <5>: strings of up to 128 bases, 1 per CU; the layout
  * FastLds<CT> is a compile time constant, so every LDS access has an immediate offset).  processWindowFast returns
  * FW_NEXT when a window overflows a tier (flags say what overflowed: 1 instances, 2 nodes, 8 candidates, 16 walk,
  * 32 stretches, 64 links, 128 weights, 512 pools (0x4000 reverse cache, 0x8000 path ids, 0x10000 forward pool,
  * 0x20000 popped paths, 0x40000 score intervals), 1024 introsort depth, 2048 base length, 4096 candidate length /
- * sequence, 8192 gap filling) and FW_GENERIC for shapes no tier supports (w > 63, a string longer than 64 bases);
- * those go to the generic engine (dbg_window.hpp).
+ * sequence, 8192 gap filling) and FW_GENERIC for shapes the tier does not support (w > 63, a string longer than its
+ * string stride: 64 bases in tiers 1-4, 128 in tier 5); those go to tier 5 / the generic engine (dbg_window.hpp).
  */
 #ifndef DACC_FAST_WINDOW_HPP
 #define DACC_FAST_WINDOW_HPP
