@@ -145,8 +145,9 @@ def main():
         assert float(len(allba)) == total_bases, "gathered bases do not add up"
         ms_per_step = 1e3 * dt / args.steps
         value = total_bases * args.steps / dt / 1e6
+        first_kernel = "k_window_fast<4>" if int(getattr(t, "first_tier", 1)) == 4 else "k_window_fast<1>"   # deep batches start in tier 4
         kern = {"k_trace": tsum / args.steps, "k_vote": vsum / args.steps,
-                "k_window_fast<1>": tsums[0] / args.steps, "k_window_fast<2>": tsums[1] / args.steps,
+                first_kernel: tsums[0] / args.steps, "k_window_fast<2>": tsums[1] / args.steps,
                 "k_window_fast<3>": tsums[2] / args.steps, "k_window": (wsum - sum(tsums)) / args.steps}
         dom = max(kern, key=kern.get)
         # algorithmic bytes (every input byte once + corrected bases) of the launch / its duration

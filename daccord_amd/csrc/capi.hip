@@ -711,6 +711,7 @@ static int runDevice(dacc_ctx * c)
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
+	c->timing.first_tier = (c->usefast && BP.deep) ? 4u : 1u; c->timing.long_windows = 0;
 	c->timing.nwindows = BP.nwindows; c->timing.nblocks = BP.nblocks; c->timing.algo_bytes = BP.algo_bytes + nbases;
 	return DACC_OK;
 }
