@@ -567,7 +567,18 @@ static int runDevice(dacc_ctx * c)
 			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
 			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0;
 			if ( !c->tierL_ok ) FL.F.ldsbytes = 0;
-			hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,static_cast<uint32_t const *>(c->d_pregenlist.p));
+			// a launch the device refuses (the LDS of a whole CU) falls back to the generic engine alone, for good
+			auto const launchLong = [&](uint32_t const * const lst)
+			{
+				(void)hipGetLastError();
+				hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,lst);
+				if ( FL.F.ldsbytes && hipGetLastError() != hipSuccess )
+				{
+					c->tierL_ok = 0; FL.F.ldsbytes = 0;
+					hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),0,c->stream2,FL,c->d_err.p,lst);
+				}
+			};
+			launchLong(static_cast<uint32_t const *>(c->d_pregenlist.p));
 			WB.pregen = c->d_pregen.p;
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
@@ -597,7 +608,7 @@ static int runDevice(dacc_ctx * c)
 						early = true;
 						HIPCHK(hipEventRecord(c->evFirstTier,s));
 						HIPCHK(hipStreamWaitEvent(c->stream2,c->evFirstTier,0));
-						hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p));
+						launchLong(static_cast<uint32_t const *>(c->d_gearly.p));
 						HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
 					}
 				}
