@@ -438,7 +438,7 @@ struct FastEngine
 		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk()[i] = ~0ull;
 		wv_sync();
 		wv_sort_keys<FastLds<CT>::keycap>(L.lastk(),nlast);
-		wv_sort_keys<CT::precap>(L.pre(),npre);
+		wv_sort_keys<CT::precap,(CT::precap == 2048 && CT::ncap == 256)>(L.pre(),npre);      // 2048 keys in registers: the deep tier (FastTier<4>) only
 	}
 
 	DEV void buildNodes(uint32_t const f)

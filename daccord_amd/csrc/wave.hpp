@@ -289,7 +289,7 @@ template<int R, int J> DEV void wv_sort_inlane(uint64_t (&v)[R], uint32_t const 
 template<int R, typename PT>
 DEV void wv_sort_regs(PT A, uint32_t const n)
 {
-	static_assert(R == 2 || R == 4 || R == 8 || R == 16,"elements per lane");
+	static_assert(R == 2 || R == 4 || R == 8 || R == 16 || R == 32,"elements per lane");
 	uint32_t const lane = wv_lane(), base = lane*R;
 	uint64_t v[R];
 	#pragma unroll
@@ -310,6 +310,7 @@ DEV void wv_sort_regs(PT A, uint32_t const n)
 			}
 		}
 		uint32_t const h = k>>1;
+		if ( R > 16 && h >= 16 ) wv_sort_inlane<R,(R > 16 ? 16 : 1)>(v,base,k);
 		if ( R > 8 && h >= 8 ) wv_sort_inlane<R,(R > 8 ? 8 : 1)>(v,base,k);
 		if ( R > 4 && h >= 4 ) wv_sort_inlane<R,(R > 4 ? 4 : 1)>(v,base,k);
 		if ( R > 2 && h >= 2 ) wv_sort_inlane<R,(R > 2 ? 2 : 1)>(v,base,k);
@@ -322,7 +323,8 @@ DEV void wv_sort_regs(PT A, uint32_t const n)
 }
 #endif
 // ascending sort of n distinct 64-bit keys in memory (all lanes call); cap = compile time bound of n
-template<uint32_t CAP, typename PT>
+// R32: also keep up to 2048 keys in registers (32 per lane); only the deep tier asks for it
+template<uint32_t CAP, bool R32 = false, typename PT>
 DEV void wv_sort_keys(PT A, uint32_t const n)
 {
 #if WSZ == 64
@@ -330,6 +332,7 @@ DEV void wv_sort_keys(PT A, uint32_t const n)
 	if ( CAP <= 256 || n <= 256 ) { wv_sort_regs<4>(A,n); return; }
 	if ( CAP <= 512 || n <= 512 ) { wv_sort_regs<8>(A,n); return; }
 	if ( CAP <= 1024 || n <= 1024 ) { wv_sort_regs<16>(A,n); return; }
+	if ( R32 && (CAP <= 2048 || n <= 2048) ) { wv_sort_regs<32>(A,n); return; }      // deep piles: 55 strings carry 1500 k-mer instances
 #endif
 	wv_bitonic_sort_n(A,n);
 }
