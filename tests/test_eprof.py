@@ -32,3 +32,18 @@ def test_estimate_is_close_to_the_truth():
     c, us, un, (p_i, p_d, cor) = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:40], ovl, d.trace, nthreads=4)
     t_i, t_d, t_cor = d.error_profile()
     assert abs(p_i - t_i) < 0.03 and abs(p_d - t_d) < 0.02 and abs(cor - t_cor) < 0.04, ((p_i, p_d, cor), (t_i, t_d, t_cor))
+
+
+def test_estimator_with_two_byte_trace_values():
+    """tspace 200: two byte trace values (as DALIGNER writes them beyond 125) through the estimator's own block alignments."""
+    d = SynthData(60000, 120, 3000, seed=11, tspace=200)
+    assert d.trace_bytes == 2
+    ovl, piles = dio.select_lowest(d.ovl, d.piles, trace_bytes=2)
+    oo, po = pyoracle.select_lowest(d.ovl, d.piles)
+    assert (oo == ovl).all() and (po == piles).all()
+    n = 16
+    O = pyoracle.Oracle(default_params(k=8, tspace=200)); O.load_db(d.bps, d.boff, d.rlen)
+    co, uo, no, pro = O.estimate_profile(piles[:n], ovl, d.trace, trace_bytes=2)
+    cx, ux, nx, prx = dio.estimate_profile(d.bps, d.boff, d.rlen, 200, piles[:n], ovl, d.trace, trace_bytes=2, nthreads=3)
+    assert list(co) == list(cx) and (uo, no) == (ux, nx) and pro == prx
+    assert ux > 50
