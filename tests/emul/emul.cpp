@@ -152,6 +152,23 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
 		bool tierok[3];
+		// the library's pre-scan (k_prescan): windows with an active B string of more than 64 bases are flagged (the tiers skip
+		// them) and listed for the launch on the second stream
+		std::vector<uint32_t> pregen((BP.nwindows+31)/32+1,0); std::vector<uint64_t> pregenlist;
+		if ( usefast )
+		{
+			for ( size_t o = 0; o < BP.ovl.size(); ++o )
+			{
+				DevOvl const & ov = BP.ovl[o]; uint64_t const winbase = BP.piles[BP.ovl_pile[o]].winbase;
+				for ( uint32_t r = 0; r < ov.ny; ++r )
+					if ( wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r] > 64u )
+					{
+						uint64_t const w = winbase + ov.y0 + r;
+						if ( !((pregen[w>>5] >> (w&31)) & 1) ) { pregen[w>>5] |= 1u << (w&31); pregenlist.push_back(w); }
+					}
+			}
+			WB.pregen = pregen.data();
+		}
 		for ( int t = 0; t < 3; ++t )
 		{
 			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].retry = 0; FB[t].gearly = 0;
@@ -203,6 +220,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			for ( uint64_t i = 0; i < n; ++i )
 			{
 				uint64_t const wdx = haveList ? cur[i] : i;
+				if ( WB.pregen && ((WB.pregen[wdx>>5] >> (wdx&31)) & 1) ) continue;      // the kernels return at once for these: not counted as run by the tier
 				int const rc = runTier(t,wdx,haveList);
 				if ( rc == FW_DONE ) { ++c->ntier[t]; continue; }
 				uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++;
@@ -213,12 +231,13 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		}
 		// the library's launch on the second stream (k_window_long): tier 5 (strings of up to 128 bases) first, the generic
 		// engine for what it cannot hold
-		FastBatch FBL; FBL.W = WB; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0;
+		FastBatch FBL; FBL.W = WB; FBL.W.pregen = 0; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0;
 		std::vector<uint8_t> ldsL(BP.ftierL.ldsbytes+64);
 		bool const longok = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap;
 		auto loadTablesL = [&]() { wave_run([&]() { FastLds< FastTier<5> > L; L.base = ldsL.data(); fast_load_tables(L,BP.ftierL.nrows,BP.ftierL.nsup,T,c->H.dpsq_vst.data()); }); };
 		if ( longok ) loadTablesL();
 		c->nlong = 0;
+		earlysnap.insert(earlysnap.begin(),pregenlist.begin(),pregenlist.end());      // launch order: pre-scan list, then the first tier's list
 		for ( size_t i = 0; i < earlysnap.size(); ++i )
 		{
 			int rc = FW_NEXT;
