@@ -1627,6 +1627,7 @@ struct FastEngine
 	{
 		clInit(F.C,chunkrow); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
 		if ( firstnode < 0 ) return;
+		PROFX_T0      // profiling builds: lane 0's tree, split into filling the bucket heap (19) and draining it (20)
 		{
 			MIt it; byFirstBegin(V,it,firstnode);
 			for ( int32_t sx = byFirstNext(V,it); sx >= 0; sx = byFirstNext(V,it) )
@@ -1671,6 +1672,7 @@ struct FastEngine
 					else ipush<true>(hp,hn,static_cast<id_t>(e),W);
 				}
 			}
+			PROFX(19)
 			while ( hn )
 			{
 				uint32_t const path = hp[0];
@@ -1710,6 +1712,7 @@ struct FastEngine
 					}
 				}
 			}
+			PROFX(20)
 		}
 	}
 	// summary of a finished forward tree in slot fi of the per-candidate tables; one bit per scan target
