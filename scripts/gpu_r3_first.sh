@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; O=gpurun_out/r3a; mkdir -p $R/$O; cd $R
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log
 ( timeout 420 python bench.py ) > $O/bench_default.log 2>&1; echo "rc=$?" >> $O/bench_default.log
 ( timeout 300 python bench.py --coverage 54 --reads 2000 --steps 2 --warmup 1 --no-cpu ) > $O/bench_54x_2000piles.log 2>&1; echo "rc=$?" >> $O/bench_54x_2000piles.log
-for V in libdaccord_hip_prof libvar_Os_prof libvar_nounroll_prof libvar_O2_prof; do
+for V in libdaccord_hip_prof libvar_Os_prof libvar_nounroll_prof libvar_O2_prof libvar_t2w1040_prof; do
   [ -f daccord_amd/$V.so ] && ( DACC_LIB=$R/daccord_amd/$V.so timeout 100 python scripts/prof_phases.py 64 ) > $O/phases_$V.log 2>&1
 done
 cd /tmp && export TMPDIR=/tmp
