@@ -145,6 +145,16 @@ __global__ void __launch_bounds__(64) k_window_long(FastBatch FB, uint32_t * err
 	}
 }
 
+// The generic engine's per-wavefront arena grows with the deepest pile of the batch (7 MB at depth 32, 200 MB at 1000,
+// 800 MB at the default -D of 5000): the number of wavefronts is bounded so that one batch's arenas stay below 32 GB
+// instead of failing the batch for want of 400 GB.
+static inline uint32_t boundByArena(uint64_t grid, uint64_t const bytes, uint64_t const mingrid)
+{
+	uint64_t const budget = 32ull << 30;
+	while ( grid > mingrid && grid*bytes > budget ) grid >>= 1;
+	return static_cast<uint32_t>(grid < 1 ? 1 : grid);
+}
+
 // safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
 // Before the LDS tiers: windows with a B string of more than 64 bases can only run in the generic engine, where one of
 // them costs as much as a few hundred thousand ordinary windows in the LDS path.  One wavefront per overlap scans its rows
@@ -670,7 +680,7 @@ static int runDevice(dacc_ctx * c)
 	{
 		growArenaCaps(BP.caps);
 		Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
-		uint32_t const g = c->retry_grid < 64 ? c->retry_grid : 64;
+		uint32_t const g = boundByArena(c->retry_grid < 64 ? c->retry_grid : 64,BP.caps.bytes,4);
 		c->retry_grid = g; c->win_grid = g; if ( c->early_grid > g ) c->early_grid = g;     // later launches of this batch use the grown arenas
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(g)*BP.caps.bytes));
 		if ( c->usefast ) HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
@@ -810,7 +820,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( c->tierL_ok && BP.ftierL.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_long),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftierL.ldsbytes));
 		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
 		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
-		c->retry_grid = wg < 512 ? wg : 512;
+		c->retry_grid = boundByArena(wg < 512 ? wg : 512,BP.caps.bytes,8);
 		c->win_grid = c->retry_grid;
 		// generic engine on the second stream (windows with a string of more than 64 bases): a wavefront per window as far
 		// as the arenas stay below 8 GB -- at 64 wavefronts the hundred such windows of config 2 (one to three per wavefront,
@@ -824,9 +834,9 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	}
 	else
 	{
-		c->win_grid = wg;
+		c->win_grid = boundByArena(wg,BP.caps.bytes,8);
 		HIPCHK(c->d_work.ensure(64));
-		HIPCHK(c->d_arena.ensure(wg*BP.caps.bytes));
+		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->win_grid)*BP.caps.bytes));
 	}
 	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
 	HIPCHK(c->d_has.ensure(BP.npos+1)); HIPCHK(c->d_oc.ensure(BP.npos+1)); HIPCHK(c->d_ld0.ensure(BP.npos+1)); HIPCHK(c->d_ocs.ensure(BP.npos+1));
