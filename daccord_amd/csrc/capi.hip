@@ -823,8 +823,8 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		c->retry_grid = boundByArena(wg < 512 ? wg : 512,BP.caps.bytes,8);
 		c->win_grid = c->retry_grid;
 		// generic engine on the second stream (windows with a string of more than 64 bases): a wavefront per window as far
-		// as the arenas stay below 8 GB -- at 64 wavefronts the hundred such windows of config 2 (one to three per wavefront,
-		// up to seconds each) took 6.6 s next to the 8.2 s of the LDS tiers, the next thing to bound the step
+		// as the arenas stay below 8 GB (the handful of such windows of config 2 took the generic engine up to 6.6 s each next to
+		// the 8.2 s of the LDS tiers; tier 5 takes them now)
 		c->early_grid = c->retry_grid < 256 ? c->retry_grid : 256;
 		while ( c->early_grid > 16 && static_cast<uint64_t>(c->early_grid)*BP.caps.bytes > (8ull<<30) ) c->early_grid >>= 1;
 		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2));

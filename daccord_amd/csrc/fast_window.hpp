@@ -85,7 +85,7 @@ template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { rch = 4,
 
 // tier 5 (one wavefront per CU, only for the windows the pre-scan found): B strings of up to 128 bases (string stride 128,
 // two words per pattern mask); everything else as tier 3 with 64 strings.  Window strings of more than 64 bases are rare
-// at the default window (about ten per million windows of config 2) but each of them costs the generic engine seconds.
+// at the default window (a few per ten million windows of config 2) but each of them costs the generic engine seconds.
 template<> struct FastTier<5> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
