@@ -64,7 +64,7 @@ HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C)
 	uint32_t const keycap = next_pow2(C.maxs < 2 ? 2 : C.maxs);
 	DACC_CARVE(str,uint8_t,C.maxs*LSTR)
 	DACC_CARVE(slen,uint16_t,C.maxs)
-	DACC_CARVE(peq,uint64_t,C.maxs*8)
+	DACC_CARVE(peq,uint64_t,C.maxs*4*LPW)
 	DACC_CARVE(akeys,uint64_t,C.precap)       // also used for the (possibly > maxs) active list
 	DACC_CARVE(koff,uint32_t,C.maxs+1)
 	DACC_CARVE(pre,uint64_t,C.precap)

@@ -1118,12 +1118,12 @@ struct WindowEngine
 	}
 
 	// ================= T9: candidate errors, lane per (candidate,string) (:5355-5363) =================
-	// global edit distance, bit-parallel (Myers), pattern = window string (<= 128 symbols, 2 words)
+	// global edit distance, bit-parallel (Myers), pattern = window string (<= LSTR symbols: one, two or LPW words)
 	DEV uint32_t myersDistance(uint32_t const j, uint8_t const * text, uint32_t const n) const
 	{
 		uint32_t const m = A.slen[j];
 		if ( m == 0 ) return n;
-		uint64_t const * PEQ = A.peq + 8*j;
+		uint64_t const * PEQ = A.peq + 4*LPW*j;
 		uint32_t score = m;
 		if ( m <= 64 )
 		{
@@ -1131,7 +1131,7 @@ struct WindowEngine
 			uint64_t const top = 1ull<<(m-1);
 			for ( uint32_t c = 0; c < n; ++c )
 			{
-				uint64_t const Eq = PEQ[2*text[c]];
+				uint64_t const Eq = PEQ[LPW*text[c]];
 				uint64_t const Xv = Eq | Mv;
 				uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
 				uint64_t Ph = Mv | ~(Xh | Pv);
@@ -1142,13 +1142,13 @@ struct WindowEngine
 				Mv = Ph & Xv;
 			}
 		}
-		else
+		else if ( m <= 128 )
 		{
 			uint64_t Pv0 = ~0ull, Mv0 = 0, Pv1 = ~0ull, Mv1 = 0;
 			uint64_t const top = 1ull<<(m-65);
 			for ( uint32_t c = 0; c < n; ++c )
 			{
-				uint64_t const Eq0 = PEQ[2*text[c]], Eq1 = PEQ[2*text[c]+1];
+				uint64_t const Eq0 = PEQ[LPW*text[c]], Eq1 = PEQ[LPW*text[c]+1];
 				// word 0
 				uint64_t const Xv0 = Eq0 | Mv0;
 				uint64_t const Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
@@ -1170,6 +1170,34 @@ struct WindowEngine
 				Mv1 = Ph1 & Xv1;
 			}
 		}
+		else
+		{
+			// block-wise over LPW words (constant trip counts: the column state stays in registers); the score is read
+			// at the top bit of the pattern's last word, the words behind it compute and are ignored
+			uint64_t Pv[LPW], Mv[LPW];
+			for ( uint32_t b = 0; b < LPW; ++b ) { Pv[b] = ~0ull; Mv[b] = 0; }
+			uint32_t const lw = (m-1)>>6;
+			uint64_t const top = 1ull<<((m-1)&63);
+			for ( uint32_t c = 0; c < n; ++c )
+			{
+				uint64_t phc = 1, mhc = 0;   // horizontal delta entering row 0: +1 (global alignment)
+				for ( uint32_t b = 0; b < LPW; ++b )
+				{
+					uint64_t const Eq = PEQ[LPW*text[c]+b];
+					uint64_t const Eqc = Eq | mhc;
+					uint64_t const Xv = Eq | Mv[b];
+					uint64_t const Xh = (((Eqc & Pv[b]) + Pv[b]) ^ Pv[b]) | Eqc;
+					uint64_t Ph = Mv[b] | ~(Xh | Pv[b]);
+					uint64_t Mh = Pv[b] & Xh;
+					if ( b == lw ) { if ( Ph & top ) ++score; else if ( Mh & top ) --score; }
+					uint64_t const pho = Ph>>63, mho = Mh>>63;
+					Ph = (Ph<<1) | phc; Mh = (Mh<<1) | mhc;
+					Pv[b] = Mh | ~(Xv | Ph);
+					Mv[b] = Ph & Xv;
+					phc = pho; mhc = mho;
+				}
+			}
+		}
 		return score;
 	}
 
@@ -1177,11 +1205,11 @@ struct WindowEngine
 	{
 		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
-			uint64_t e[8] = {0,0,0,0,0,0,0,0};
+			uint64_t * e = A.peq + 4*LPW*j;
+			for ( uint32_t i = 0; i < 4*LPW; ++i ) e[i] = 0;
 			uint32_t const m = A.slen[j];
 			uint8_t const * s = A.str + j*LSTR;
-			for ( uint32_t i = 0; i < m; ++i ) e[2*s[i] + (i>>6)] |= 1ull<<(i&63);
-			for ( uint32_t i = 0; i < 8; ++i ) A.peq[8*j+i] = e[i];
+			for ( uint32_t i = 0; i < m; ++i ) e[LPW*s[i] + (i>>6)] |= 1ull<<(i&63);
 		}
 		wv_sync();
 	}
@@ -1450,7 +1478,7 @@ struct WindowEngine
 		uint64_t const top = 1ull<<(m-1);
 		for ( uint32_t c = 0; c < n; ++c )
 		{
-			uint64_t const Eq = PEQ[2*cons[c]];
+			uint64_t const Eq = PEQ[LPW*cons[c]];
 			uint64_t const Xv = Eq | Mv;
 			uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
 			uint64_t Ph = Mv | ~(Xh | Pv);

@@ -80,7 +80,8 @@ struct ArenaCaps
 	uint64_t bytes;     // total arena bytes per wavefront (filled by arena_layout)
 };
 
-enum { LSTR = 128 };       // max window string length held by the kernel
+enum { LSTR = 256 };       // max window string length held by the generic engine (one byte trace values: a tspace block of B is at most 255 bases)
+enum { LPW = LSTR/64 };     // 64 bit words per pattern mask of a window string
 enum { WREC = 256 };       // bytes per window output record
 enum { MAXCONS = 96 };     // max consensus length
 

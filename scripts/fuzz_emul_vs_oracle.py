@@ -1,6 +1,6 @@
 """Randomized parity runs: kernel logic (1-lane emulation, tests/emul) vs the CPU oracle over random run parameters
 (w, a, k ranges, filter frequencies, -d, -m, -f, -l, -e), error profiles and coverages.
-usage: python scripts/fuzz_emul_vs_oracle.py <seed> <rounds> [--wide] [--lanes64]      (found the -f / empty pile and the scratch overflow bugs)"""
+usage: python scripts/fuzz_emul_vs_oracle.py <seed> <rounds> [--wide] [--lanes64] [--warp]      (found the -f / empty pile and the scratch overflow bugs)"""
 import sys, os, time, random, collections
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,11 +14,15 @@ bad=0
 from common import random_run_config, random_run_config_wide
 for r in range(nrounds):
     kw, data, maxin, nplc = (random_run_config_wide if wide else random_run_config)(rng)
+    if '--warp' in sys.argv and not data.get('warp'): data['warp'] = (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))   # every round with badly aligned trace blocks
     try:
-        d=SynthData(data['genome_len'],data['nreads'],data['read_len'],**{k:v for k,v in data.items() if k not in ('genome_len','nreads','read_len','profile')})
+        d=SynthData(data['genome_len'],data['nreads'],data['read_len'],**{k:v for k,v in data.items() if k not in ('genome_len','nreads','read_len','profile','warp')})
         prof=data.get('profile') or d.error_profile()
         ovl,piles=pyoracle.pile_select(d.ovl,d.piles,maxinput=maxin)
         npl=min(len(piles),nplc)
+        if data.get('warp'):
+            from common import warp_trace
+            d.trace=warp_trace(ovl,piles,d.trace,range(npl),*data['warp'])
         p=default_params(**kw)
         O=pyoracle.Oracle(p); O.set_error_profile(*prof); O.load_db(d.bps,d.boff,d.rlen)
         E=emul_lib.Emul(p,lanes=lanes); E.set_error_profile(*prof); E.load_db(d.bps,d.boff,d.rlen)

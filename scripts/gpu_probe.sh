@@ -1,6 +1,6 @@
 # Native probe for the last seconds of a round's GPU time: the C++ front end on the files of scripts/make_probe.py, no
 # Python.  Each case: FASTA md5 against the oracle's (probe_in/<case>.expected.md5).
-O=gpurun_out/r2probe; mkdir -p $O
+O=${PROBE_OUT:-gpurun_out/probe}; mkdir -p $O
 export LD_LIBRARY_PATH=$PWD/daccord_amd:$LD_LIBRARY_PATH
 while read name args; do
   s=$(date +%s.%N)

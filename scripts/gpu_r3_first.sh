@@ -3,6 +3,7 @@
 # the generic engine on the second stream), then the default bench and the code size experiment.
 # Run scripts/r3_prepare_variants.sh first (here, no GPU).  About 9 minutes on the box.
 R=$GRAFT_REPO_ROOT; O=gpurun_out/r3a; mkdir -p $R/$O; cd $R
+[ -f probe_in/cases.txt ] && bash scripts/gpu_probe.sh   # python scripts/make_probe.py first (here): 4 cases through the C++ front end in seconds, incl. `warp` (strings of 129..256 bases, never run on a GPU)
 ( timeout 600 python -m pytest tests -x -q -m gpu ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log
 ( timeout 420 python bench.py ) > $O/bench_default.log 2>&1; echo "rc=$?" >> $O/bench_default.log

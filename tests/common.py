@@ -90,4 +90,33 @@ def random_run_config_wide(rng):
     if rng.random() < 0.25:
         # an error profile that is not the data's (an estimate from other reads): narrow or wide model tables
         data["profile"] = rng.choice([(0.01, 0.002, 0.98), (0.03, 0.01, 0.95), (0.2, 0.05, 0.7), (0.05, 0.05, 0.85)])
+    if rng.random() < 0.15:
+        # badly aligned trace blocks (warp_trace): B window strings of up to three times the window size
+        data["warp"] = (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
     return kw, data, maxin, npl
+
+
+def warp_trace(ovl, piles, trace, pile_ids, every=3, extra=115):
+    """Synthetic bad alignments: for every `every`-th overlap of the given piles, one interior trace block gets `extra`
+    more B bases (taken from the overlap's other blocks, so that the B lengths still sum to bepos-bbpos).  The windows
+    inside such a block have B strings of two to three times the window size.  Returns the new trace array."""
+    tr = trace.copy()
+    for pi in pile_ids:
+        f, n = int(piles[pi]["first_ovl"]), int(piles[pi]["novl"])
+        for z in range(f, f + n, every):
+            o = ovl[z]; nb = int(o["tlen"]) // 2; t0 = int(o["trace_off"])
+            if nb < 8:
+                continue
+            bl = [int(tr[t0 + 2 * i + 1]) for i in range(nb)]
+            tgt = nb // 2
+            take = min(extra, 250 - bl[tgt]); got = 0
+            for i in list(range(1, tgt)) + list(range(tgt + 1, nb - 1)):
+                g = min(bl[i] - 40, take - got)
+                if g > 0:
+                    bl[i] -= g; got += g
+                if got == take:
+                    break
+            bl[tgt] += got
+            for i in range(nb):
+                tr[t0 + 2 * i + 1] = bl[i]
+    return tr

@@ -196,3 +196,23 @@ def test_windows_with_long_strings_run_in_tier5(lanes):
     assert E.count_long() > 20 and E.counts()[3] <= E.count_long() // 10
     assert windows_equal(O.windows(), E.windows()) == []
     assert frags_equal(fo, bo, fe, be)
+
+
+@pytest.mark.parametrize("lanes", [1, 64])
+def test_window_strings_beyond_128_bases(lanes):
+    """Badly aligned trace blocks (a block of 100 A bases against more than 200 B bases): at w = 63 the windows inside
+    have B strings of 129..256 bases, which only the generic engine holds (string stride LSTR = 256, block-wise Myers
+    over four words for the candidate errors); the reference has no limit there (std::string windows)."""
+    from common import warp_trace
+    d = SynthData(100000, 200, 5000, seed=1)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    tr = warp_trace(ovl, piles, d.trace, [0, 1])
+    p = default_params(k=8, w=63, a=16)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p, lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    sel = slice(0, 2 if lanes == 1 else 1)
+    fo, bo = O.run(piles[sel], ovl, tr, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[sel], ovl, tr)
+    assert E.count_long() > 20
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be) and len(bo) > 3000
