@@ -19,7 +19,7 @@ struct HeapCC { double w; uint32_t o, l; };                               // Con
 struct Arena
 {
 	// window strings
-	uint8_t * str; uint16_t * slen; uint64_t * peq; uint64_t * akeys; uint32_t * koff;
+	uint8_t * str; uint16_t * slen; uint64_t * peq; uint64_t * mst; uint64_t * akeys; uint32_t * koff;
 	// k-mer instances
 	uint64_t * pre; uint64_t * lastk; uint32_t * nstart0;
 	// nodes
@@ -62,9 +62,10 @@ HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C)
 {
 	uint64_t o = 0;
 	uint32_t const keycap = next_pow2(C.maxs < 2 ? 2 : C.maxs);
-	DACC_CARVE(str,uint8_t,C.maxs*LSTR)
+	DACC_CARVE(str,uint8_t,static_cast<uint64_t>(C.maxs)*C.lstr)
 	DACC_CARVE(slen,uint16_t,C.maxs)
-	DACC_CARVE(peq,uint64_t,C.maxs*4*LPW)
+	DACC_CARVE(peq,uint64_t,static_cast<uint64_t>(C.maxs)*4*(C.lstr>>6))
+	DACC_CARVE(mst,uint64_t,64*2*(C.lstr>>6))    // per lane column state (Pv, Mv) of the block-wise Myers for strings beyond LSTR
 	DACC_CARVE(akeys,uint64_t,C.precap)       // also used for the (possibly > maxs) active list
 	DACC_CARVE(koff,uint32_t,C.maxs+1)
 	DACC_CARVE(pre,uint64_t,C.precap)

@@ -47,6 +47,7 @@ struct BatchPlan
 	std::vector<uint64_t> fragbase;
 	uint64_t nwindows, nblocks, nwt, npos, nfragslots, algo_bytes;
 	uint32_t maxdepth, maxcols;
+	uint64_t maxspan;         // upper bound of the B window string lengths of the batch (from the trace values)
 	std::vector<int32_t> pile_status;         // per submitted pile: DACC_OK or why it was dropped
 	std::vector<std::string> pile_errors;     // first messages of dropped piles
 	ArenaCaps caps;
@@ -61,7 +62,7 @@ struct BatchPlan
 		uint32_t const tab_nrows = 0, uint32_t const tab_nsup = 0)
 	{
 		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear(); pile_status.assign(np,DACC_OK); pile_errors.clear();
-		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0; ndeepwin = 0; deep = false;
+		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0; maxspan = 0; ndeepwin = 0; deep = false;
 		if ( trace_bytes != 1 && trace_bytes != 2 ) { err = "trace values are 1 byte (tspace <= 125) or 2 bytes"; return DACC_EINVAL; }
 		if ( par.tspace <= 0 || par.tspace > 512 ) { err = "tspace must be in [1,512] (column vectors of the trace kernels: 2, 4 or 8 64-bit words)"; return DACC_ENOTSUP; }
 		uint8_t const * tr8 = static_cast<uint8_t const *>(trace); uint16_t const * tr16 = static_cast<uint16_t const *>(trace);
@@ -124,6 +125,17 @@ struct BatchPlan
 				int64_t const nblk = (o.aepos + ts - 1)/ts - o.abpos/ts;
 				v.nblk = nblk; v.blk0 = nblocks; v.trace_off = o.trace_off;
 				for ( int64_t b = 0; b < nblk; ++b ) { uint32_t const bl = tv(o.trace_off+2*b+1); if ( bl > maxcols ) maxcols = bl; }
+				{
+					// longest B span a window can have: a window of w bases touches at most nbw consecutive tspace blocks
+					int64_t const nbw = (static_cast<int64_t>(par.w) + ts - 2)/ts + 1;
+					uint64_t run = 0;
+					for ( int64_t b = 0; b < nblk; ++b )
+					{
+						run += tv(o.trace_off+2*b+1);
+						if ( b >= nbw ) run -= tv(o.trace_off+2*(b-nbw)+1);
+						if ( run > maxspan ) maxspan = run;
+					}
+				}
 				nblocks += nblk;
 				algo_bytes += 40 + static_cast<uint64_t>(o.tlen)*trace_bytes + (o.bepos-o.bbpos+3)/4;
 				// active window range [y0,y0+ny): start(y) >= abpos and end(y) <= aepos
@@ -176,7 +188,10 @@ struct BatchPlan
 		caps.poolcap = 8192;
 		caps.blcap = 256;
 		caps.conscap = 32768 + MAXCONS;
-		caps.pad = 0; caps.bytes = 0;
+		// string stride of the generic engine: what the longest possible B window string needs (LSTR for ordinary data:
+		// two blocks of a hundred bases; more only for badly aligned blocks), a multiple of 64, at most LSTRMAX
+		caps.lstr = static_cast<uint32_t>(std::min<uint64_t>(LSTRMAX,std::max<uint64_t>(LSTR,(maxspan+63)&~static_cast<uint64_t>(63))));
+		caps.bytes = 0;
 		// LDS fast path capacity tiers (compile time, fast_window.hpp); windows beyond them are re-run by the generic engine
 		// A batch whose windows are mostly too deep for tier 1 (coverage of 40x and more) starts in the deep tier instead
 		deep = 2*ndeepwin > nwindows;

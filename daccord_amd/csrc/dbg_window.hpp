@@ -144,7 +144,7 @@ struct WindowEngine
 			uint32_t const len = A.slen[j];
 			if ( len < k ) continue;
 			uint32_t const numk = len-k+1;
-			uint8_t const * s = A.str + j*LSTR;
+			uint8_t const * s = A.str + static_cast<uint64_t>(j)*C.lstr;
 			uint32_t const o = A.koff[j];
 			for ( uint32_t i = lane; i < numk; i += WSZ )
 			{
@@ -163,7 +163,7 @@ struct WindowEngine
 			uint32_t tot; uint32_t const pre = wv_scan_excl(has,tot);
 			if ( has )
 			{
-				uint8_t const * s = A.str + j*LSTR;
+				uint8_t const * s = A.str + static_cast<uint64_t>(j)*C.lstr;
 				uint64_t v = 0;
 				for ( uint32_t q = 0; q < k; ++q ) v = (v<<2) | s[len-k+q];
 				A.lastk[base+pre] = (v<<32) | (static_cast<uint64_t>(len-k)<<16) | j;
@@ -1123,7 +1123,8 @@ struct WindowEngine
 	{
 		uint32_t const m = A.slen[j];
 		if ( m == 0 ) return n;
-		uint64_t const * PEQ = A.peq + 4*LPW*j;
+		uint32_t const lpw = C.lstr>>6;
+		uint64_t const * PEQ = A.peq + static_cast<uint64_t>(4*lpw)*j;
 		uint32_t score = m;
 		if ( m <= 64 )
 		{
@@ -1131,7 +1132,7 @@ struct WindowEngine
 			uint64_t const top = 1ull<<(m-1);
 			for ( uint32_t c = 0; c < n; ++c )
 			{
-				uint64_t const Eq = PEQ[LPW*text[c]];
+				uint64_t const Eq = PEQ[lpw*text[c]];
 				uint64_t const Xv = Eq | Mv;
 				uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
 				uint64_t Ph = Mv | ~(Xh | Pv);
@@ -1148,7 +1149,7 @@ struct WindowEngine
 			uint64_t const top = 1ull<<(m-65);
 			for ( uint32_t c = 0; c < n; ++c )
 			{
-				uint64_t const Eq0 = PEQ[LPW*text[c]], Eq1 = PEQ[LPW*text[c]+1];
+				uint64_t const Eq0 = PEQ[lpw*text[c]], Eq1 = PEQ[lpw*text[c]+1];
 				// word 0
 				uint64_t const Xv0 = Eq0 | Mv0;
 				uint64_t const Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
@@ -1170,7 +1171,7 @@ struct WindowEngine
 				Mv1 = Ph1 & Xv1;
 			}
 		}
-		else
+		else if ( m <= LSTR )
 		{
 			// block-wise over LPW words (constant trip counts: the column state stays in registers); the score is read
 			// at the top bit of the pattern's last word, the words behind it compute and are ignored
@@ -1183,13 +1184,41 @@ struct WindowEngine
 				uint64_t phc = 1, mhc = 0;   // horizontal delta entering row 0: +1 (global alignment)
 				for ( uint32_t b = 0; b < LPW; ++b )
 				{
-					uint64_t const Eq = PEQ[LPW*text[c]+b];
+					uint64_t const Eq = PEQ[lpw*text[c]+b];
 					uint64_t const Eqc = Eq | mhc;
 					uint64_t const Xv = Eq | Mv[b];
 					uint64_t const Xh = (((Eqc & Pv[b]) + Pv[b]) ^ Pv[b]) | Eqc;
 					uint64_t Ph = Mv[b] | ~(Xh | Pv[b]);
 					uint64_t Mh = Pv[b] & Xh;
 					if ( b == lw ) { if ( Ph & top ) ++score; else if ( Mh & top ) --score; }
+					uint64_t const pho = Ph>>63, mho = Mh>>63;
+					Ph = (Ph<<1) | phc; Mh = (Mh<<1) | mhc;
+					Pv[b] = Mh | ~(Xv | Ph);
+					Mv[b] = Ph & Xv;
+					phc = pho; mhc = mho;
+				}
+			}
+		}
+		else
+		{
+			// beyond LSTR: the same over nw words with the column state of this lane in the arena
+			uint32_t const nw = (m+63)>>6;
+			uint64_t * const Pv = A.mst + static_cast<uint64_t>(lane)*2*lpw, * const Mv = Pv + lpw;
+			for ( uint32_t b = 0; b < nw; ++b ) { Pv[b] = ~0ull; Mv[b] = 0; }
+			uint64_t const top = 1ull<<((m-1)&63);
+			for ( uint32_t c = 0; c < n; ++c )
+			{
+				uint64_t phc = 1, mhc = 0;
+				for ( uint32_t b = 0; b < nw; ++b )
+				{
+					uint64_t const Eq = PEQ[lpw*text[c]+b];
+					uint64_t const Eqc = Eq | mhc;
+					uint64_t const pv = Pv[b], mv = Mv[b];
+					uint64_t const Xv = Eq | mv;
+					uint64_t const Xh = (((Eqc & pv) + pv) ^ pv) | Eqc;
+					uint64_t Ph = mv | ~(Xh | pv);
+					uint64_t Mh = pv & Xh;
+					if ( b == nw-1 ) { if ( Ph & top ) ++score; else if ( Mh & top ) --score; }
 					uint64_t const pho = Ph>>63, mho = Mh>>63;
 					Ph = (Ph<<1) | phc; Mh = (Mh<<1) | mhc;
 					Pv[b] = Mh | ~(Xv | Ph);
@@ -1205,11 +1234,12 @@ struct WindowEngine
 	{
 		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
-			uint64_t * e = A.peq + 4*LPW*j;
-			for ( uint32_t i = 0; i < 4*LPW; ++i ) e[i] = 0;
+			uint32_t const lpw = C.lstr>>6;
+			uint64_t * e = A.peq + static_cast<uint64_t>(4*lpw)*j;
+			for ( uint32_t i = 0; i < 4*lpw; ++i ) e[i] = 0;
 			uint32_t const m = A.slen[j];
-			uint8_t const * s = A.str + j*LSTR;
-			for ( uint32_t i = 0; i < m; ++i ) e[LPW*s[i] + (i>>6)] |= 1ull<<(i&63);
+			uint8_t const * s = A.str + static_cast<uint64_t>(j)*C.lstr;
+			for ( uint32_t i = 0; i < m; ++i ) e[lpw*s[i] + (i>>6)] |= 1ull<<(i&63);
 		}
 		wv_sync();
 	}
@@ -1478,7 +1508,7 @@ struct WindowEngine
 		uint64_t const top = 1ull<<(m-1);
 		for ( uint32_t c = 0; c < n; ++c )
 		{
-			uint64_t const Eq = PEQ[LPW*cons[c]];
+			uint64_t const Eq = PEQ[(C.lstr>>6)*cons[c]];
 			uint64_t const Xv = Eq | Mv;
 			uint64_t const Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
 			uint64_t Ph = Mv | ~(Xh | Pv);

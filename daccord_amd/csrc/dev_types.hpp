@@ -76,12 +76,13 @@ struct ArenaCaps
 	uint32_t poolcap;   // path pool entries (each direction)
 	uint32_t blcap;     // distinct base lengths (heaps per length)
 	uint32_t conscap;   // candidate text bytes
-	uint32_t pad;
+	uint32_t lstr;      // string stride of the generic engine: a multiple of 64, at least LSTR (host plan: longest B span a window can have)
 	uint64_t bytes;     // total arena bytes per wavefront (filled by arena_layout)
 };
 
-enum { LSTR = 256 };       // max window string length held by the generic engine (one byte trace values: a tspace block of B is at most 255 bases)
-enum { LPW = LSTR/64 };     // 64 bit words per pattern mask of a window string
+enum { LSTR = 256 };       // least string stride of the generic engine (ArenaCaps::lstr); up to here the Myers column state stays in registers
+enum { LPW = LSTR/64 };     // 64 bit words of such a column
+enum { LSTRMAX = 4096 };   // largest string stride the host plan asks for (a longer B window string drops its pile)
 enum { WREC = 256 };       // bytes per window output record
 enum { MAXCONS = 96 };     // max consensus length
 

@@ -119,10 +119,10 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 			uint64_t const row = o.wtoff + (y - o.y0);
 			uint32_t const bs = B.wt_b[row], be = B.wt_e[row];
 			uint32_t const len = be-bs;
-			if ( len > LSTR ) { E.setOverflow(0x40000); if ( lane == 0 ) A.slen[j] = 0; continue; }
+			if ( len > B.C.lstr ) { E.setOverflow(0x40000); if ( lane == 0 ) A.slen[j] = 0; continue; }
 			uint64_t const off = B.boff[o.bread]; uint32_t const rl = B.rlen[o.bread]; bool const inv = o.flags & 1;
 			for ( uint32_t p = lane; p < len; p += WSZ )
-				A.str[j*LSTR+p] = readBase(B.bps,off,rl,inv,bs+p);
+				A.str[static_cast<uint64_t>(j)*B.C.lstr+p] = readBase(B.bps,off,rl,inv,bs+p);
 			if ( lane == 0 ) A.slen[j] = len;
 		}
 	}

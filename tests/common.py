@@ -93,10 +93,12 @@ def random_run_config_wide(rng):
     if rng.random() < 0.15:
         # badly aligned trace blocks (warp_trace): B window strings of up to three times the window size
         data["warp"] = (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
+        if data["tspace"] > 125 and rng.random() < 0.5:
+            data["warp"] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000)   # two byte trace values: strings beyond 256 bases
     return kw, data, maxin, npl
 
 
-def warp_trace(ovl, piles, trace, pile_ids, every=3, extra=115):
+def warp_trace(ovl, piles, trace, pile_ids, every=3, extra=115, cap=250):
     """Synthetic bad alignments: for every `every`-th overlap of the given piles, one interior trace block gets `extra`
     more B bases (taken from the overlap's other blocks, so that the B lengths still sum to bepos-bbpos).  The windows
     inside such a block have B strings of two to three times the window size.  Returns the new trace array."""
@@ -109,7 +111,7 @@ def warp_trace(ovl, piles, trace, pile_ids, every=3, extra=115):
                 continue
             bl = [int(tr[t0 + 2 * i + 1]) for i in range(nb)]
             tgt = nb // 2
-            take = min(extra, 250 - bl[tgt]); got = 0
+            take = min(extra, cap - bl[tgt]); got = 0      # cap: one byte trace values
             for i in list(range(1, tgt)) + list(range(tgt + 1, nb - 1)):
                 g = min(bl[i] - 40, take - got)
                 if g > 0:

@@ -1,6 +1,7 @@
 """Kernel LOGIC vs oracle on the CPU: the device headers compiled as a 1-lane wavefront
 (tests/emul/emul.cpp, test harness only) must reproduce the oracle bit for bit -- tables, per-window
 consensus, fragments.  The real 64-lane gfx950 build is checked by test_gpu_parity.py (-m gpu)."""
+import numpy as np
 import pytest
 import pyoracle
 import emul_lib
@@ -214,5 +215,25 @@ def test_window_strings_beyond_128_bases(lanes):
     fo, bo = O.run(piles[sel], ovl, tr, nthreads=4, want_windows=True)
     fe, be = E.run(piles[sel], ovl, tr)
     assert E.count_long() > 20
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be) and len(bo) > 3000
+
+
+@pytest.mark.parametrize("lanes", [1, 64])
+def test_window_strings_beyond_256_bases(lanes):
+    """Two byte trace values (tspace 126) with blocks of 126 A bases against 700 B bases: window strings of more than 256
+    bases.  The host plan sizes the generic engine's string stride from the trace values (ArenaCaps::lstr) and the
+    candidate errors run the block-wise Myers with its column state in the arena."""
+    from common import warp_trace
+    d = SynthData(100000, 200, 5000, seed=1, tspace=126)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    tr = warp_trace(ovl, piles, d.trace, [0, 1], every=4, extra=580, cap=2000)
+    assert tr.dtype == np.uint16 and tr.max() > 600
+    p = default_params(k=8, w=63, a=16, tspace=126)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p, lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    sel = slice(0, 2 if lanes == 1 else 1)
+    fo, bo = O.run(piles[sel], ovl, tr, trace_bytes=2, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[sel], ovl, tr, trace_bytes=2)
     assert windows_equal(O.windows(), E.windows()) == []
     assert frags_equal(fo, bo, fe, be) and len(bo) > 3000
