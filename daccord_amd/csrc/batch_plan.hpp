@@ -177,7 +177,9 @@ struct BatchPlan
 		}
 		// scratch capacities
 		uint64_t const depthcap = std::min<uint64_t>(static_cast<uint64_t>(maxdepth)+1, par.maxalign ? par.maxalign : 1);
-		caps.maxs = std::max<uint32_t>(2,static_cast<uint32_t>(std::min<uint64_t>(depthcap,4096)));
+		// strings per window of the generic engine: as deep as the batch is, up to 8192 (the default -D keeps 5000 overlaps
+		// per read; the number of wavefronts is bounded by the arena budget, capi.hip: boundByArena)
+		caps.maxs = std::max<uint32_t>(2,static_cast<uint32_t>(std::min<uint64_t>(depthcap,8192)));
 		caps.precap = hostNextPow2(std::max<uint32_t>(256,std::max<uint32_t>(caps.maxs*72,maxdepth+1)));
 		caps.nodecap = caps.precap;
 		caps.fcap = caps.nodecap*24;
