@@ -37,6 +37,7 @@ static inline void growArenaCaps(ArenaCaps & c)
 {
 	c.precap *= 2; c.nodecap *= 2;        // stays a power of two (bitonic sorts)
 	c.fcap *= 4; c.strcap *= 2; c.linkcap *= 4; c.sfcap *= 4; c.rlcap *= 4; c.poolcap *= 4; c.conscap = 4*(c.conscap-MAXCONS) + MAXCONS;
+	c.blcap *= 2;                         // base lengths of the enumerated paths (long window strings make long paths)
 }
 
 struct BatchPlan
@@ -196,6 +197,7 @@ struct BatchPlan
 		// string stride of the generic engine: what the longest possible B window string needs (LSTR for ordinary data:
 		// two blocks of a hundred bases; more only for badly aligned blocks), a multiple of 64, at most LSTRMAX
 		caps.lstr = static_cast<uint32_t>(std::min<uint64_t>(LSTRMAX,std::max<uint64_t>(LSTR,(maxspan+63)&~static_cast<uint64_t>(63))));
+		if ( caps.lstr > LSTR ) caps.blcap = caps.lstr + 128;    // a stretch runs as far as a string does, a path half a window further
 		caps.bytes = 0;
 		// LDS fast path capacity tiers (compile time, fast_window.hpp); windows beyond them are re-run by the generic engine
 		// A batch whose windows are mostly too deep for tier 1 (coverage of 40x and more) starts in the deep tier instead
