@@ -237,3 +237,20 @@ def test_window_strings_beyond_256_bases(lanes):
     fe, be = E.run(piles[sel], ovl, tr, trace_bytes=2)
     assert windows_equal(O.windows(), E.windows()) == []
     assert frags_equal(fo, bo, fe, be) and len(bo) > 3000
+
+
+def test_long_strings_make_long_stretches():
+    """k = 14 on window strings of several hundred bases: an unbranched stretch runs as far as a string does, so the
+    enumerations' per-base-length heaps (ArenaCaps::blcap) are sized with the string stride (found by the CPU fuzzing
+    with warped traces: flags 0x800 at the former fixed 256)."""
+    from common import warp_trace
+    d = SynthData(100000, 200, 5000, seed=1, tspace=126)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    tr = warp_trace(ovl, piles, d.trace, [0, 1], every=4, extra=580, cap=2000)
+    p = default_params(k=14, w=40, a=20, tspace=126)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[:2], ovl, tr, trace_bytes=2, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[:2], ovl, tr, trace_bytes=2)
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fe, be) and len(bo) > 3000
