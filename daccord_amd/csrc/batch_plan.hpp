@@ -90,9 +90,10 @@ struct BatchPlan
 				uint64_t bsum = 0; uint32_t bmax = 0;
 				for ( int64_t b = 0; b < nblk; ++b ) { uint32_t const bl = tv(o.trace_off+2*b+1); bsum += bl; if ( bl > bmax ) bmax = bl; }
 				if ( static_cast<int64_t>(bsum) != o.bepos-o.bbpos ) { bad = "trace B lengths do not sum to bepos-bbpos"; break; }
-				// what the LDS column stores of the trace kernels hold (capi.hip: k_trace 64 lanes, k_trace_wide<4|8> 8 lanes at
-				// least); only two byte trace values can say more, and such a block is no alignment: the pile is dropped
-				if ( bmax > (tsv <= 128 ? 928u : (tsv <= 256 ? 4096u : 2048u)) ) { bad = "a trace block spans too many B bases"; break; }
+				// what the LDS column stores of the trace kernels hold at 8 lanes per wavefront (capi.hip: k_trace_wide<4> for
+				// tspace <= 256, <8> beyond); only two byte trace values can say more, and such a block is no alignment: the
+				// pile is dropped
+				if ( bmax > (tsv <= 256 ? 4096u : 2048u) ) { bad = "a trace block spans too many B bases"; break; }
 			}
 			uint32_t const pnovl = bad ? 0u : p.novl;
 			if ( bad )

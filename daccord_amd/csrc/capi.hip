@@ -763,7 +763,9 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	// a few rounds of blocks per workgroup
 	{
 		c->trace_bytes = trace_bytes;
-		c->tr_words = c->par.tspace <= 128 ? 2 : (c->par.tspace <= 256 ? 4 : 8);
+		// two word columns for tspace <= 128 while every lane's column store fits (blocks of up to 928 B bases: always with
+		// one byte trace values); a batch with a longer block runs the four word kernel, which sizes its lanes to the LDS
+		c->tr_words = (c->par.tspace <= 128 && BP.maxcols <= 928) ? 2 : (c->par.tspace <= 256 ? 4 : 8);
 		c->tr_lanes = 64;
 		if ( c->tr_words == 2 ) c->tr_lds = traceSlots(BP.maxcols)*64u*34u;
 		else

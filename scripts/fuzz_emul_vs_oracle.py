@@ -15,7 +15,7 @@ from common import random_run_config, random_run_config_wide
 for r in range(nrounds):
     kw, data, maxin, nplc = (random_run_config_wide if wide else random_run_config)(rng)
     if '--warp' in sys.argv and not data.get('warp'):   # every round with badly aligned trace blocks
-        data['warp'] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000 if data['tspace'] > 128 else 900) if data['tspace'] > 125 else (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
+        data['warp'] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000) if data['tspace'] > 125 else (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
     try:
         d=SynthData(data['genome_len'],data['nreads'],data['read_len'],**{k:v for k,v in data.items() if k not in ('genome_len','nreads','read_len','profile','warp')})
         prof=data.get('profile') or d.error_profile()

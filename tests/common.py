@@ -94,7 +94,7 @@ def random_run_config_wide(rng):
         # badly aligned trace blocks (warp_trace): B window strings of up to three times the window size
         data["warp"] = (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
         if data["tspace"] > 125 and rng.random() < 0.5:
-            data["warp"] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000 if data["tspace"] > 128 else 900)   # two byte trace values: strings beyond 256 bases (blocks within what k_trace holds: a longer one drops its pile)
+            data["warp"] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000)   # two byte trace values: strings beyond 256 bases (blocks within what the trace kernels hold: 4096 / 2048 B bases, a longer one drops its pile)
     return kw, data, maxin, npl
 
 

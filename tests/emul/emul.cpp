@@ -114,7 +114,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		std::vector<uint64_t> colw(traceSlots(BP.maxcols)*4); std::vector<uint16_t> colsc(traceSlots(BP.maxcols));
 		TraceStoreMem st; st.w = colw.data(); st.sc = colsc.data();
 		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag;
-		if ( P.tspace <= 128 ) for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);
+		if ( P.tspace <= 128 && BP.maxcols <= 928 ) for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);   // as the library chooses (capi.hip: tr_words)
 		else
 		{
 			// wide blocks: the device's lane-interleaved column store over a host buffer (16 lanes, block t on lane t % 16)

@@ -98,18 +98,36 @@ def test_window_strings_beyond_256_bases():
 
 
 def test_monstrous_trace_block_drops_its_pile_only_emulation():
-    """Two byte trace values can name a block of a thousand B bases, more than the trace kernel's LDS column store holds:
-    the plan drops that pile (reported), the batch goes on."""
+    """Two byte trace values can name a block of thousands of B bases, more than the trace kernels' LDS column stores hold
+    (2048 at tspace 300): the plan drops that pile (reported), the batch goes on."""
     from daccord_amd.synth import SynthData
     from common import warp_trace
-    d = SynthData(100000, 200, 5000, seed=1, tspace=126)
+    d = SynthData(100000, 200, 5000, seed=1, tspace=300)
     ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
-    tr = warp_trace(ovl, piles, d.trace, [1], every=7, extra=1000, cap=3000)
-    assert tr.max() > 928
-    p = default_params(k=8, tspace=126)
+    tr = warp_trace(ovl, piles, d.trace, [1], every=7, extra=2500, cap=5000)
+    assert tr.max() > 2048
+    p = default_params(k=8, tspace=300)
     E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
     fx, bx = E.run(piles[:3], ovl, tr, trace_bytes=2)
     O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
     fo, bo = O.run(piles[[0, 2]], ovl, d.trace, trace_bytes=2, nthreads=2)
     assert frags_equal(fo, bo, fx, bx)
     assert not (fx["aread"] == piles[1]["aread"]).any()
+
+
+def test_long_trace_block_at_tspace_126_runs_the_wide_trace_kernel_emulation():
+    """A block of more than 928 B bases at tspace <= 128 does not fit the two word trace kernel's 64 column stores: the batch
+    runs k_trace_wide<4> (lanes sized to the LDS) and gives the oracle's result."""
+    from daccord_amd.synth import SynthData
+    from common import warp_trace, windows_equal
+    d = SynthData(100000, 200, 5000, seed=1, tspace=126)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    tr = warp_trace(ovl, piles, d.trace, [0, 1], every=6, extra=1100, cap=3000)
+    assert tr.max() > 928
+    p = default_params(k=8, tspace=126)
+    E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E.run(piles[:2], ovl, tr, trace_bytes=2)
+    O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
+    fo, bo = O.run(piles[:2], ovl, tr, trace_bytes=2, nthreads=4, want_windows=True)
+    assert windows_equal(O.windows(), E.windows()) == []
+    assert frags_equal(fo, bo, fx, bx) and len(bo) > 3000
