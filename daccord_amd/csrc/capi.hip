@@ -565,7 +565,10 @@ static int runDevice(dacc_ctx * c)
 		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
 		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = c->d_prof.p;
 		WB.pregen = 0;
-		if ( c->usefast )
+		// no LDS tier usable (DACC_TIERS=0 or a model table no tier's overlay holds): everything runs in the generic engine on
+		// the main stream; the pre-scan / second stream would hand the same windows to two kernels
+		bool const anytier = c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2];
+		if ( c->usefast && anytier )
 		{
 			// windows only the generic engine can run (a string longer than 64 bases): found by a scan of the window tables and
 			// started on the second stream now, concurrently with all LDS tiers
@@ -691,7 +694,7 @@ static int runDevice(dacc_ctx * c)
 		WindowBatch WB;
 		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
 		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
-		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = 0;
+		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = 0; WB.pregen = 0;
 		hipLaunchKernelGGL(k_window,dim3(g),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p),static_cast<uint32_t *>(0));
 		int const rc = voteAndFetch(); if ( rc ) return rc;
 	}

@@ -30,6 +30,12 @@
 #include <sstream>
 #include <iostream>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <chrono>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "../../include/daccord_hip.h"
 #include "../../include/daccord_io.h"
 
@@ -40,7 +46,7 @@ struct Options
 	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
 	bool f = false; int V = 1; bool haveI = false, haveJ = false; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
 	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
-	bool eprofonly = false, keepeprof = false;
+	bool eprofonly = false, keepeprof = false; int device = 0; uint64_t batch = 2000;
 	std::vector<std::string> pos;
 };
 
@@ -85,6 +91,8 @@ Options parse(int argc, char ** argv)
 			else if ( val("eprofonly",v) ) o.eprofonly = v.empty() || v != "0";
 			else if ( val("keepeprof",v) ) o.keepeprof = v.empty() || v != "0";
 			else if ( val("eprof",v) ) o.eprof = v;
+			else if ( val("device",v) ) o.device = static_cast<int>(num("--device",v));
+			else if ( val("batch",v) ) { o.batch = num("--batch",v); if ( !o.batch ) die("--batch needs a positive number of A reads"); }
 			else if ( val("deepprofileonly",v) ) die("--deepprofileonly (k-mer depth profile of the estimator) is not part of this path");
 			else die("unknown option " + a);
 			continue;
@@ -120,7 +128,8 @@ Options parse(int argc, char ** argv)
 			"  -w<40> window  -a<10> advance  -k<8|lo,hi> k-mer size  -d<max depth>  -D<5000> max alignments per read  --vard<v>\n"
 			"  -m<3> min window coverage  -e<max window error>  -l<0> min output length  -f produce full reads\n"
 			"  -I<lo,hi> read interval (inclusive)  -J<i,j> part i of j  --minfilterfreq<0> --maxfilterfreq<2>\n"
-			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof\n");
+			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof\n"
+			"  --device<0> HIP device  --batch<2000> A reads per GPU batch  (one process per GPU: -J<g,G> --device<g>)\n");
 		std::exit(EXIT_FAILURE);
 	}
 	return o;
@@ -194,14 +203,23 @@ int main(int argc, char ** argv)
 	int64_t const toparead = maxaread >= 0 ? maxaread+1 : maxaread;
 	if ( o.V ) std::fprintf(stderr,"[V] minaread=%lld toparead=%lld\n",static_cast<long long>(minaread),static_cast<long long>(toparead));
 
+	// the .las must belong to this database: the reference's readers throw on an id beyond it
+	if ( novl && lasmax >= static_cast<int64_t>(A.n) )
+		die("A read id " + std::to_string(lasmax) + " of " + lasfn + " is beyond the " + std::to_string(A.n) + " reads of " + o.pos[1] + ": the .las does not belong to this database");
+	if ( o.vard && !avgrl ) die("--vard needs a database with reads (average read length is zero)");
+	uint64_t const nB = twodb ? B2.n : A.n;
+
 	// batch of piles [b0,b1): load, top-D select per pile, shift B ids in two database mode
-	std::vector<dacc_overlap> sel; std::vector<dacc_pile> spiles; std::vector<dacc_overlap> tmp;
-	void const * trace = 0; uint64_t ntrace = 0;
-	auto loadBatch = [&](int64_t const b0, int64_t const b1, bool const lowest) -> void
+	struct Batch { std::vector<dacc_overlap> sel; std::vector<dacc_pile> spiles; std::vector<uint8_t> trace; uint64_t ntrace = 0; bool end = false; std::string err; };
+	std::vector<dacc_overlap> tmp;
+	auto loadBatch = [&](int64_t const b0, int64_t const b1, bool const lowest, Batch & B) -> void
 	{
-		dacc_pile const * piles = 0; uint64_t npiles = 0; dacc_overlap const * ovl = 0; uint64_t no = 0;
-		if ( dacc_las_piles(las,b0,b1,&piles,&npiles,&ovl,&no,&trace,&ntrace) ) die(std::string("las: ") + dacc_las_error(las));
-		sel.clear(); spiles.clear();
+		dacc_pile const * piles = 0; uint64_t npiles = 0; dacc_overlap const * ovl = 0; uint64_t no = 0; void const * trace = 0; uint64_t ntrace = 0;
+		B.sel.clear(); B.spiles.clear(); B.trace.clear(); B.ntrace = 0; B.err.clear();
+		if ( dacc_las_piles(las,b0,b1,&piles,&npiles,&ovl,&no,&trace,&ntrace) ) { B.err = std::string("las: ") + dacc_las_error(las); return; }
+		for ( uint64_t z = 0; z < no; ++z )
+			if ( static_cast<uint64_t>(ovl[z].bread) >= nB )
+			{ B.err = "B read id " + std::to_string(ovl[z].bread) + " (A read " + std::to_string(ovl[z].aread) + ") is beyond the " + std::to_string(nB) + " reads of the database"; return; }
 		for ( uint64_t i = 0; i < npiles; ++i )
 		{
 			uint64_t const rl = prlen[piles[i].aread];
@@ -210,14 +228,18 @@ int main(int argc, char ** argv)
 			tmp.resize(std::max<uint64_t>(piles[i].novl,1)); uint64_t nout = 0;
 			int const rc = lowest ? dacc_pile_select_lowest(ovl+piles[i].first_ovl,piles[i].novl,tbytes,lmaxinput,tmp.data(),&nout)
 			                      : dacc_pile_select(ovl+piles[i].first_ovl,piles[i].novl,tbytes,lmaxinput,tmp.data(),&nout);
-			if ( rc ) die("pile selection failed");
-			dacc_pile q; q.aread = piles[i].aread; q.novl = nout; q.first_ovl = sel.size();
-			for ( uint64_t z = 0; z < nout; ++z ) { dacc_overlap v = tmp[z]; v.bread += nA; sel.push_back(v); }
-			spiles.push_back(q);
+			if ( rc ) { B.err = "pile selection failed"; return; }
+			dacc_pile q; q.aread = piles[i].aread; q.novl = nout; q.first_ovl = B.sel.size();
+			for ( uint64_t z = 0; z < nout; ++z ) { dacc_overlap v = tmp[z]; v.bread += nA; B.sel.push_back(v); }
+			B.spiles.push_back(q);
 		}
+		// the handle's arrays are valid until its next call, which the loader makes while this batch is on the GPU
+		B.trace.assign(static_cast<uint8_t const *>(trace),static_cast<uint8_t const *>(trace) + ntrace*static_cast<uint64_t>(tbytes));
+		B.ntrace = ntrace;
 	};
 
-	// error profile
+	// error profile: --eprof, else the file; estimated if the file is missing or older than the .las (unless --keepeprof),
+	// daccord.cpp:1653-1660
 	double prof[3] = {0,0,0};
 	std::string const eproffn = o.E.empty() ? (lasfn + ".eprof") : o.E;
 	bool have = false;
@@ -227,65 +249,159 @@ int main(int argc, char ** argv)
 		std::istringstream is(s); if ( !(is >> prof[0] >> prof[1] >> prof[2]) ) die("--eprof needs three numbers: p_i,p_d,est_cor");
 		have = true;
 	}
-	else if ( readProfileText(eproffn,prof) ) have = true;
+	else
+	{
+		struct stat se, sl;
+		bool const exists = ::stat(eproffn.c_str(),&se) == 0;
+		bool const older = exists && ::stat(lasfn.c_str(),&sl) == 0 &&
+			( se.st_mtim.tv_sec < sl.st_mtim.tv_sec || (se.st_mtim.tv_sec == sl.st_mtim.tv_sec && se.st_mtim.tv_nsec < sl.st_mtim.tv_nsec) );
+		if ( exists && !(older && !o.keepeprof) )
+		{
+			if ( !readProfileText(eproffn,prof) ) die("cannot parse the error profile " + eproffn + " (three numbers: p_i p_d est_cor)");
+			have = true;
+		}
+	}
+	if ( !have && !(minaread <= maxaread) )
+	{
+		// an empty part (-J beyond the data) has nothing to estimate from and nothing to correct: the reference emits nothing
+		if ( o.V ) std::fprintf(stderr,"[V] empty read interval, nothing to do\n");
+		dacc_las_close(las); dacc_db_close(A.h); if ( twodb ) dacc_db_close(B2.h);
+		return EXIT_SUCCESS;
+	}
 	if ( !have )
 	{
 		// estimate from the first 1024 piles of the interval (daccord.cpp:1653-1878): k=8, w=40, a=5
+		auto const te0 = std::chrono::steady_clock::now();
 		int64_t const top = std::min<int64_t>(toparead,minaread+1024);
 		uint64_t counts[4] = {0,0,0,0}; uint64_t usable = 0, unusable = 0; double eavg = 0, edif = 0;
 		dacc_eprof * ep = 0;
 		if ( dacc_eprof_create(&ep,tspace,pbps,pboff,prlen,nreads,twodb ? 1 : 0) ) die("error profile estimation: out of memory");
 		unsigned int hw = std::thread::hardware_concurrency(); if ( !hw ) hw = 1; if ( hw > 64 ) hw = 64;
+		Batch EB;
 		for ( int64_t b0 = minaread; b0 < top; b0 += 256 )
 		{
-			loadBatch(b0,std::min<int64_t>(top,b0+256),true);
-			if ( spiles.empty() ) continue;
-			if ( dacc_eprof_add(ep,spiles.data(),spiles.size(),sel.data(),sel.size(),trace,ntrace,tbytes,o.d,hw) ) die("error profile estimation: malformed overlap records");
+			loadBatch(b0,std::min<int64_t>(top,b0+256),true,EB);
+			if ( !EB.err.empty() ) die(EB.err);
+			if ( EB.spiles.empty() ) continue;
+			if ( dacc_eprof_add(ep,EB.spiles.data(),EB.spiles.size(),EB.sel.data(),EB.sel.size(),EB.trace.data(),EB.ntrace,tbytes,o.d,hw) ) die("error profile estimation failed (out of memory)");
 		}
 		if ( dacc_eprof_finish(ep,counts,&usable,&unusable,&eavg,&edif,prof) ) die("error profile estimation found no usable window; give --eprof<p_i,p_d,est_cor>");
 		dacc_eprof_destroy(ep);
 		std::fprintf(stderr,"usable=%llu unusable=%llu eavg=%g edif=%g\n",static_cast<unsigned long long>(usable),static_cast<unsigned long long>(unusable),eavg,edif);
 		std::fprintf(stderr,"AlignmentStatistics(matches=%llu,mismatches=%llu,insertions=%llu,deletions=%llu)\n",
 			static_cast<unsigned long long>(counts[0]),static_cast<unsigned long long>(counts[1]),static_cast<unsigned long long>(counts[2]),static_cast<unsigned long long>(counts[3]));
-		std::ofstream out(eproffn.c_str());
-		char buf[128]; std::snprintf(buf,sizeof(buf),"%.17g %.17g %.17g\n",prof[0],prof[1],prof[2]); out << buf;
+		if ( o.V ) std::fprintf(stderr,"[V] error profile estimated on %u host threads in %.2f s\n",hw,std::chrono::duration<double>(std::chrono::steady_clock::now()-te0).count());
+		// temp file + rename (daccord.cpp:1855-1860): parallel -J jobs on one .las never see a partly written profile
+		std::string const tmpfn = eproffn + ".tmp." + std::to_string(static_cast<long long>(::getpid()));
+		{
+			std::ofstream out(tmpfn.c_str());
+			char buf[128]; std::snprintf(buf,sizeof(buf),"%.17g %.17g %.17g\n",prof[0],prof[1],prof[2]); out << buf;
+			out.flush();
+			if ( !out ) { std::remove(tmpfn.c_str()); die("cannot write the error profile " + tmpfn); }
+		}
+		if ( std::rename(tmpfn.c_str(),eproffn.c_str()) != 0 ) { std::remove(tmpfn.c_str()); die("cannot rename " + tmpfn + " to " + eproffn); }
 	}
 	if ( o.V ) std::fprintf(stderr,"[V] p_i=%.17g p_d=%.17g est_cor=%.17g\n",prof[0],prof[1],prof[2]);
 	if ( o.eprofonly ) return EXIT_SUCCESS;
 
 	dacc_params p; std::memset(&p,0,sizeof(p));
 	p.w = o.w; p.a = o.a; p.klow = o.klow; p.khigh = o.khigh; p.minfilterfreq = o.minff; p.maxfilterfreq = o.maxff; p.minwindowcov = o.m;
-	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = 0; p.verbose = o.V;
+	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = o.device; p.verbose = o.V;
 	dacc_ctx * ctx = 0;
 	{ int const rc = dacc_create(&ctx,&p); if ( rc ) die("dacc_create failed (" + std::to_string(rc) + "): no usable HIP device or bad parameters"); }
 	if ( dacc_load_db(ctx,pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctx));
 
 	if ( dacc_set_error_profile(ctx,prof[0],prof[1],prof[2]) ) die(std::string("error profile: ") + dacc_last_error(ctx));
 
-	uint64_t well = 0;
-	int64_t const batch = 2000;
-	std::string rec;
-	for ( int64_t b0 = minaread; b0 < toparead; b0 += batch )
-	{
-		loadBatch(b0,std::min(toparead,b0+batch),false);
-		if ( spiles.empty() ) continue;
-		if ( dacc_submit_piles(ctx,spiles.data(),spiles.size(),sel.data(),sel.size(),trace,ntrace,tbytes) )
-			die(std::string("batch failed: ") + dacc_last_error(ctx));
-		{ char const * pe = dacc_pile_errors(ctx); if ( pe && *pe ) std::fprintf(stderr,"[E] skipped reads:\n%s",pe); }
-		dacc_fragment const * fr = 0; uint64_t nf = 0; char const * bases = 0; uint64_t nb = 0;
-		if ( dacc_collect(ctx,&fr,&nf,&bases,&nb) ) die(std::string("collect: ") + dacc_last_error(ctx));
-		rec.clear();
-		for ( uint64_t i = 0; i < nf; ++i )
+	// Three stages, overlapped like the reference overlaps input, handlers and output with its threads (daccord.cpp:2107-2112):
+	// a loader thread reads the byte range of the next batch of A reads from the .las and selects its piles, this thread
+	// plans the batch and runs it on the GPU, a writer thread turns the fragments of the previous batch into FASTA text.
+	int64_t const batch = static_cast<int64_t>(o.batch);
+	struct Out { std::vector<dacc_fragment> fr; std::string bases; bool end = false; };
+	std::mutex mu; std::condition_variable cv;
+	std::deque<Batch *> loaded; std::deque<Batch *> freeb; std::deque<Out *> outs; std::deque<Out *> freeo;
+	Batch bslots[2]; Out oslots[2];
+	freeb.push_back(&bslots[0]); freeb.push_back(&bslots[1]); freeo.push_back(&oslots[0]); freeo.push_back(&oslots[1]);
+	auto const t0 = std::chrono::steady_clock::now();
+	std::thread loader([&]() {
+		for ( int64_t b0 = minaread; ; b0 += batch )
 		{
-			char hdr[160];
-			std::snprintf(hdr,sizeof(hdr),">%d/%llu/%u_%u A=[%u,%u]\n",fr[i].aread+1,static_cast<unsigned long long>(well++),fr[i].first,fr[i].first+fr[i].len,fr[i].first,fr[i].last);
-			rec += hdr;
-			for ( uint32_t q = 0; q < fr[i].len; q += 80 ) { rec.append(bases+fr[i].seq_off+q,std::min<uint32_t>(80,fr[i].len-q)); rec += '\n'; }
+			Batch * B;
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeb.empty(); }); B = freeb.front(); freeb.pop_front(); }
+			B->end = !(b0 < toparead);
+			if ( !B->end ) loadBatch(b0,std::min(toparead,b0+batch),false,*B);
+			bool const stop = B->end || !B->err.empty();
+			{ std::lock_guard<std::mutex> lk(mu); loaded.push_back(B); }
+			cv.notify_all();
+			if ( stop ) break;
 		}
-		std::fwrite(rec.data(),1,rec.size(),stdout);
-		dacc_release(ctx);
+	});
+	uint64_t well = 0, totalbases = 0;
+	std::thread writer([&]() {
+		std::string rec;
+		while ( true )
+		{
+			Out * O;
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !outs.empty(); }); O = outs.front(); outs.pop_front(); }
+			if ( O->end ) break;
+			rec.clear();
+			for ( size_t i = 0; i < O->fr.size(); ++i )
+			{
+				dacc_fragment const & f = O->fr[i];
+				char hdr[160];
+				std::snprintf(hdr,sizeof(hdr),">%d/%llu/%u_%u A=[%u,%u]\n",f.aread+1,static_cast<unsigned long long>(well++),f.first,f.first+f.len,f.first,f.last);
+				rec += hdr;
+				for ( uint32_t q = 0; q < f.len; q += 80 ) { rec.append(O->bases.data()+f.seq_off+q,std::min<uint32_t>(80,f.len-q)); rec += '\n'; }
+			}
+			std::fwrite(rec.data(),1,rec.size(),stdout);
+			{ std::lock_guard<std::mutex> lk(mu); freeo.push_back(O); }
+			cv.notify_all();
+		}
+	});
+	std::string fatal;
+	double gpu_s = 0; uint64_t nbatches = 0;
+	while ( true )
+	{
+		Batch * B;
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !loaded.empty(); }); B = loaded.front(); loaded.pop_front(); }
+		if ( !B->err.empty() ) { fatal = B->err; break; }
+		if ( B->end ) break;
+		if ( !B->spiles.empty() )
+		{
+			auto const tb0 = std::chrono::steady_clock::now();
+			if ( dacc_submit_piles(ctx,B->spiles.data(),B->spiles.size(),B->sel.data(),B->sel.size(),B->trace.data(),B->ntrace,tbytes) )
+			{ fatal = std::string("batch failed: ") + dacc_last_error(ctx); break; }
+			gpu_s += std::chrono::duration<double>(std::chrono::steady_clock::now()-tb0).count(); ++nbatches;
+			{ char const * pe = dacc_pile_errors(ctx); if ( pe && *pe ) std::fprintf(stderr,"[E] skipped reads:\n%s",pe); }
+			dacc_fragment const * fr = 0; uint64_t nf = 0; char const * bases = 0; uint64_t nb = 0;
+			if ( dacc_collect(ctx,&fr,&nf,&bases,&nb) ) { fatal = std::string("collect: ") + dacc_last_error(ctx); break; }
+			Out * O;
+			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeo.empty(); }); O = freeo.front(); freeo.pop_front(); }
+			O->end = false; O->fr.assign(fr,fr+nf); O->bases.assign(bases,nb); totalbases += nb;
+			dacc_release(ctx);
+			{ std::lock_guard<std::mutex> lk(mu); outs.push_back(O); }
+			cv.notify_all();
+		}
+		{ std::lock_guard<std::mutex> lk(mu); freeb.push_back(B); }
+		cv.notify_all();
 	}
+	{
+		Out * O;
+		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeo.empty(); }); O = freeo.front(); freeo.pop_front(); }
+		O->end = true;
+		{ std::lock_guard<std::mutex> lk(mu); outs.push_back(O); }
+		cv.notify_all();
+	}
+	writer.join();
+	if ( !fatal.empty() ) { std::fflush(stdout); std::fprintf(stderr,"[E] %s\n",fatal.c_str()); std::_Exit(EXIT_FAILURE); }
+	loader.join();
 	std::fflush(stdout);
+	if ( o.V )
+	{
+		double const el = std::chrono::duration<double>(std::chrono::steady_clock::now()-t0).count();
+		std::fprintf(stderr,"[V] %llu corrected bases in %.2f s end to end (load + select + plan + GPU + FASTA) = %.3f Mbase/s; %llu batches, %.2f s in dacc_submit_piles\n",
+			static_cast<unsigned long long>(totalbases),el,el > 0 ? totalbases/el/1e6 : 0.0,static_cast<unsigned long long>(nbatches),gpu_s);
+	}
 	dacc_destroy(ctx);
 	dacc_las_close(las); dacc_db_close(A.h); if ( twodb ) dacc_db_close(B2.h);
 	return EXIT_SUCCESS;

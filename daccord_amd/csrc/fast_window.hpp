@@ -67,7 +67,12 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
+#if defined(DACC_T1_LEAN)
+// occupancy experiment (scripts/gpu_r3_occ.sh): tier 1 with small capacities so that 5-6 wavefronts share a CU; used with DACC_TAB_GLOBAL
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 24, idmax = 250, rpstcap = 256, lstr = 64, maxs = 16, precap = 512, ncap = 288, scap = 48, lcap = 352, wcap = 240, rccap = 64, fcap = 48, siqcap = 56, blcap = 96 }; };
+#else
 template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+#endif
 // DACC_T2_WCAP: experiment hook (scripts/r3_prepare_variants.sh): 1040 weights make tier 2 81 808 bytes, which still fits twice
 // into 160 KB if LDS is handed out in granules of 1280 bytes or less (unverified; 992 -> 80 512 bytes is what was measured)
 #ifndef DACC_T2_WCAP
@@ -267,7 +272,11 @@ struct FastLds
 	FLD(ulo,uint8_t,2*CT::scap,e_toff)
 	FLD(uhi,uint8_t,2*CT::scap,e_ulo)
 	FLD(tab,uint32_t,(upool-taskbytes-o_cdh)/4,o_cdh)   // also over the candidate buffers, which are dead at that time
+#if defined(DACC_TAB_GLOBAL)
+	static constexpr uint32_t tabcap = 0x7FFFFFFFu;
+#else
 	static constexpr uint32_t tabcap = (upool-taskbytes-o_cdh)/4;
+#endif
 	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
 };
 #undef FLD
@@ -308,13 +317,13 @@ DEV void fast_load_tables(FastLds<CT> const & L, uint32_t const nrows, uint32_t 
 
 #if defined(DACC_EMUL)
 // emulation only: per-window maxima of the variable-size structures (design aid, DACC_EMUL_STATS=<file>)
-struct FastStats { uint32_t v[24]; void clear() { for ( int i = 0; i < 24; ++i ) v[i] = 0; } void mx(int i, uint32_t x) { if ( x > v[i] ) v[i] = x; } void add(int i, uint32_t x) { v[i] += x; } };
+struct FastStats { uint32_t v[32]; void clear() { for ( int i = 0; i < 32; ++i ) v[i] = 0; } void mx(int i, uint32_t x) { if ( x > v[i] ) v[i] = x; } void add(int i, uint32_t x) { v[i] += x; } };
 static FastStats g_fstats;
 static inline void fstats_dump(int const tier)
 {
 	static FILE * sf = 0; static bool tried = false;
 	if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_STATS"); if ( fn ) sf = fopen(fn,"w"); }
-	if ( sf ) { fprintf(sf,"%d",tier); for ( int i = 0; i < 24; ++i ) fprintf(sf," %u",g_fstats.v[i]); fprintf(sf,"\n"); fflush(sf); }
+	if ( sf ) { fprintf(sf,"%d",tier); for ( int i = 0; i < 32; ++i ) fprintf(sf," %u",g_fstats.v[i]); fprintf(sf,"\n"); fflush(sf); }
 }
 static inline FILE * ftrav_file() { static FILE * f = 0; static bool tried = false; if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_TRAV"); if ( fn ) f = fopen(fn,"w"); } return f; }
 #define FSTAT_MX(i,x) g_fstats.mx(i,x)
@@ -928,10 +937,69 @@ struct FastEngine
 
 	}
 
+	// Can any (first, last) candidate pair of this activation state offer a candidate at all?  A candidate is a chain of
+	// view stretches from the first k-mer to the last k-mer (forward path, junction, reverse path: traverse :4838-5097), i.e.
+	// a walk of at least one active edge from the node of `first` to the node of `last`.  Base stretches cover every active
+	// edge that can be reached from a branch node (computeStretches :2844-2986), pieces are parts of them, so a breadth first
+	// search over the base stretches from the first k-mer candidates decides it: if it reaches no last k-mer candidate,
+	// traverse() has nothing to enumerate and returns false (ACCo == 0) -- feasibility, both enumerations and the pairs are
+	// skipped.  The condition is necessary only (feasibility and the length bounds are not looked at): a reachable pair
+	// goes through the enumerations as before.  Scratch: the weight arrays, which are written after this.
+	DEV bool pairReachable()
+	{
+		static_assert(2u*CT::ncap + CT::scap + 8u <= 4u*CT::wcap,"reachability scratch must fit the first weight array");
+		LDSQ uint8_t * const seedN = reinterpret_cast<LDSQ uint8_t *>(L.wF_lo());
+		LDSQ uint8_t * const reachN = seedN + CT::ncap;
+		LDSQ uint8_t * const vis = reachN + CT::ncap;
+		if ( nF == 0 || nL == 0 ) return false;
+		for ( uint32_t z = lane; z < nn; z += WSZ ) { seedN[z] = 0; reachN[z] = 0; }
+		for ( uint32_t s = lane; s < n0; s += WSZ ) vis[s] = 0;
+		wv_sync();
+		// a first k-mer at a stretch end starts the stretches that begin there; one strictly inside a stretch leads to its end
+		for ( uint32_t c = lane; c < nF; c += WSZ )
+		{
+			uint32_t const z = L.fnode()[c], par = L.parF()[c];
+			if ( z == 0xFFFF ) continue;
+			if ( par == FNOPAR ) seedN[z] = 1; else reachN[L.slast()[par]] = 1;
+		}
+		wv_sync();
+		while ( true )
+		{
+			uint32_t changed = 0;
+			for ( uint32_t s = lane; s < n0; s += WSZ )
+				if ( !vis[s] )
+				{
+					uint32_t const f = L.sfirst()[s];
+					if ( seedN[f] | reachN[f] ) { vis[s] = 1; reachN[L.slast()[s]] = 1; changed = 1; }
+				}
+			wv_sync();
+			if ( !wv_any(changed) ) break;
+		}
+		uint32_t ok = 0;
+		for ( uint32_t c = lane; c < nL; c += WSZ )
+		{
+			uint32_t const z = L.lnode()[c], par = L.parL()[c];
+			if ( z == 0xFFFF ) continue;
+			if ( par == FNOPAR ) ok |= reachN[z];
+			else
+			{
+				ok |= vis[par];      // entered through its first node
+				uint32_t const pl = L.posL()[c];
+				for ( uint32_t f = 0; f < nF; ++f ) if ( L.parF()[f] == par && L.posF()[f] < pl ) ok = 1;     // a first k-mer before it inside the same stretch
+			}
+		}
+		bool const res = wv_any(ok) != 0;
+		wv_sync();
+		return res;
+	}
+
 	// copy of the model table in LDS, row stride nrows+1: the extra row is zero so that positions beyond the table can be
 	// clamped instead of branched on; one more all-zero position (nsup) for read positions behind the support
 	DEV void loadTab()
 	{
+#if defined(DACC_TAB_GLOBAL)
+		return;      // experiment: the model table is read from HBM / L2 / L1 where it is needed
+#endif
 		uint32_t const stride = nrows+1;
 		uint32_t pos = static_cast<uint32_t>(lane) / stride, row = static_cast<uint32_t>(lane) - pos*stride;     // the one division of the copy
 		uint32_t const dpos = WSZ / stride, drow = WSZ - dpos*stride;
@@ -1106,8 +1174,13 @@ struct FastEngine
 					uint32_t const ip_b = IP[i0_b];
 					uint32_t const pp = P+j;
 					uint32_t const pc = pp < nrows ? pp : nrows;
+#if defined(DACC_TAB_GLOBAL)
+					uint64_t U = tabAt<true>(ip_a,pc,stride);
+					for ( uint32_t q = 1; q < f_a; ++q ) U += tabAt<true>(static_cast<uint32_t>(IP[i0_a+q]),pc,stride);
+#else
 					uint64_t U = L.tab()[ip_a*stride + pc];
 					for ( uint32_t q = 1; q < f_a; ++q ) U += L.tab()[static_cast<uint32_t>(IP[i0_a+q])*stride + pc];
+#endif
 					if ( U < FW_THRES_FEAS ) { ok = false; break; }
 					sum += U;
 					if ( j == 0 ) f1 = U;
@@ -1173,7 +1246,11 @@ struct FastEngine
 		uint32_t const i0 = L.nps()[z], f = L.nfreq()[z];
 		LDSQ uint8_t const * IP = rev ? L.irpos() : L.ipos();
 		uint64_t u = 0;
+#if defined(DACC_TAB_GLOBAL)
+		for ( uint32_t q = 0; q < f; ++q ) u += tabAt<true>(static_cast<uint32_t>(IP[i0+q]),p,nrows+1);
+#else
 		for ( uint32_t q = 0; q < f; ++q ) u += L.tab()[static_cast<uint32_t>(IP[i0+q])*(nrows+1) + p];
+#endif
 		return u;
 	}
 	DEV int32_t sfFind(uint32_t const s, uint32_t const p) const
@@ -2254,6 +2331,9 @@ struct FastEngine
 		PROF(*this,8)
 		findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
+#if !defined(DACC_NO_REACH)
+		if ( !pairReachable() ) { FSTAT_ADD(23,1); PROF(*this,16) return false; }
+#endif
 		PROF(*this,16)
 		loadTab();
 		PROF(*this,17)
@@ -2499,7 +2579,7 @@ struct FastEngine
 		wv_sync();
 		PROF(*this,13)
 		FSTAT_MX(0,mao); FSTAT_MX(1,npre); FSTAT_MX(2,nn); FSTAT_MX(3,n0); FSTAT_MX(4,npool); FSTAT_MX(5,nlinks); FSTAT_MX(6,nwF); FSTAT_MX(7,nwR);
-		FSTAT_MX(8,rstop); FSTAT_MX(9,nF); FSTAT_MX(10,nL); FSTAT_ADD(11,1); FSTAT_MX(12,nc);
+		FSTAT_MX(8,rstop); FSTAT_MX(9,nF); FSTAT_MX(10,nL); FSTAT_ADD(11,1); FSTAT_MX(12,nc); FSTAT_ADD(24,nc ? 0u : 1u);
 #if defined(DACC_EMUL)
 		if ( lane == 0 ) { FILE * f = ftrav_file(); if ( f ) { uint32_t nlv = 0; for ( uint32_t i = 0; i < nL; ++i ) nlv += L.lnode()[i] != 0xFFFF; fprintf(f,"%d %u %u %u %u %u %u %u %u %u %u %u %u\n",int(CT::maxs),mao,npre,nn,n0,npool,nF,nL,nlv,rstop,nwF,nwR,nc); fflush(f); } }
 #endif

@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include "../../include/daccord_hip.h"
 
 namespace {
@@ -333,7 +334,7 @@ struct Worker
 
 struct dacc_eprof
 {
-	Store R; int32_t tspace; bool twodb; Acc A; std::string err;
+	Store R; int32_t tspace; bool twodb; Acc A; std::string err; uint64_t skipped = 0;
 };
 
 extern "C" {
@@ -341,45 +342,69 @@ extern "C" {
 int dacc_eprof_create(dacc_eprof ** out, int32_t tspace, uint8_t const * bps, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads, int two_databases)
 {
 	if ( !out || !bps || !boff || !rlen || tspace <= 0 ) return DACC_EINVAL;
-	dacc_eprof * e = new (std::nothrow) dacc_eprof; if ( !e ) return DACC_ENOMEM;
+	dacc_eprof * e = 0;
+	try { e = new dacc_eprof; } catch ( ... ) { return DACC_ENOMEM; }
 	e->R.bps = bps; e->R.boff = boff; e->R.rlen = rlen; e->R.nreads = nreads; e->tspace = tspace; e->twodb = two_databases != 0;
 	*out = e; return DACC_OK;
 }
 void dacc_eprof_destroy(dacc_eprof * e) { delete e; }
 
+// A malformed pile (record outside the database, trace values that do not add up, overlaps of different A reads or not
+// sorted by abpos) is skipped, as the correction path drops only that pile (batch_plan.hpp) and the reference logs one read
+// and goes on (daccord.cpp:2464-2478); nothing is thrown across the ABI, worker exceptions end the call with DACC_ENOMEM.
 int dacc_eprof_add(dacc_eprof * e, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl,
 	void const * trace, uint64_t ntrace, int trace_bytes, uint64_t maxalign, int nthreads)
 {
 	if ( !e || (npiles && (!piles || !ovl || !trace)) || (trace_bytes != 1 && trace_bytes != 2) ) return DACC_EINVAL;
-	for ( uint64_t i = 0; i < npiles; ++i )
+	try
 	{
-		if ( piles[i].first_ovl + piles[i].novl > novl ) return DACC_EINVAL;
-		for ( uint32_t z = 0; z < piles[i].novl; ++z )
+		std::vector<uint8_t> good(npiles,1);
+		for ( uint64_t i = 0; i < npiles; ++i )
 		{
-			dacc_overlap const & o = ovl[piles[i].first_ovl+z];
-			if ( o.aread < 0 || static_cast<uint64_t>(o.aread) >= e->R.nreads || o.bread < 0 || static_cast<uint64_t>(o.bread) >= e->R.nreads || o.abpos < 0 || o.aepos <= o.abpos ||
-			     static_cast<uint32_t>(o.aepos) > e->R.rlen[o.aread] || o.bbpos < 0 || o.bepos < o.bbpos || static_cast<uint32_t>(o.bepos) > e->R.rlen[o.bread] || o.trace_off + o.tlen > ntrace )
-				return DACC_EINVAL;
-			int64_t const ts = e->tspace; if ( o.tlen != 2*((o.aepos+ts-1)/ts - o.abpos/ts) ) return DACC_EINVAL;
-			uint64_t bs = 0; for ( int32_t b = 0; b < o.tlen/2; ++b ) bs += Worker::tv(trace,trace_bytes,o.trace_off+2*b+1);
-			if ( static_cast<int64_t>(bs) != o.bepos-o.bbpos ) return DACC_EINVAL;
+			if ( piles[i].first_ovl + piles[i].novl > novl ) return DACC_EINVAL;     // the arrays themselves are inconsistent
+			for ( uint32_t z = 0; z < piles[i].novl && good[i]; ++z )
+			{
+				dacc_overlap const & o = ovl[piles[i].first_ovl+z];
+				bool ok = !( o.aread < 0 || static_cast<uint64_t>(o.aread) >= e->R.nreads || o.bread < 0 || static_cast<uint64_t>(o.bread) >= e->R.nreads || o.abpos < 0 || o.aepos <= o.abpos ||
+				     static_cast<uint32_t>(o.aepos) > e->R.rlen[o.aread] || o.bbpos < 0 || o.bepos < o.bbpos || static_cast<uint32_t>(o.bepos) > e->R.rlen[o.bread] || o.tlen < 0 || o.trace_off + o.tlen > ntrace );
+				ok = ok && o.aread == piles[i].aread && ( z == 0 || ovl[piles[i].first_ovl+z-1].abpos <= o.abpos );
+				if ( ok ) { int64_t const ts = e->tspace; ok = o.tlen == 2*((o.aepos+ts-1)/ts - o.abpos/ts); }
+				if ( ok )
+				{
+					uint64_t bs = 0; for ( int32_t b = 0; b < o.tlen/2; ++b ) bs += Worker::tv(trace,trace_bytes,o.trace_off+2*b+1);
+					ok = static_cast<int64_t>(bs) == o.bepos-o.bbpos;
+				}
+				if ( !ok ) good[i] = 0;
+			}
+			if ( !good[i] ) e->skipped += 1;
 		}
+		if ( nthreads < 1 ) nthreads = 1;
+		std::vector<Acc> part(nthreads); std::vector<double> eloc(npiles,0.0);
+		std::atomic<uint64_t> next(0);
+		std::atomic<int> failed(0);
+		auto body = [&](int const t)
+		{
+			try
+			{
+				Worker W(e->R,e->tspace,e->twodb,maxalign);
+				for ( uint64_t i = next++; i < npiles; i = next++ )
+					if ( good[i] ) eloc[i] = W.pile(ovl+piles[i].first_ovl,piles[i].novl,trace,trace_bytes,part[t]);
+			}
+			catch ( ... ) { failed = 1; }
+		};
+		std::vector<std::thread> T;
+		for ( int t = 1; t < nthreads; ++t )
+		{
+			try { T.emplace_back(body,t); } catch ( ... ) { break; }     // fewer threads than asked for is not an error
+		}
+		body(0);
+		for ( size_t t = 0; t < T.size(); ++t ) T[t].join();
+		if ( failed ) return DACC_ENOMEM;
+		for ( int t = 0; t < nthreads; ++t ) { for ( int q = 0; q < 4; ++q ) e->A.cnt[q] += part[t].cnt[q]; e->A.usable += part[t].usable; e->A.unusable += part[t].unusable; }
+		for ( uint64_t i = 0; i < npiles; ++i ) if ( eloc[i] != 0.0 ) e->A.eloc.push_back(eloc[i]);      // in pile order
 	}
-	if ( nthreads < 1 ) nthreads = 1;
-	std::vector<Acc> part(nthreads); std::vector<double> eloc(npiles,0.0);
-	std::atomic<uint64_t> next(0);
-	auto body = [&](int const t)
-	{
-		Worker W(e->R,e->tspace,e->twodb,maxalign);
-		for ( uint64_t i = next++; i < npiles; i = next++ )
-			eloc[i] = W.pile(ovl+piles[i].first_ovl,piles[i].novl,trace,trace_bytes,part[t]);
-	};
-	std::vector<std::thread> T;
-	for ( int t = 1; t < nthreads; ++t ) T.emplace_back(body,t);
-	body(0);
-	for ( size_t t = 0; t < T.size(); ++t ) T[t].join();
-	for ( int t = 0; t < nthreads; ++t ) { for ( int q = 0; q < 4; ++q ) e->A.cnt[q] += part[t].cnt[q]; e->A.usable += part[t].usable; e->A.unusable += part[t].unusable; }
-	for ( uint64_t i = 0; i < npiles; ++i ) if ( eloc[i] != 0.0 ) e->A.eloc.push_back(eloc[i]);      // in pile order
+	catch ( std::bad_alloc const & ) { return DACC_ENOMEM; }
+	catch ( ... ) { return DACC_ENOMEM; }
 	return DACC_OK;
 }
 

@@ -13,6 +13,11 @@
 #include <algorithm>
 #include <new>
 #include <stdexcept>
+#include <cstdlib>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <sys/types.h>
 #include "../../include/daccord_io.h"
 
 namespace {
@@ -67,15 +72,77 @@ struct dacc_db
 
 struct dacc_las
 {
-	std::string err;
-	std::vector<uint8_t> D;
+	std::string err, path;
+	int fd;
 	int64_t novl; int32_t tspace; int32_t tbytes;
-	std::vector<dacc_overlap> ovl;          // all records, .las order
-	std::vector<uint8_t> trace;             // all trace values, tbytes each
-	std::vector<uint64_t> afirst;           // index of the first record of aread (size = maxaread+2)
+	uint64_t fsize;
+	// index: byte offset of the first record of A read a (a = 0..maxaread+1; a read without records shares its
+	// successor's offset), the reference's .las index (daccord.cpp:1075-1094, DalignerIndexDecoder) kept in memory
+	std::vector<uint64_t> aoff;
 	int64_t minaread, maxaread;
+	bool index_from_sidecar;
+	std::vector<uint8_t> buf;               // bytes of the requested range
 	std::vector<dacc_pile> opiles; std::vector<dacc_overlap> oovl; std::vector<uint8_t> otrace;
+	dacc_las() : fd(-1), novl(0), tspace(0), tbytes(1), fsize(0), minaread(0), maxaread(-1), index_from_sidecar(false) {}
+	~dacc_las() { if ( fd >= 0 ) ::close(fd); }
 };
+
+namespace {
+
+// sidecar index "<las>.daidx" (our own format, little endian): magic, file size, novl, tspace, minaread, maxaread, n, aoff[n].
+// Written once (temp file + rename) by whichever process scans the .las first; -J g,G processes that start later load it
+// instead of scanning the whole file again.  DACC_LAS_INDEX=0 disables reading and writing it.
+static char const IDXMAGIC[8] = {'D','A','C','C','I','D','X','1'};
+static bool sidecarEnabled() { char const * e = std::getenv("DACC_LAS_INDEX"); return !(e && e[0] == '0'); }
+static bool loadSidecar(dacc_las & L)
+{
+	std::vector<uint8_t> D; std::string err;
+	FILE * f = std::fopen((L.path + ".daidx").c_str(),"rb");
+	if ( !f ) return false;
+	uint8_t h[56];
+	bool ok = std::fread(h,1,sizeof(h),f) == sizeof(h) && std::memcmp(h,IDXMAGIC,8) == 0;
+	if ( ok )
+	{
+		uint64_t const fs = get64(h+8); int64_t const novl = get64(h+16); int32_t const tsp = get32(h+24);
+		int64_t const mina = get64(h+32), maxa = get64(h+40); uint64_t const n = get64(h+48);
+		ok = fs == L.fsize && novl == L.novl && tsp == L.tspace && maxa >= -1 && n == static_cast<uint64_t>(maxa+2) && n < (1ull<<40);
+		if ( ok )
+		{
+			L.aoff.resize(n);
+			ok = n == 0 || std::fread(L.aoff.data(),8,n,f) == n;
+			for ( uint64_t i = 0; ok && i+1 < n; ++i ) ok = L.aoff[i] <= L.aoff[i+1];
+			ok = ok && (n == 0 || (L.aoff[0] >= 12 && L.aoff[n-1] <= L.fsize));     // bytes behind the last record are ignored
+			if ( ok ) { L.minaread = mina; L.maxaread = maxa; }
+		}
+	}
+	std::fclose(f);
+	if ( !ok ) L.aoff.clear();
+	return ok;
+}
+static void writeSidecar(dacc_las const & L)
+{
+	std::string const fn = L.path + ".daidx", tmp = fn + ".tmp." + std::to_string(static_cast<long long>(::getpid()));
+	FILE * f = std::fopen(tmp.c_str(),"wb");
+	if ( !f ) return;                      // read-only directory: every process scans for itself
+	uint8_t h[56]; std::memset(h,0,sizeof(h));
+	std::memcpy(h,IDXMAGIC,8); put64(h+8,L.fsize); put64(h+16,L.novl); put32(h+24,L.tspace); put64(h+32,L.minaread); put64(h+40,L.maxaread); put64(h+48,L.aoff.size());
+	bool ok = std::fwrite(h,1,sizeof(h),f) == sizeof(h) && (L.aoff.empty() || std::fwrite(L.aoff.data(),8,L.aoff.size(),f) == L.aoff.size());
+	ok = (std::fclose(f) == 0) && ok;
+	if ( !ok || std::rename(tmp.c_str(),fn.c_str()) != 0 ) std::remove(tmp.c_str());
+}
+// all of [off,off+n) or false
+static bool preadAll(int fd, uint8_t * dst, uint64_t n, uint64_t off)
+{
+	while ( n )
+	{
+		ssize_t const r = ::pread(fd,dst,n > (1ull<<30) ? (1ull<<30) : n,static_cast<off_t>(off));
+		if ( r <= 0 ) return false;
+		dst += r; off += r; n -= r;
+	}
+	return true;
+}
+
+}
 
 extern "C" {
 
@@ -144,52 +211,59 @@ int dacc_las_open(const char * path, dacc_las ** out)
 	if ( !path || !out ) return DACC_EINVAL;
 	dacc_las * las = new (std::nothrow) dacc_las; *out = las;
 	if ( !las ) return DACC_ENOMEM;
-	las->novl = 0; las->tspace = 0; las->tbytes = 1; las->minaread = 0; las->maxaread = -1;
-	// one pass over the file with a bounded buffer: the records go straight into the overlap / trace arrays (the file
-	// itself is never held in memory); no exception leaves this function
+	// The file is never held in memory (daccord.cpp:2133-2181 reads the byte range of a pile through the index): one
+	// sequential pass over the record headers builds the A read -> byte offset table, unless a sidecar index from an
+	// earlier run is there; dacc_las_piles then reads exactly the bytes of the A reads it is asked for.
 	try
 	{
-		FILE * f = std::fopen(path,"rb");
-		if ( !f ) { las->err = std::string("cannot open ") + path; return DACC_EINVAL; }
-		struct Closer { FILE * f; ~Closer() { std::fclose(f); } } closer = { f };
-		std::vector<char> iobuf(1u<<22); std::setvbuf(f,iobuf.data(),_IOFBF,iobuf.size());
+		las->path = path;
+		las->fd = ::open(path,O_RDONLY);
+		if ( las->fd < 0 ) { las->err = std::string("cannot open ") + path; return DACC_EINVAL; }
+		struct stat st;
+		if ( ::fstat(las->fd,&st) != 0 || st.st_size < 12 ) { las->err = "overlap file too short"; return DACC_EINVAL; }
+		las->fsize = static_cast<uint64_t>(st.st_size);
 		uint8_t hdr[12];
-		if ( std::fread(hdr,1,12,f) != 12 ) { las->err = "overlap file too short"; return DACC_EINVAL; }
+		if ( !preadAll(las->fd,hdr,12,0) ) { las->err = "overlap file too short"; return DACC_EINVAL; }
 		las->novl = get64(hdr); las->tspace = get32(hdr+8);
-		std::fseek(f,0,SEEK_END); long const fsize = std::ftell(f); std::fseek(f,12,SEEK_SET);
-		if ( las->novl < 0 || las->tspace <= 0 || fsize < 12 || static_cast<uint64_t>(las->novl) > static_cast<uint64_t>(fsize-12)/40 )
+		if ( las->novl < 0 || las->tspace <= 0 || static_cast<uint64_t>(las->novl) > (las->fsize-12)/40 )
 		{ las->err = "bad overlap file header"; return DACC_EINVAL; }
 		las->tbytes = las->tspace <= 125 ? 1 : 2;                                  // TRACE_XOVR of align.h
-		las->ovl.reserve(las->novl);
-		las->trace.reserve(static_cast<size_t>(fsize-12) - static_cast<size_t>(las->novl)*40);
-		int64_t prev = -1;
-		uint64_t left = static_cast<uint64_t>(fsize-12);
+		if ( sidecarEnabled() && loadSidecar(*las) ) { las->index_from_sidecar = true; return DACC_OK; }
+		// scan: record headers through a 16 MB window, trace bytes are skipped (not copied anywhere)
+		uint64_t const W = 1ull<<24;
+		std::vector<uint8_t> win(W);
+		uint64_t wlo = 0, whi = 0;           // file range held in win
+		uint64_t pos = 12; int64_t prev = -1;
+		std::vector<uint64_t> & aoff = las->aoff;
 		for ( int64_t i = 0; i < las->novl; ++i )
 		{
-			uint8_t r[40];
-			if ( left < 40 || std::fread(r,1,40,f) != 40 ) { las->err = "overlap file truncated"; return DACC_EINVAL; }
-			left -= 40;
-			dacc_overlap o; std::memset(&o,0,sizeof(o));
-			o.tlen = get32(r+0); o.diffs = get32(r+4); o.abpos = get32(r+8); o.bbpos = get32(r+12); o.aepos = get32(r+16); o.bepos = get32(r+20);
-			uint32_t fl; std::memcpy(&fl,r+24,4); o.flags = fl; o.aread = get32(r+28); o.bread = get32(r+32);
-			size_t const tb = static_cast<size_t>(o.tlen < 0 ? 0 : o.tlen)*las->tbytes;
-			if ( o.tlen < 0 || tb > left ) { las->err = "overlap file truncated (trace)"; return DACC_EINVAL; }
-			if ( o.aread < 0 || o.bread < 0 ) { las->err = "negative read id in an overlap record"; return DACC_EINVAL; }
-			o.trace_off = las->trace.size()/las->tbytes;
-			size_t const t0 = las->trace.size(); las->trace.resize(t0+tb);
-			if ( tb && std::fread(las->trace.data()+t0,1,tb,f) != tb ) { las->err = "overlap file truncated (trace)"; return DACC_EINVAL; }
-			left -= tb;
-			if ( o.aread < prev ) { las->err = "records are not sorted by A read"; return DACC_EINVAL; }
-			prev = o.aread;
-			las->ovl.push_back(o);
+			if ( pos + 40 > las->fsize ) { las->err = "overlap file truncated"; return DACC_EINVAL; }
+			if ( pos < wlo || pos + 40 > whi )
+			{
+				uint64_t const n = std::min<uint64_t>(W,las->fsize-pos);
+				if ( !preadAll(las->fd,win.data(),n,pos) ) { las->err = "read error on the overlap file"; return DACC_EINVAL; }
+				wlo = pos; whi = pos + n;
+			}
+			uint8_t const * r = win.data() + (pos-wlo);
+			int32_t const tlen = get32(r+0), aread = get32(r+28), bread = get32(r+32);
+			uint64_t const tb = static_cast<uint64_t>(tlen < 0 ? 0 : tlen)*las->tbytes;
+			if ( tlen < 0 || pos + 40 + tb > las->fsize ) { las->err = "overlap file truncated (trace)"; return DACC_EINVAL; }
+			if ( aread < 0 || bread < 0 ) { las->err = "negative read id in an overlap record"; return DACC_EINVAL; }
+			if ( aread < prev ) { las->err = "records are not sorted by A read"; return DACC_EINVAL; }
+			if ( aread != prev )
+			{
+				if ( prev < 0 ) las->minaread = aread;
+				aoff.resize(static_cast<size_t>(aread)+1,pos);     // reads without records (prev+1..aread-1) share this offset
+				prev = aread;
+			}
+			pos += 40 + tb;
 		}
 		if ( las->novl )
 		{
-			las->minaread = las->ovl.front().aread; las->maxaread = las->ovl.back().aread;
-			las->afirst.assign(las->maxaread+2,las->ovl.size());
-			for ( size_t i = las->ovl.size(); i-- > 0; ) las->afirst[las->ovl[i].aread] = i;
-			for ( int64_t a = las->maxaread; a >= 0; --a ) if ( las->afirst[a] > las->afirst[a+1] ) las->afirst[a] = las->afirst[a+1];
+			las->maxaread = prev;
+			aoff.push_back(pos);
 		}
+		if ( sidecarEnabled() && las->novl ) writeSidecar(*las);
 	}
 	catch ( std::bad_alloc const & ) { las->err = "out of memory"; return DACC_ENOMEM; }
 	catch ( std::exception const & ex ) { las->err = ex.what(); return DACC_EINVAL; }
@@ -212,21 +286,34 @@ int dacc_las_piles(dacc_las * las, int64_t afirst, int64_t alast, const dacc_pil
 	las->opiles.clear(); las->oovl.clear(); las->otrace.clear();
 	if ( afirst < 0 ) afirst = 0;
 	if ( alast > las->maxaread+1 ) alast = las->maxaread+1;
-	for ( int64_t a = afirst; a < alast; ++a )
+	if ( afirst < alast )
 	{
-		uint64_t const lo = las->afirst[a], hi = las->afirst[a+1];
-		if ( lo == hi ) continue;
-		dacc_pile P; P.aread = a; P.novl = hi-lo; P.first_ovl = las->oovl.size();
-		for ( uint64_t i = lo; i < hi; ++i )
+		uint64_t const lo = las->aoff[afirst], hi = las->aoff[alast];
+		las->buf.resize(hi-lo);
+		if ( hi > lo && !preadAll(las->fd,las->buf.data(),hi-lo,lo) ) { las->err = "read error on the overlap file"; return DACC_EINVAL; }
+		uint64_t pos = 0; uint64_t const n = hi-lo;
+		int64_t cur = -1;
+		while ( pos < n )
 		{
-			dacc_overlap o = las->ovl[i];
-			size_t const tb = static_cast<size_t>(o.tlen)*las->tbytes;
-			uint8_t const * src = las->trace.data() + o.trace_off*las->tbytes;
+			if ( pos + 40 > n ) { las->err = "overlap file changed under the index (record header)"; return DACC_EINVAL; }
+			uint8_t const * r = las->buf.data() + pos;
+			dacc_overlap o; std::memset(&o,0,sizeof(o));
+			o.tlen = get32(r+0); o.diffs = get32(r+4); o.abpos = get32(r+8); o.bbpos = get32(r+12); o.aepos = get32(r+16); o.bepos = get32(r+20);
+			uint32_t fl; std::memcpy(&fl,r+24,4); o.flags = fl; o.aread = get32(r+28); o.bread = get32(r+32);
+			uint64_t const tb = static_cast<uint64_t>(o.tlen < 0 ? 0 : o.tlen)*las->tbytes;
+			if ( o.tlen < 0 || pos + 40 + tb > n || o.aread < afirst || o.aread >= alast || o.aread < cur || o.bread < 0 )
+			{ las->err = "overlap file changed under the index (record)"; return DACC_EINVAL; }
+			if ( o.aread != cur )
+			{
+				dacc_pile P; P.aread = o.aread; P.novl = 0; P.first_ovl = las->oovl.size();
+				las->opiles.push_back(P); cur = o.aread;
+			}
 			o.trace_off = las->otrace.size()/las->tbytes;
-			las->otrace.insert(las->otrace.end(),src,src+tb);
+			las->otrace.insert(las->otrace.end(),r+40,r+40+tb);
 			las->oovl.push_back(o);
+			las->opiles.back().novl += 1;
+			pos += 40 + tb;
 		}
-		las->opiles.push_back(P);
 	}
 	*piles = las->opiles.data(); *npiles = las->opiles.size(); *ovl = las->oovl.data(); *novl = las->oovl.size();
 	*trace = las->otrace.data(); *ntrace = las->otrace.size()/las->tbytes;

@@ -69,7 +69,7 @@ def write_db(path, bps, boff, rlen):
 
 
 class LasFile:
-    """A DALIGNER .las file loaded in memory with its aread -> records table."""
+    """A DALIGNER .las file on disk with its A read -> byte offset table (the records are read per requested range)."""
 
     def __init__(self, path):
         self.L = lib(); self.h = C.c_void_p()

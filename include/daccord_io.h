@@ -39,12 +39,15 @@ int  dacc_db_write(const char *path, const uint8_t *bps, uint64_t bps_bytes,
 
 /* ---- overlaps: replaces OverlapParser + the .las index (daccord.cpp:1075-1094, 2133-2160) ---- */
 
-/* Loads the file and builds the aread -> records table in memory (records must be contiguous per aread). */
+/* Opens the file and builds the A read -> byte offset table (one sequential pass over the record headers, or the sidecar
+ * index <path>.daidx an earlier run left; DACC_LAS_INDEX=0 in the environment turns the sidecar off).  The records
+ * themselves stay on disk: records must be sorted by A read, as LAsort leaves them. */
 int  dacc_las_open(const char *path, dacc_las **las);
 void dacc_las_close(dacc_las *las);
 int  dacc_las_info(dacc_las *las, int64_t *novl, int32_t *tspace, int32_t *trace_bytes,
                    int64_t *min_aread, int64_t *max_aread);
-/* Piles of the A reads in [afirst,alast) in .las order (not yet top-D selected: see dacc_pile_select).
+/* Piles of the A reads in [afirst,alast) in .las order (not yet top-D selected: see dacc_pile_select): reads exactly the
+ * byte range of these A reads from the file (daccord.cpp:2133-2181 does the same per pile through the .las index).
  * Output arrays are owned by the handle and valid until the next call / close. */
 int  dacc_las_piles(dacc_las *las, int64_t afirst, int64_t alast,
                     const dacc_pile **piles, uint64_t *npiles,

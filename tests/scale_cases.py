@@ -9,6 +9,18 @@ CASES = {
     # config 2 of BASELINE.json = bench.py's default data set (seed 3); the first 1000 of its 10 000 piles
     "cfg2": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=1000,
                  params=[dict(k=14)]),
+    # config 2 again, stratified over the whole 10 000-pile batch: the first 62 piles, 125 piles around each
+    # of the seven interior boundaries of the eight per-XCD window queues ((n*q)>>3, capi.hip next_window) and the last 125
+    "cfg2s": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
+                  pile_ranges=[[0, 62]] + [[1250 * q - 62, 1250 * q + 63] for q in range(1, 8)] + [[9875, 10000]],
+                  params=[dict(k=14)]),
+    # config 3 stand-in (D. melanogaster 20x is 140 Mbase; the files are not in the container): a 100-pile slice of a 20x set
+    # with a larger genome and longer reads than config 2
+    "cfg3": dict(genome_len=7000000, nreads=10000, read_len=14000, seed=7, synth={}, first=4000, npiles=100,
+                 params=[dict(k=14)]),
+    # config 4 shape again, 200 piles of a 54x set (cfg4 above is a 50-pile slice)
+    "cfg4b": dict(genome_len=222222, nreads=1200, read_len=10000, seed=14, synth={}, first=500, npiles=200,
+                  params=[dict(k=14)]),
     # config 1 stand-in at the reference's default k (the E. coli files are not in the container)
     "cfg1k8": dict(genome_len=500000, nreads=1000, read_len=10000, seed=2, synth={}, first=0, npiles=100,
                    params=[dict(k=8)]),
@@ -25,7 +37,10 @@ def make_case(case, pile_select):
     from daccord_amd.synth import SynthData
     d = SynthData(case["genome_len"], case["nreads"], case["read_len"], seed=case["seed"], **case["synth"])
     ovl, piles = pile_select(d.ovl, d.piles)
-    sel = piles[case["first"]:case["first"] + case["npiles"]]
+    if "pile_ranges" in case:
+        sel = np.concatenate([piles[a:b] for a, b in case["pile_ranges"]])
+    else:
+        sel = piles[case["first"]:case["first"] + case["npiles"]]
     return d, ovl, piles, sel
 
 

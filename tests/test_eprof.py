@@ -47,3 +47,18 @@ def test_estimator_with_two_byte_trace_values():
     cx, ux, nx, prx = dio.estimate_profile(d.bps, d.boff, d.rlen, 200, piles[:n], ovl, d.trace, trace_bytes=2, nthreads=3)
     assert list(co) == list(cx) and (uo, no) == (ux, nx) and pro == prx
     assert ux > 50
+
+
+def test_estimator_skips_a_malformed_pile():
+    """One pile with a broken record (trace values that do not add up to the B span) must not end the estimation: the
+    result equals the estimate over the other piles (the correction path drops only that pile too)."""
+    d = SynthData(60000, 120, 3000, seed=1)
+    ovl, piles = dio.select_lowest(d.ovl, d.piles)
+    n = 12
+    bad = ovl.copy()
+    z = int(piles[3]["first_ovl"]) + 1
+    bad[z]["bepos"] += 7
+    good_piles = np.concatenate([piles[:3], piles[4:n]])
+    c0, u0, n0, p0 = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, good_piles, ovl, d.trace, nthreads=2)
+    c1, u1, n1, p1 = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:n], bad, d.trace, nthreads=2)
+    assert list(c0) == list(c1) and (u0, n0) == (u1, n1) and p0 == p1
