@@ -328,7 +328,37 @@ static inline void fstats_dump(int const tier)
 static inline FILE * ftrav_file() { static FILE * f = 0; static bool tried = false; if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_TRAV"); if ( fn ) f = fopen(fn,"w"); } return f; }
 #define FSTAT_MX(i,x) g_fstats.mx(i,x)
 #define FSTAT_ADD(i,x) g_fstats.add(i,x)
+// design aid (DACC_EMUL_FEAS=<file>): per traversal the feasibility tasks' iteration counts, grouped as the 64 lanes would run them
+#include <vector>
+#include <algorithm>
+struct FeasIters { std::vector<uint32_t> it, ln; void clear() { it.clear(); ln.clear(); } };
+static FeasIters g_feasit;
+static inline void feasit_dump()
+{
+	static FILE * f = 0; static bool tried = false;
+	if ( !tried ) { tried = true; char const * fn = getenv("DACC_EMUL_FEAS"); if ( fn ) f = fopen(fn,"w"); }
+	if ( !f ) { g_feasit.clear(); return; }
+	std::vector<uint32_t> const & it = g_feasit.it; std::vector<uint32_t> const & ln = g_feasit.ln;
+	uint64_t tot = 0, lock = 0, locksorted = 0;
+	for ( size_t i = 0; i < it.size(); ++i ) tot += it[i];
+	for ( size_t i = 0; i < it.size(); i += 64 ) { uint32_t m = 0; for ( size_t q = i; q < it.size() && q < i+64; ++q ) m = std::max(m,it[q]); lock += m; }
+	std::vector< std::pair<uint32_t,uint32_t> > P; for ( size_t i = 0; i < it.size(); ++i ) P.push_back(std::make_pair(ln[i],it[i]));
+	std::stable_sort(P.begin(),P.end(),[](std::pair<uint32_t,uint32_t> const & a, std::pair<uint32_t,uint32_t> const & b){ return a.first > b.first; });
+	for ( size_t i = 0; i < P.size(); i += 64 ) { uint32_t m = 0; for ( size_t q = i; q < P.size() && q < i+64; ++q ) m = std::max(m,P[q].second); locksorted += m; }
+	uint64_t lockcls = 0;
+	{
+		std::vector< std::pair<uint32_t,uint32_t> > Q; for ( size_t i = 0; i < it.size(); ++i ) { uint32_t c = 0; while ( (2u<<c) <= ln[i] ) ++c; Q.push_back(std::make_pair(c,it[i])); }
+		std::stable_sort(Q.begin(),Q.end(),[](std::pair<uint32_t,uint32_t> const & a, std::pair<uint32_t,uint32_t> const & b){ return a.first > b.first; });
+		for ( size_t i = 0; i < Q.size(); i += 64 ) { uint32_t m = 0; for ( size_t q = i; q < Q.size() && q < i+64; ++q ) m = std::max(m,Q[q].second); lockcls += m; }
+	}
+	fprintf(f,"%zu %llu %llu %llu %llu\n",it.size(),(unsigned long long)tot,(unsigned long long)lock,(unsigned long long)locksorted,(unsigned long long)lockcls);
+	g_feasit.clear();
+}
+#define FEAS_ITERS(t,len,n) { g_feasit.it.push_back(n); g_feasit.ln.push_back(len); }
+#define FEAS_DUMP() feasit_dump();
 #else
+#define FEAS_ITERS(t,len,n)
+#define FEAS_DUMP()
 #define FSTAT_MX(i,x)
 #define FSTAT_ADD(i,x)
 #endif
@@ -1181,12 +1211,13 @@ struct FastEngine
 					uint64_t U = L.tab()[ip_a*stride + pc];
 					for ( uint32_t q = 1; q < f_a; ++q ) U += L.tab()[static_cast<uint32_t>(IP[i0_a+q])*stride + pc];
 #endif
-					if ( U < FW_THRES_FEAS ) { ok = false; break; }
+					if ( U < FW_THRES_FEAS ) { ok = false; FEAS_ITERS(t,len,j+1) break; }
 					sum += U;
 					if ( j == 0 ) f1 = U;
 					fl = U;
 					i0_a = i0_b; f_a = f_b; ip_a = ip_b; i0_b = i0_c; f_b = f_c; z_c = z_d;
 				}
+				if ( ok ) { FEAS_ITERS(t,len,len) }
 				#undef DACC_LKN
 			}
 			// append the feasible ones: forward tasks precede reverse tasks, the tasks of a stretch are consecutive
@@ -1228,8 +1259,9 @@ struct FastEngine
 				}
 			}
 			nwF += dacc_popc64(okb & ~revb); nwR += dacc_popc64(okb & revb);
-			if ( nwF > CT::wcap || nwR > CT::wcap ) { over(128); return; }
+			if ( nwF > CT::wcap || nwR > CT::wcap ) { over(128); FEAS_DUMP() return; }
 		}
+		FEAS_DUMP()
 		wv_sync();
 	}
 	// weights of feasible (stretch, position) entry i.  A node weight is a sum of at most 255 table words (< 2^40), a

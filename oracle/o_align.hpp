@@ -23,8 +23,31 @@
 #include <cstdint>
 #include <algorithm>
 #include <utility>
+#include <cstdlib>
 
 namespace oracle {
+
+/*
+ * Exposure switches (scripts/exposure_report.py): every choice this restatement had to make where
+ * libmaus2 defines the behaviour can be flipped through the environment, so that the share of the output that depends
+ * on the choice can be MEASURED.  Defaults (all unset / 0) are the documented definitions above; nothing in the product
+ * reads these.
+ *   ORACLE_TB_BLOCK / ORACLE_TB_CONS  traceback priority of the block alignments (computeTrace) / of the consensus -> A
+ *                                     alignment: 0 diag>del>ins (default), 1 diag>ins>del, 2 del>diag>ins, 3 ins>diag>del,
+ *                                     4 del>ins>diag, 5 ins>del>diag
+ *   ORACLE_HEAP_TIE                   0 default; 1: sift-up swaps on <= (equal keys rise); 2: sift-down prefers the right
+ *                                     child among equal children; 3: both
+ *   ORACLE_KLIM_DELTA                 added to binomRowUpperLimit (-1, 0, +1)
+ *   ORACLE_CONV                       0 double, ascending index (default); 1 long double accumulation; 2 descending index
+ */
+struct Variant
+{
+	int tb_block, tb_cons, heap_tie, klim_delta, conv;
+	static int envi(char const * n) { char const * e = std::getenv(n); return e ? std::atoi(e) : 0; }
+	Variant() : tb_block(envi("ORACLE_TB_BLOCK")), tb_cons(envi("ORACLE_TB_CONS")), heap_tie(envi("ORACLE_HEAP_TIE")),
+		klim_delta(envi("ORACLE_KLIM_DELTA")), conv(envi("ORACLE_CONV")) {}
+};
+inline Variant const & variant() { static Variant const V; return V; }
 
 enum Step : uint8_t { STEP_MATCH = 0, STEP_MISMATCH = 1, STEP_INS = 2, STEP_DEL = 3 };
 
@@ -34,7 +57,7 @@ struct Aligner
 	std::vector<uint8_t> trace; // forward order after align()
 
 	// returns edit distance; trace holds the edit script
-	uint64_t align(uint8_t const * a, uint64_t const m, uint8_t const * b, uint64_t const n)
+	uint64_t align(uint8_t const * a, uint64_t const m, uint8_t const * b, uint64_t const n, int const order = 0)
 	{
 		uint64_t const W = n+1;
 		D.resize((m+1)*W);
@@ -55,15 +78,24 @@ struct Aligner
 		}
 		trace.clear();
 		uint64_t i = m, j = n;
+		// move priority: 0 = diagonal, 1 = up (DEL), 2 = left (INS), tried in the order the variant names
+		static int const ORD[6][3] = { {0,1,2}, {0,2,1}, {1,0,2}, {2,0,1}, {1,2,0}, {2,1,0} };
+		int const * const ord = ORD[(order >= 0 && order < 6) ? order : 0];
 		while ( i || j )
 		{
 			uint16_t const d = D[i*W+j];
-			if ( i && j && D[(i-1)*W+(j-1)] + (a[i-1] != b[j-1]) == d )
+			bool const okd = i && j && D[(i-1)*W+(j-1)] + (a[i-1] != b[j-1]) == d;
+			bool const oku = i && D[(i-1)*W+j] + 1 == d;
+			bool const okl = j && D[i*W+(j-1)] + 1 == d;
+			int mv = -1;
+			for ( int q = 0; q < 3 && mv < 0; ++q )
+				if ( (ord[q] == 0 && okd) || (ord[q] == 1 && oku) || (ord[q] == 2 && okl) ) mv = ord[q];
+			if ( mv == 0 )
 			{
 				trace.push_back( (a[i-1] == b[j-1]) ? STEP_MATCH : STEP_MISMATCH );
 				--i; --j;
 			}
-			else if ( i && D[(i-1)*W+j] + 1 == d )
+			else if ( mv == 1 )
 			{
 				trace.push_back(STEP_DEL);
 				--i;

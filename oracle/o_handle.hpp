@@ -148,7 +148,7 @@ static inline void computeTrace(dacc_overlap const & o, void const * trace, int 
 		int64_t const a_i_1 = std::min<int64_t>(a_i+tspace,o.aepos);
 		int64_t const b_i_1 = b_i + traceValue(trace,trace_bytes,o.trace_off+2*i+1);
 		int64_t const as = std::max<int64_t>(a_i,o.abpos);
-		NP.align(aptr+as,a_i_1-as,bptr+b_i,b_i_1-b_i);
+		NP.align(aptr+as,a_i_1-as,bptr+b_i,b_i_1-b_i,variant().tb_block);
 		out.insert(out.end(),NP.trace.begin(),NP.trace.end());
 		b_i = b_i_1;
 		a_i = a_i_1;
@@ -394,7 +394,7 @@ struct HandleContext
 					std::memcpy(wr.cons,cdata,std::min<uint64_t>(clen,sizeof(wr.cons)-1));
 
 					// :2429-2493
-					NP.align(w_ua,windowsize,cdata,clen);
+					NP.align(w_ua,windowsize,cdata,clen,variant().tb_cons);
 					uint64_t apos = astart;
 					uint8_t const * ta = NP.trace.data();
 					uint8_t const * te = ta + NP.trace.size();

@@ -22,6 +22,7 @@
 #include <functional>
 #include <cstddef>
 #include <cassert>
+#include "o_align.hpp"   // variant()
 
 namespace oracle {
 
@@ -47,7 +48,7 @@ struct FiniteSizeHeap
 		while ( i )
 		{
 			size_t const p = (i-1) >> 1;
-			if ( cmp(H[i],H[p]) )
+			if ( cmp(H[i],H[p]) || ((variant().heap_tie & 1) && !cmp(H[p],H[i])) )
 			{
 				std::swap(H[i],H[p]);
 				i = p;
@@ -72,7 +73,7 @@ struct FiniteSizeHeap
 		size_t r;
 		while ( (r = 2*i+2) < f )
 		{
-			size_t const m = cmp(H[r-1],H[r]) ? (r-1) : r;
+			size_t const m = (variant().heap_tie & 2) ? (cmp(H[r],H[r-1]) ? r : (cmp(H[r-1],H[r]) ? (r-1) : r)) : (cmp(H[r-1],H[r]) ? (r-1) : r);
 			if ( cmp(H[i],H[m]) )
 				return;
 			std::swap(H[i],H[m]);

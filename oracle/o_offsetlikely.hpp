@@ -29,6 +29,7 @@
 #include <utility>
 #include <algorithm>
 #include <limits>
+#include "o_align.hpp"   // variant()
 
 namespace oracle {
 
@@ -157,12 +158,27 @@ inline std::vector<double> convolve(std::vector<double> const & x, std::vector<d
 	std::vector<double> r(x.size()+y.size()-1);
 	for ( uint64_t n = 0; n < r.size(); ++n )
 	{
-		double s = 0.0;
 		uint64_t const ilow = (n >= y.size()-1) ? (n-(y.size()-1)) : 0;
 		uint64_t const ihigh = std::min<uint64_t>(n,x.size()-1);
-		for ( uint64_t i = ilow; i <= ihigh; ++i )
-			s += x[i]*y[n-i];
-		r[n] = s;
+		if ( variant().conv == 1 )
+		{
+			long double s = 0.0L;
+			for ( uint64_t i = ilow; i <= ihigh; ++i ) s += static_cast<long double>(x[i])*static_cast<long double>(y[n-i]);
+			r[n] = static_cast<double>(s);
+		}
+		else if ( variant().conv == 2 )
+		{
+			double s = 0.0;
+			for ( uint64_t i = ihigh+1; i-- > ilow; ) s += x[i]*y[n-i];
+			r[n] = s;
+		}
+		else
+		{
+			double s = 0.0;
+			for ( uint64_t i = ilow; i <= ihigh; ++i )
+				s += x[i]*y[n-i];
+			r[n] = s;
+		}
 	}
 	return r;
 }
@@ -273,7 +289,11 @@ struct KmerLimit
 		if ( p_k )
 		{
 			while ( !(i < Vlim.size()) )
-				Vlim.push_back(binomRowUpperLimit(p_k,Vlim.size(),0.99));
+			{
+				int64_t v = static_cast<int64_t>(binomRowUpperLimit(p_k,Vlim.size(),0.99)) + variant().klim_delta;
+				if ( v < 0 ) v = 0;
+				Vlim.push_back(static_cast<uint64_t>(v));
+			}
 			return Vlim[i];
 		}
 		else
