@@ -158,18 +158,27 @@ def main():
                 "window_ms_all_tiers": round(wsum / args.steps, 3),
                 "windows_handed_on": {"tier1": touts[0], "tier2": touts[1], "tier3_to_generic": touts[2]}}
         # HBM traffic and issue counters of the dominant kernel from the PMC passes (rocprofv3 --pmc, separate runs,
-        # scripts/gpu_pmc.sh -> profiles/r02_pmc_summary.json): only quoted when collected on this very workload
+        # scripts/gpu_pmc.sh -> profiles/<round>_pmc_summary.json): quoted only when they were collected on this very
+        # workload AND on the very kernel sources this build was made from (csrc_hash) -- never stale counters
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-            wl = pm["workload"]
-            if (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) == (args.reads, args.readlen, args.coverage, args.k) and dom in pm["kernels"]:
+            import glob
+            from daccord_amd import build as _build
+            cur = _build.csrc_hash()
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+                pm = json.load(open(fn))
+                wl = pm["workload"]
+                if pm.get("csrc_hash") != cur or (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) != (args.reads, args.readlen, args.coverage, args.k) or dom not in pm["kernels"]:
+                    continue
                 kk = pm["kernels"][dom]
                 roof["traffic"] = int(kk["traffic_bytes_per_launch"])
                 for key in ("valu_issue_frac", "salu_issue_frac", "lds_issue_frac", "wait_frac", "resident_waves_per_cu", "pmc_kernel_ms"):
                     if key in kk:
                         roof[key] = kk[key]
                 roof["traffic_all_kernels"] = {k: int(v["traffic_bytes_per_launch"]) for k, v in pm["kernels"].items()}
-                roof["pmc_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this workload)"
+                roof["pmc_source"] = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this workload, csrc %s)" % (os.path.basename(fn), cur)
+                break
+            else:
+                roof["pmc_source"] = "none for this build (csrc %s): traffic is null until scripts/gpu_pmc.sh has run on it" % cur
         except Exception:
             pass
         res = {
@@ -194,16 +203,36 @@ def main():
                 h.update(engine.fasta(fr[i:i + 256], ba, start_well=well).encode()); well += len(fr[i:i + 256])
             return h.hexdigest()
         par = {"gpu_fasta_sha256_all": fasta_sha256(allfr, allba), "piles_all": int(len(allpiles))}
-        gold = os.path.join(ROOT, "tests", "golden", "scale_cfg2.json")
+        # The oracle's committed digests (build container, tests/golden/make_golden_scale.py): piles STRATIFIED over the whole
+        # batch -- the first 62, 125 around each of the seven interior boundaries of the eight per-XCD window queues, the last
+        # 125 (scale_cfg2s.json) -- and, if present, the first 1000 piles (scale_cfg2.json); default workload only.  Other
+        # workloads of the same generator: --coverage 54 / --ont against their own fixtures when the shapes match.
         default_set = (total_reads, args.readlen, args.coverage, args.k, args.seed, args.ont) == (10000, 10000, 20.0, 14, 3, False)
-        if default_set and os.path.exists(gold):
-            G = json.load(open(gold))["runs"][0]
-            n = G["npiles"]
-            lim = int(allpiles[n - 1]["aread"])
-            sel = allfr[allfr["aread"] <= lim]
+        def compare_golden(name):
+            gold = os.path.join(ROOT, "tests", "golden", "scale_%s.json" % name)
+            if not os.path.exists(gold):
+                return None
+            GG = json.load(open(gold)); G = GG["runs"][0]; spec = GG["spec"]
+            ranges = spec.get("pile_ranges") or [[spec["first"], spec["first"] + spec["npiles"]]]
+            idx = np.concatenate([np.arange(a, b) for a, b in ranges])
+            areads = allpiles["aread"][idx]
+            sel = allfr[np.isin(allfr["aread"], areads)]
             h = fasta_sha256(sel, allba)
-            par.update({"piles_compared": n, "gpu_fasta_sha256": h, "oracle_fasta_sha256": G["fasta_sha256"], "identical": h == G["fasta_sha256"],
-                        "oracle_source": "tests/golden/scale_cfg2.json (oracle run in the build container, tests/golden/make_golden_scale.py)"})
+            out = {"fixture": "tests/golden/scale_%s.json" % name, "piles_compared": int(len(idx)), "pile_ranges": ranges,
+                   "gpu_fasta_sha256": h, "oracle_fasta_sha256": G["fasta_sha256"], "identical": h == G["fasta_sha256"]}
+            if not out["identical"] and "pile_sha256" in G:
+                bad = []
+                for j, a in enumerate(areads):
+                    f = allfr[allfr["aread"] == a]
+                    if hashlib.sha256(engine.fasta(f, allba).encode()).hexdigest()[:12] != G["pile_sha256"][j]:
+                        bad.append(int(idx[j]))
+                out["piles_that_differ"] = bad[:50]
+            return out
+        if default_set:
+            cmp_ = [c for c in (compare_golden("cfg2s"), compare_golden("cfg2")) if c]
+            if cmp_:
+                par.update({"piles_compared": int(sum(c["piles_compared"] for c in cmp_)), "identical": all(c["identical"] for c in cmp_), "fixtures": cmp_,
+                            "oracle_source": "oracle run in the build container (tests/golden/make_golden_scale.py); stratified over all eight queue ranges of the batch"})
         res["parity"] = par
         # ---- accuracy against the known truth of the synthetic reads (checkconsensus measurement, README.md:406-472):
         # the only quality figure that does not depend on the oracle ----

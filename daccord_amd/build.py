@@ -13,6 +13,17 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-Wno-unused-value"]
 
 
+def csrc_hash():
+    """SHA-256 (16 hex digits) over the kernel and host sources: recorded with PMC summaries (scripts/pmc_summarize.py) so
+    that bench.py quotes counters only when they were collected on the very code it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, srcs):
     return (not os.path.exists(target)) or os.path.getmtime(target) < max(os.path.getmtime(s) for s in srcs)
 

@@ -406,8 +406,8 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2;
-	uint32_t tier_grid[3], retry_grid, early_grid; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2;
+	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
 	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
@@ -468,7 +468,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release();
+	c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
 	delete c;
@@ -488,6 +488,7 @@ int dacc_set_error_profile(dacc_ctx * c, double p_i, double p_d, double est_cor)
 	if ( (rc = upload(c,c->d_dpsq,c->H.dpsq.data(),c->H.dpsq.size())) ) return rc;
 	if ( (rc = upload(c,c->d_vs,c->H.dpsq_vs.data(),c->H.dpsq_vs.size())) ) return rc;
 	if ( (rc = upload(c,c->d_vst,c->H.dpsq_vst.data(),c->H.dpsq_vst.size())) ) return rc;
+	if ( (rc = upload(c,c->d_tab32,c->H.tab32.data(),c->H.tab32.size())) ) return rc;
 	if ( (rc = upload(c,c->d_first,c->H.dpsq_first.data(),c->H.dpsq_first.size())) ) return rc;
 	if ( (rc = upload(c,c->d_size,c->H.dpsq_size.data(),c->H.dpsq_size.size())) ) return rc;
 	if ( (rc = upload(c,c->d_suplo,c->H.suplo.data(),c->H.suplo.size())) ) return rc;
@@ -578,7 +579,7 @@ static int runDevice(dacc_ctx * c)
 				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
 			HIPCHK(hipEventRecord(c->evPrescan,s));
 			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
-			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0;
+			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0; FL.gslab = 0; FL.gstride = 0; FL.tab32 = c->d_tab32.p;
 			if ( !c->tierL_ok ) FL.F.ldsbytes = 0;
 			// a launch the device refuses (the LDS of a whole CU) falls back to the generic engine alone, for good
 			auto const launchLong = [&](uint32_t const * const lst)
@@ -604,6 +605,7 @@ static int runDevice(dacc_ctx * c)
 				if ( c->tier_ok[t] )
 				{
 					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p;
+					FB.gslab = c->d_gslab.p; FB.gstride = c->gstride[t]; FB.tab32 = c->d_tab32.p;
 					// only the first tier feeds the early generic list (its kernel reads the list once, right after that tier): a
 					// window that reaches a later tier first (mao beyond the earlier tier) and turns out to be generic-only takes
 					// the ordinary hand-over chain to the generic kernel at the end
@@ -819,6 +821,9 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			if ( fg < 8 ) fg = 8;
 			c->tier_grid[t] = fg;
 			HIPCHK(c->d_retry[t].ensure(BP.nwindows+2));
+			// gw tiers: one global slab per workgroup (weights, spill); the tiers run one after the other and share the buffer
+			c->gstride[t] = F.gbytes;
+			if ( F.gbytes ) HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg)*F.gbytes + 256));
 		}
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);

@@ -60,6 +60,7 @@ struct FastCaps
 	uint32_t tabcap;             // 32-bit words the table overlay of this tier can hold
 	uint32_t nrows, nsup;        // dimensions of the fixed-point table copy held in LDS
 	uint32_t ldsbytes;
+	uint32_t gbytes;             // gw tiers: bytes of global scratch per workgroup (0: none)
 };
 
 struct FSI { uint64_t w; uint16_t left, right, current, path; };   // ScoreInterval (left/right/current: sorted reverse entries, path: forward pop index)
@@ -67,31 +68,35 @@ struct FCC { uint64_t w; uint32_t o, l; };                                      
 
 // compile time capacities of the two tiers: every LDS offset below is an instruction immediate
 template<int TIER> struct FastTier;
-#if defined(DACC_T1_LEAN)
-// occupancy experiment (scripts/gpu_r3_occ.sh): tier 1 with small capacities so that 5-6 wavefronts share a CU; used with DACC_TAB_GLOBAL
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 24, idmax = 250, rpstcap = 256, lstr = 64, maxs = 16, precap = 512, ncap = 288, scap = 48, lcap = 352, wcap = 240, rccap = 64, fcap = 48, siqcap = 56, blcap = 96 }; };
+// gw: the weights of the feasible (stretch, position) pairs and the model table live in global memory (a scratch slab per
+// workgroup / the padded 32 bit table), the build-phase arrays are overlaid by the enumeration pools (spilled to the slab
+// while the enumerations run): layout FastLds<CT,true>.  Round 3 measured that a second wavefront per SIMD hides the LDS
+// round trips of the first almost completely (profiles/r03a_occupancy_experiment.md), so LDS bytes per window decide the
+// throughput: tier 1 is 26.3 KB = 6 wavefronts per CU with (almost) the capacities it had at 53.8 KB = 3 per CU.
+#if defined(DACC_T1_LEGACY)
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 #else
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 #endif
 // DACC_T2_WCAP: experiment hook (scripts/r3_prepare_variants.sh): 1040 weights make tier 2 81 808 bytes, which still fits twice
 // into 160 KB if LDS is handed out in granules of 1280 bytes or less (unverified; 992 -> 80 512 bytes is what was measured)
 #ifndef DACC_T2_WCAP
 #define DACC_T2_WCAP 992
 #endif
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = DACC_T2_WCAP, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = DACC_T2_WCAP, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
 // small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
 // has about a hundred nodes, while the 55 strings of a window carry 1500 k-mer instances.
-template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 
 // tier 5 (one wavefront per CU, only for the windows the pre-scan found): B strings of up to 128 bases (string stride 128,
 // two words per pattern mask); everything else as tier 3 with 64 strings.  Window strings of more than 64 bases are rare
 // at the default window (a few per ten million windows of config 2) but each of them costs the generic engine seconds.
-template<> struct FastTier<5> { typedef uint16_t id_t; enum : uint32_t { rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<5> { typedef uint16_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -106,8 +111,11 @@ HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 	static constexpr uint32_t e_##name = (o_##name + static_cast<uint32_t>(sizeof(type))*static_cast<uint32_t>(count) + 7u) & ~7u; \
 	HDEV LDSQ type * name() const { return reinterpret_cast<LDSQ type *>(base + o_##name); }
 
+template<typename CT, bool GW = (CT::gw != 0)> struct FastLds;
+
+// legacy layout: everything in LDS (tiers 2-5)
 template<typename CT>
-struct FastLds
+struct FastLds<CT,false>
 {
 	LDSQ uint8_t * base;
 	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
@@ -272,12 +280,191 @@ struct FastLds
 	FLD(ulo,uint8_t,2*CT::scap,e_toff)
 	FLD(uhi,uint8_t,2*CT::scap,e_ulo)
 	FLD(tab,uint32_t,(upool-taskbytes-o_cdh)/4,o_cdh)   // also over the candidate buffers, which are dead at that time
-#if defined(DACC_TAB_GLOBAL)
-	static constexpr uint32_t tabcap = 0x7FFFFFFFu;
-#else
 	static constexpr uint32_t tabcap = (upool-taskbytes-o_cdh)/4;
-#endif
 	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
+	// scratch of the stretch construction, the candidate search and the reachability test: borrowed from the weight arrays,
+	// which are written after them.  Walk slots (wtmp) of 64 node ids each in front, the walking table behind them.
+	static_assert(6u*CT::ncap + 16u <= e_wR1_hi - o_wF_lo,"scratch tables of the stretch walk must fit the weight arrays");
+	static_assert(CT::wcap*4 >= CT::ncap*2,"interior node table must fit the weight array it borrows");
+	static_assert(2u*CT::ncap + CT::scap + 8u <= 4u*CT::wcap,"reachability scratch must fit the first weight array");
+	HDEV LDSQ uint32_t * xcnt32() const { return reinterpret_cast<LDSQ uint32_t *>(base + o_wF_lo); }
+	HDEV LDSQ uint16_t * xstep() const { return reinterpret_cast<LDSQ uint16_t *>(base + ((e_wR1_hi - 2u*CT::ncap) & ~7u)); }
+	HDEV LDSQ uint16_t * xwtmp() const { return reinterpret_cast<LDSQ uint16_t *>(base + o_wF_lo); }
+	static constexpr uint32_t xnslot = (((e_wR1_hi - 2u*CT::ncap) & ~7u) - o_wF_lo) / 128u;
+	HDEV LDSQ uint16_t * xsid() const { return reinterpret_cast<LDSQ uint16_t *>(base + o_wR_lo); }
+	HDEV LDSQ uint8_t * xspos() const { return reinterpret_cast<LDSQ uint8_t *>(base + o_wR1_lo); }
+	HDEV LDSQ uint8_t * xreach() const { return reinterpret_cast<LDSQ uint8_t *>(base + o_wF_lo); }
+};
+
+/*
+ * gw layout (tier 1 since round 3).  Three regions:
+ *   P  live during the whole window: string lengths, support bounds, serial scratch, node keys, fhead, best consensus;
+ *   S  results of the build phase that the first phases of a traversal (stretches, candidates, feasibility) and its last
+ *      ones (candidate errors, next activation state) need, but not the enumerations and the pairs in between: the
+ *      enumeration pools are laid over S, whose bytes are spilled to the workgroup's global slab before the
+ *      enumerations and restored after the pairs (two bulk copies of 12 KB per traversal);
+ *   X  overlay A (sorted instances, build phase) / overlay B (stretches, candidates, candidate heap, lane scratch).
+ * The weights of the feasible (stretch, position) pairs (16 of the 54 KB of the legacy tier 1) live in the global slab,
+ * the model table is read from its padded 32 bit copy in global memory (both stay in L1/L2).  The scratch tables of the
+ * stretch construction sit in parts of overlay B that are written later (pattern masks: raw stretches; candidate heap,
+ * sequences and lane scratch: predecessor counts, walking table, interior nodes, reachability, feasibility tasks).
+ */
+template<typename CT>
+struct FastLds<CT,true>
+{
+	LDSQ uint8_t * base;
+	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
+	static_assert((CT::precap & (CT::precap-1)) == 0,"precap must be a power of two: the bitonic sorts pad to one");
+	static_assert(sizeof(typename CT::id_t) > 1 || (CT::fcap <= 256 && CT::rccap <= 256),"pool slots are recorded as id_t (pout)");
+	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
+	static_assert(CT::lstr == 64,"the gw layout holds strings of up to 64 bases");
+	static constexpr uint32_t pw = CT::lstr/64;
+	// ---- P ----
+	FLD(slen,uint8_t,CT::maxs,0)
+	FLD(suplo8,uint8_t,FSUPCAP,e_slen)
+	FLD(suphi8,uint8_t,FSUPCAP,e_suplo8)
+	FLD(vrem,uint8_t,8,e_suphi8)
+	FLD(vadd,uint8_t,8,e_vrem)
+	FLD(vapos,uint8_t,8,e_vadd)
+	FLD(vfn,uint16_t,8,e_vapos)
+	FLD(vln,uint16_t,8,e_vfn)
+	FLD(sstack,uint16_t,3*24,e_vln)
+	FLD(chain,uint8_t,64,e_sstack)
+	FLD(nv,uint32_t,CT::ncap,e_chain)
+	FLD(npred,uint8_t,CT::ncap,e_nv)
+	FLD(bestL,uint8_t,MAXCONS,e_npred)
+	static constexpr uint32_t sbase = (e_bestL + 15u) & ~15u;
+	// ---- S (spilled while the pools are live) ----
+	FLD(str,uint8_t,CT::maxs*CT::lstr,sbase)
+	FLD(peq,uint64_t,CT::maxs*4*pw,e_str)
+	FLD(ipos,uint8_t,CT::precap,e_peq)
+	FLD(irpos,uint8_t,CT::precap,e_ipos)
+	FLD(nps,uint16_t,CT::ncap+1,e_irpos)
+	FLD(nfreq,uint8_t,CT::ncap,e_nps)
+	FLD(succ0,uint16_t,CT::ncap,e_nfreq)
+	FLD(sinfo,uint16_t,CT::ncap,e_succ0)
+	FLD(nrange,uint32_t,CT::ncap,e_sinfo)
+	FLD(mfirst,uint64_t,keycap,e_nrange)
+	FLD(mlast,uint64_t,keycap,e_mfirst)
+	static constexpr uint32_t send = (e_mlast + 15u) & ~15u;
+	static constexpr uint32_t sbytes = send - sbase;
+	// ---- enumeration pools: overlay of S ----
+	FLD(rc_w,uint64_t,CT::rccap,sbase)
+	FLD(rc_parent,typename CT::id_t,CT::rccap,e_rc_w)
+	FLD(rc_stretch,uint8_t,CT::rccap,e_rc_parent)
+	FLD(rc_pos,uint8_t,CT::rccap,e_rc_stretch)
+	FLD(rc_len,uint8_t,CT::rccap,e_rc_pos)
+	FLD(rc_baselen,uint8_t,CT::rccap,e_rc_len)
+	FLD(rc_acc,typename CT::id_t,CT::rccap,e_rc_baselen)
+	FLD(rc_ord,typename CT::id_t,CT::rccap,e_rc_acc)
+	FLD(rc_arw,typename CT::id_t,CT::rccap,e_rc_ord)
+	FLD(rc_sbl,uint8_t,CT::rccap,e_rc_arw)
+	FLD(rc_front,uint32_t,CT::rccap,e_rc_sbl)
+	FLD(rbase,uint16_t,CT::fnc+1,e_rc_front)
+	FLD(rn,uint16_t,CT::fnc+1,e_rbase)
+	FLD(rmaxw,uint64_t,CT::fnc+1,e_rn)
+	FLD(rtmask,uint64_t,CT::fnc+1,e_rmaxw)
+	FLD(rfmask,uint64_t,CT::fnc+1,e_rtmask)
+	FLD(f_w,uint64_t,CT::fcap,e_rfmask)
+	FLD(f_parent,typename CT::id_t,CT::fcap,e_f_w)
+	FLD(f_stretch,uint8_t,CT::fcap,e_f_parent)
+	FLD(f_pos,uint8_t,CT::fcap,e_f_stretch)
+	FLD(f_baselen,uint8_t,CT::fcap,e_f_pos)
+	FLD(f_len,uint8_t,CT::fcap,e_f_baselen)
+	FLD(fp_id,typename CT::id_t,CT::fcap,e_f_len)
+	FLD(fp_cl,uint8_t,CT::fcap,e_fp_id)
+	FLD(fp_front,uint32_t,CT::fcap,e_fp_cl)
+	FLD(fp_adj,uint64_t,CT::fcap,e_fp_front)
+	FLD(fchb,uint8_t,8*CT::fnw*(CT::fnc+1),e_fp_adj)
+	FLD(fnp,uint16_t,CT::fnc+1,e_fchb)
+	FLD(ffm,uint64_t,CT::fnc+1,e_fnp)
+	FLD(ftm,uint64_t,CT::fnc+1,e_ffm)
+	FLD(fmx,uint64_t,CT::fnc+1,e_ftm)
+	FLD(pout,typename CT::id_t,32*32,e_fmx)
+	FLD(poutn,uint8_t,32,e_pout)
+	FLD(ctr,uint32_t,4,e_poutn)
+	FLD(rchx,uint8_t,32,e_ctr)
+	static constexpr uint32_t upool = e_rchx;
+	static_assert(upool <= send,"the enumeration pools must fit the build-phase arrays they overlay");
+	FLD(rchb,uint8_t,(CT::fnc < 64 ? CT::fnc : 64u)*32,o_fchb)
+	static_assert(e_rchb <= o_pout,"reverse chunk lists must fit the per first k-mer tables");
+	static constexpr uint32_t ubase = send;
+	// ---- overlay A: build phase ----
+	FLD(pre,uint64_t,CT::precap,ubase)
+	FLD(lastk,uint64_t,keycap,e_pre)
+	static constexpr uint32_t uA = e_lastk;
+	// ---- overlay B: traversal ----
+	FLD(sfirst,uint16_t,CT::scap,ubase)
+	FLD(slast,uint16_t,CT::scap,e_sfirst)
+	FLD(sslen,uint16_t,CT::scap,e_slast)
+	FLD(slink,uint16_t,CT::scap,e_sslen)
+	FLD(maskF,uint64_t,CT::scap,e_slink)
+	FLD(maskR,uint64_t,CT::scap,e_maskF)
+	FLD(woffF,uint16_t,CT::scap,e_maskR)
+	FLD(woffR,uint16_t,CT::scap,e_woffF)
+	FLD(links,uint16_t,CT::lcap,e_woffR)
+	FLD(lhead,uint8_t,CT::ncap,e_links)
+	FLD(lord,uint32_t,CT::scap,e_lhead)
+	FLD(ppos,uint8_t,CT::scap,e_lord)
+	FLD(fkmer,uint32_t,CT::fnc,e_ppos)
+	FLD(lkmer,uint32_t,CT::fnc,e_fkmer)
+	FLD(fnode,uint16_t,CT::fnc,e_lkmer)
+	FLD(lnode,uint16_t,CT::fnc,e_fnode)
+	FLD(parF,uint8_t,CT::fnc,e_lnode)
+	FLD(posF,uint8_t,CT::fnc,e_parF)
+	FLD(parL,uint8_t,CT::fnc,e_posF)
+	FLD(posL,uint8_t,CT::fnc,e_parL)
+	FLD(pieF,uint8_t,CT::fnc,e_posL)
+	FLD(pieL,uint8_t,CT::fnc,e_pieF)
+	static constexpr uint32_t xbase = (e_pieL + 15u) & ~15u;
+	FLD(cdh,FCC,16,xbase)
+	FLD(cseq,uint8_t,18*FSEQCAP,e_cdh)
+	FLD(ch,FCC,16,e_cseq)
+	FLD(acc,FCC,16,e_ch)
+	FLD(accerr,uint32_t,16,e_acc)
+	FLD(canderr,uint8_t,16*CT::maxs,e_accerr)
+	FLD(consL,uint8_t,16*MAXCONS,e_canderr)
+	static constexpr uint32_t lscrbytes = 2560u*static_cast<uint32_t>(sizeof(typename CT::id_t));
+	FLD(lscr,uint8_t,lscrbytes,e_cseq)
+	FLD(siq,FSI,CT::siqcap,e_cseq)
+	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
+	static constexpr uint32_t uB = fcmax(e_consL,e_lscr);
+	static constexpr uint32_t xbytes = uB - xbase;
+	// raw stretches: over the pattern masks and weight offsets, which the feasibility writes later
+	FLD(tfirst,uint16_t,CT::scap,o_maskF)
+	FLD(tlast,uint16_t,CT::scap,e_tfirst)
+	FLD(tslen,uint16_t,CT::scap,e_tlast)
+	FLD(tlink,uint16_t,CT::scap,e_tslen)
+	FLD(skey,uint64_t,fcpow2(CT::scap),e_tlink)
+	static_assert(e_skey <= o_links,"raw stretches must fit the mask / offset arrays they borrow");
+	// scratch over [xbase,uB): candidate heap, sequences and lane scratch are written by the enumerations only
+	FLD(alpv,uint64_t,MAXCONS+1,xbase)
+	FLD(almv,uint64_t,MAXCONS+1,e_alpv)
+	FLD(albot,uint16_t,MAXCONS+1,e_almv)
+	FLD(alops,uint8_t,2*MAXCONS+2*64+8,e_albot)
+	static_assert(e_alops <= uB,"final alignment scratch");
+	static constexpr uint32_t taskbytes = ((2*CT::scap+2)*2 + 2*(2*CT::scap) + 15u) & ~15u;
+	FLD(toff,uint16_t,2*CT::scap+2,xbase)
+	FLD(ulo,uint8_t,2*CT::scap,e_toff)
+	FLD(uhi,uint8_t,2*CT::scap,e_ulo)
+	static_assert(e_uhi <= uB,"feasibility tasks");
+	static_assert(6u*CT::ncap + 16u <= xbytes,"predecessor counts and walking table must fit the scratch");
+	static_assert(3u*CT::ncap + 16u <= xbytes && 2u*CT::ncap + CT::scap + 8u <= xbytes,"interior node table / reachability scratch");
+	HDEV LDSQ uint32_t * xcnt32() const { return reinterpret_cast<LDSQ uint32_t *>(base + xbase); }
+	HDEV LDSQ uint16_t * xstep() const { return reinterpret_cast<LDSQ uint16_t *>(base + xbase + 4u*CT::ncap + 8u); }
+	HDEV LDSQ uint16_t * xsid() const { return reinterpret_cast<LDSQ uint16_t *>(base + xbase); }
+	HDEV LDSQ uint8_t * xspos() const { return reinterpret_cast<LDSQ uint8_t *>(base + xbase + 2u*CT::ncap + 8u); }
+	HDEV LDSQ uint8_t * xreach() const { return reinterpret_cast<LDSQ uint8_t *>(base + xbase); }
+	static constexpr uint32_t uend = fcmax(uA,uB);
+	// scratch behind the build overlay (gap filling): small in this layout, a window that needs more goes to the next tier
+	FLD(gfbuf,uint64_t,(uB > uA ? (uB-uA)/8 : 0u),uA)
+	static constexpr uint32_t gfcap = uB > uA ? (uB-uA)/8 : 0u;
+	static constexpr uint32_t tabcap = 0x7FFFFFFFu;      // no LDS copy of the model table
+	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
+	// the global slab of a workgroup: forward weights, reverse weights (16 bytes per entry), spill of S; the walk slots of
+	// the stretch construction borrow the weight part
+	static constexpr uint32_t g_wF = 0, g_wR = 16u*CT::wcapg, g_spill = 32u*CT::wcapg, g_bytes = ((32u*CT::wcapg + sbytes + 255u) & ~255u);
+	static constexpr uint32_t xnslot = (32u*CT::wcapg) / 128u;
 };
 #undef FLD
 
@@ -290,6 +477,7 @@ HDEV FastCaps fastCapsOf(uint32_t const nrows, uint32_t const nsup)
 	C.nrows = nrows; C.nsup = nsup;
 	C.ldsbytes = FastLds<CT>::bytes(nrows,nsup);
 	C.tabcap = FastLds<CT>::tabcap;
+	if constexpr ( CT::gw != 0 ) C.gbytes = FastLds<CT>::g_bytes; else C.gbytes = 0;
 	return C;
 }
 
@@ -300,6 +488,9 @@ struct FastBatch
 	uint64_t const * dpsq_vst;  // [nsup][nrows] transposed fixed-point table (HBM); copied to LDS as 32-bit
 	uint32_t * retry;           // [0] = count, [1..] = window indices for the next capacity tier
 	uint32_t * gearly;          // same layout: windows no LDS tier can run (w > 63, a string > 64): straight to the generic engine
+	uint8_t * gslab;            // gw tiers: global scratch, gstride bytes per workgroup (weights, spill of the build-phase arrays)
+	uint64_t gstride;
+	uint32_t const * tab32;     // gw tiers: [nsup+1][nrows+1] 32 bit copy of the fixed-point table, zero row / column at the end
 };
 
 // once per workgroup: the support bounds of the model table
@@ -370,6 +561,10 @@ struct FastEngine
 	FastLds<CT> L; DevTables T; DevParams P;
 	uint32_t nrows, nsup;
 	uint64_t const * vst;        // [nsup][nrows] fixed-point model table in HBM
+	enum : bool { GW = (CT::gw != 0) };
+	uint8_t * gslab;             // gw: this workgroup's global slab
+	uint32_t const * gtab;       // gw: padded 32 bit table in global memory
+	struct G4 { uint32_t x, y, z, w; };      // one 16 byte weight record
 	int lane; uint32_t flags;
 	uint64_t * prof;
 	uint32_t mao, k; uint64_t kmask;
@@ -733,11 +928,10 @@ struct FastEngine
 	// each of its active successors (LDS atomics on a scratch word array) instead of every node searching its four
 	// possible predecessors; stepT[z] = the node a walk continues with from z (exactly one active successor and one active
 	// predecessor), 0xFFFF where a stretch ends.  Both tables borrow the weight arrays, which are written much later.
-	DEV LDSQ uint16_t * stepTable() const { return reinterpret_cast<LDSQ uint16_t *>(L.base + ((FastLds<CT>::e_wR1_hi - 2u*CT::ncap) & ~7u)); }
+	DEV LDSQ uint16_t * stepTable() const { return L.xstep(); }
 	DEV void computePredCounts()
 	{
-		static_assert(6u*CT::ncap + 16u <= FastLds<CT>::e_wR1_hi - FastLds<CT>::o_wF_lo,"scratch tables of the stretch walk must fit the weight arrays");
-		LDSQ uint32_t * const cnt32 = reinterpret_cast<LDSQ uint32_t *>(L.wF_lo());
+		LDSQ uint32_t * const cnt32 = L.xcnt32();
 		LDSQ uint16_t * const stepT = stepTable();
 		for ( uint32_t z = lane; z < nn; z += WSZ ) cnt32[z] = 0;
 		wv_sync();
@@ -758,7 +952,8 @@ struct FastEngine
 		wv_sync();
 	}
 	// out (if given) receives the first `cap` nodes
-	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, LDSQ uint16_t * out, uint32_t & lastnode, uint32_t const cap = 0xFFFFFFFFu)
+	template<typename OUTP>
+	DEV uint32_t walkStretch(uint32_t const z, uint32_t const i, OUTP out, uint32_t & lastnode, uint32_t const cap = 0xFFFFFFFFu)
 	{
 		LDSQ uint16_t const * const stepT = stepTable();
 		int32_t cur = succNode(z,i);
@@ -806,13 +1001,21 @@ struct FastEngine
 		// walk every stretch once: the nodes go to a scratch slot of WSLOT entries per stretch in the (not yet used) weight
 		// arrays and are compacted into `links` below; a stretch without a slot or longer than it is walked a second time
 		enum { WSLOT = 64 };
-		LDSQ uint16_t * const wtmp = reinterpret_cast<LDSQ uint16_t *>(L.wF_lo());
-		uint32_t const nslot = (((FastLds<CT>::e_wR1_hi - 2u*CT::ncap) & ~7u) - FastLds<CT>::o_wF_lo) / (2*WSLOT);     // the walking table sits behind the slots
+		uint32_t const nslot = FastLds<CT>::xnslot;     // legacy: the walking table sits behind the slots; gw: slots in the global slab
 		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
 			uint32_t ln;
 			uint32_t const sub = L.tlast()[q];
-			L.tslen()[q] = walkStretch(L.tfirst()[q],sub,q < nslot ? wtmp + q*WSLOT : static_cast<LDSQ uint16_t *>(0),ln,WSLOT);
+			if constexpr ( GW )
+			{
+				uint16_t * const wtmp = reinterpret_cast<uint16_t *>(gslab);
+				L.tslen()[q] = walkStretch(L.tfirst()[q],sub,q < nslot ? wtmp + q*WSLOT : static_cast<uint16_t *>(0),ln,WSLOT);
+			}
+			else
+			{
+				LDSQ uint16_t * const wtmp = L.xwtmp();
+				L.tslen()[q] = walkStretch(L.tfirst()[q],sub,q < nslot ? wtmp + q*WSLOT : static_cast<LDSQ uint16_t *>(0),ln,WSLOT);
+			}
 			L.skey()[q] = (static_cast<uint64_t>(sub)<<32) | ln;     // successor index (for a second walk) and last node
 		}
 		wv_sync();
@@ -832,7 +1035,11 @@ struct FastEngine
 		{
 			uint32_t const len = L.tslen()[q]; uint64_t const sk = L.skey()[q];
 			LDSQ uint16_t * const dst = L.links() + L.tlink()[q];
-			if ( q < nslot && len <= WSLOT ) { LDSQ uint16_t const * src = wtmp + q*WSLOT; for ( uint32_t t = 0; t < len; ++t ) dst[t] = src[t]; }
+			if ( q < nslot && len <= WSLOT )
+			{
+				if constexpr ( GW ) { uint16_t const * src = reinterpret_cast<uint16_t const *>(gslab) + q*WSLOT; for ( uint32_t t = 0; t < len; ++t ) dst[t] = src[t]; }
+				else { LDSQ uint16_t const * src = L.xwtmp() + q*WSLOT; for ( uint32_t t = 0; t < len; ++t ) dst[t] = src[t]; }
+			}
 			else { uint32_t ln; walkStretch(L.tfirst()[q],static_cast<uint32_t>(sk>>32),dst,ln); }
 			L.tlast()[q] = static_cast<uint32_t>(sk);
 		}
@@ -911,9 +1118,8 @@ struct FastEngine
 		{
 			// node -> (stretch, index) for the interior nodes, in the not yet used weight arrays: one pass over the stretches
 			// (lane per stretch, indices downwards so that the first occurrence of a node stays), then one lookup per candidate
-			LDSQ uint16_t * const sid = reinterpret_cast<LDSQ uint16_t *>(L.wR_lo());
-			LDSQ uint8_t * const spos = reinterpret_cast<LDSQ uint8_t *>(L.wR1_lo());
-			static_assert(CT::wcap*4 >= CT::ncap*2,"interior node table must fit the weight array it borrows");
+			LDSQ uint16_t * const sid = L.xsid();
+			LDSQ uint8_t * const spos = L.xspos();
 			for ( uint32_t z = lane; z < nn; z += WSZ ) sid[z] = 0xFFFF;
 			wv_sync();
 			for ( uint32_t s = lane; s < n0; s += WSZ )
@@ -977,8 +1183,7 @@ struct FastEngine
 	// goes through the enumerations as before.  Scratch: the weight arrays, which are written after this.
 	DEV bool pairReachable()
 	{
-		static_assert(2u*CT::ncap + CT::scap + 8u <= 4u*CT::wcap,"reachability scratch must fit the first weight array");
-		LDSQ uint8_t * const seedN = reinterpret_cast<LDSQ uint8_t *>(L.wF_lo());
+		LDSQ uint8_t * const seedN = L.xreach();
 		LDSQ uint8_t * const reachN = seedN + CT::ncap;
 		LDSQ uint8_t * const vis = reachN + CT::ncap;
 		if ( nF == 0 || nL == 0 ) return false;
@@ -1027,9 +1232,8 @@ struct FastEngine
 	// clamped instead of branched on; one more all-zero position (nsup) for read positions behind the support
 	DEV void loadTab()
 	{
-#if defined(DACC_TAB_GLOBAL)
-		return;      // experiment: the model table is read from HBM / L2 / L1 where it is needed
-#endif
+		if constexpr ( GW ) return;      // gw tiers read the padded 32 bit table from global memory (L1 / L2 resident) where they need it
+		else {
 		uint32_t const stride = nrows+1;
 		uint32_t pos = static_cast<uint32_t>(lane) / stride, row = static_cast<uint32_t>(lane) - pos*stride;     // the one division of the copy
 		uint32_t const dpos = WSZ / stride, drow = WSZ - dpos*stride;
@@ -1039,11 +1243,18 @@ struct FastEngine
 			pos += dpos; row += drow; if ( row >= stride ) { row -= stride; ++pos; }
 		}
 		wv_sync();
+		}
+	}
+	// entry [pos][pc] of the padded table (row stride nrows+1, zero row nrows, zero position nsup)
+	DEV uint32_t tabR(uint32_t const idx) const
+	{
+		if constexpr ( GW ) return gtab[idx];
+		else return L.tab()[idx];
 	}
 	template<bool GT> DEV uint32_t tabAt(uint32_t const pos, uint32_t const pc, uint32_t const stride) const
 	{
 		if ( GT ) return (pc < nrows && pos < nsup) ? static_cast<uint32_t>(vst[pos*nrows+pc]) : 0u;
-		else return L.tab()[pos*stride+pc];
+		else return tabR(pos*stride+pc);
 	}
 	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions; GT: read the table from HBM
 	// (middle pieces created while the LDS copy is overlaid by the enumeration pools) ----
@@ -1103,19 +1314,8 @@ struct FastEngine
 				#undef DACC_NODE
 				uint64_t const bf = wv_ballot(ok), br = wv_ballot(okr);
 				uint32_t const pre = dacc_popc64(bf & ltmask), prer = dacc_popc64(br & ltmask);
-				if ( ok && bF+pre < CT::wcap )
-				{
-					uint32_t const o = bF+pre;
-					L.wF_lo()[o] = static_cast<uint32_t>(sum); L.wF_hi()[o] = static_cast<uint16_t>(sum>>32);
-					L.wF1_lo()[o] = static_cast<uint32_t>(f1); L.wF1_hi()[o] = static_cast<uint8_t>(f1>>32);
-					L.wFl_lo()[o] = static_cast<uint32_t>(fl); L.wFl_hi()[o] = static_cast<uint8_t>(fl>>32);
-				}
-				if ( okr && bR+prer < CT::wcap )
-				{
-					uint32_t const o = bR+prer;
-					L.wR_lo()[o] = static_cast<uint32_t>(rsum); L.wR_hi()[o] = static_cast<uint16_t>(rsum>>32);
-					L.wR1_lo()[o] = static_cast<uint32_t>(r1); L.wR1_hi()[o] = static_cast<uint8_t>(r1>>32);
-				}
+				if ( ok && bF+pre < CT::wcap ) putF(bF+pre,sum,f1,fl);
+				if ( okr && bR+prer < CT::wcap ) putR(bR+prer,rsum,r1);
 				mF |= bf << c; mR |= br << c;
 				bF += dacc_popc64(bf); bR += dacc_popc64(br);
 			}
@@ -1138,11 +1338,20 @@ struct FastEngine
 		PROFX_T0
 		uint32_t const ns = sto-sfrom, nu = 2*ns;          // units: forward stretches, then reverse stretches
 		uint32_t const stride = nrows+1;
-		uint32_t tbase = 0;
-		for ( uint32_t c = 0; c < nu; c += WSZ )
+		// The tasks of a round run in lock step for as long as the longest of them walks its stretch, so the units are
+		// processed in classes of decreasing stretch length (lock step iterations per traversal at config 2: 248 in pool
+		// order, 97 sorted by length, about 105 in these classes; 65 is the sum of the iterations over 64).  Any order of
+		// the units gives the same weights: a unit's entries stay consecutive and ascending in its own list, only the place
+		// of the list in the weight arrays changes.  Position q of the order holds (lo | unit << 7) in the bytes of ulo/uhi.
+		enum { NCHU = (2*CT::scap + WSZ - 1)/WSZ, NCLS = 12 };
+		static_assert(2*CT::scap < 512,"unit ids are packed into 9 bits");
+		LDSQ uint16_t * const urec = reinterpret_cast<LDSQ uint16_t *>(L.ulo());
+		uint32_t ulo_r[NCHU], uw_r[NCHU], ucls_r[NCHU], upos_r[NCHU];
+		#pragma unroll
+		for ( uint32_t cc = 0; cc < NCHU; ++cc )
 		{
-			uint32_t const u = c + lane;
-			uint32_t w = 0;
+			uint32_t const u = cc*WSZ + lane;
+			uint32_t w = 0, lo_ = 0, cls = NCLS;
 			if ( u < nu )
 			{
 				bool const rev = u >= ns; uint32_t const s = sfrom + (rev ? u-ns : u);
@@ -1157,12 +1366,41 @@ struct FastEngine
 					lo = a > lo ? a : lo; hi = b < hi ? b : hi;
 				}
 				if ( hi < lo ) hi = lo;
-				w = static_cast<uint32_t>(hi-lo);
-				L.ulo()[u] = lo; L.uhi()[u] = hi;
+				w = static_cast<uint32_t>(hi-lo); lo_ = static_cast<uint32_t>(lo);
+				cls = len >= 49 ? 0u : len >= 33 ? 1u : len >= 25 ? 2u : len >= 17 ? 3u : len >= 13 ? 4u : len >= 9 ? 5u : len >= 7 ? 6u : len >= 5 ? 7u : len == 4 ? 8u : len == 3 ? 9u : len == 2 ? 10u : 11u;
 				if ( rev ) { L.maskR()[s] = 0; L.woffR()[s] = 0; } else { L.maskF()[s] = 0; L.woffF()[s] = 0; }
 			}
+			ulo_r[cc] = lo_; uw_r[cc] = w; ucls_r[cc] = cls; upos_r[cc] = 0;
+		}
+		{
+			uint32_t run = 0;
+			for ( uint32_t k = 0; k < NCLS; ++k )
+			{
+				#pragma unroll
+				for ( uint32_t cc = 0; cc < NCHU; ++cc )
+				{
+					if ( cc*WSZ >= nu ) break;
+					bool const mine = ucls_r[cc] == k;
+					uint32_t tot; uint32_t const pre = wv_scan_flag(mine,tot);
+					if ( mine ) upos_r[cc] = run + pre;
+					run += tot;
+				}
+			}
+		}
+		#pragma unroll
+		for ( uint32_t cc = 0; cc < NCHU; ++cc )
+		{
+			uint32_t const u = cc*WSZ + lane;
+			if ( u < nu ) { urec[upos_r[cc]] = static_cast<uint16_t>(ulo_r[cc] | (u << 7)); L.toff()[upos_r[cc]] = static_cast<uint16_t>(uw_r[cc]); }
+		}
+		wv_sync();
+		uint32_t tbase = 0;
+		for ( uint32_t c = 0; c < nu; c += WSZ )
+		{
+			uint32_t const q = c + lane;
+			uint32_t const w = q < nu ? L.toff()[q] : 0u;
 			uint32_t tot; uint32_t const pre = wv_scan_excl(w,tot);
-			if ( u < nu ) L.toff()[u] = tbase + pre;
+			if ( q < nu ) L.toff()[q] = tbase + pre;
 			tbase += tot;
 		}
 		PROFX(18)
@@ -1183,9 +1421,11 @@ struct FastEngine
 				while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( L.toff()[mid] <= t ) lo = mid; else hi = mid; }
 				u = lo;
 			}
-			bool const rev = u >= ns; uint32_t const s = sfrom + (rev ? u-ns : u);
+			uint32_t const ur = act ? urec[u] : 0u;          // u = position in the processing order
+			uint32_t const uu = ur >> 7;
+			bool const rev = uu >= ns; uint32_t const s = sfrom + (rev ? uu-ns : uu);
 			uint32_t const t0 = act ? L.toff()[u] : 0u;
-			uint32_t const P = act ? (static_cast<uint32_t>(L.ulo()[u]) + (t-t0)) : 0u;
+			uint32_t const P = act ? ((ur & 127u) + (t-t0)) : 0u;
 			bool ok = act;
 			uint64_t sum = 0, f1 = 0, fl = 0;
 			if ( act )
@@ -1204,13 +1444,8 @@ struct FastEngine
 					uint32_t const ip_b = IP[i0_b];
 					uint32_t const pp = P+j;
 					uint32_t const pc = pp < nrows ? pp : nrows;
-#if defined(DACC_TAB_GLOBAL)
-					uint64_t U = tabAt<true>(ip_a,pc,stride);
-					for ( uint32_t q = 1; q < f_a; ++q ) U += tabAt<true>(static_cast<uint32_t>(IP[i0_a+q]),pc,stride);
-#else
-					uint64_t U = L.tab()[ip_a*stride + pc];
-					for ( uint32_t q = 1; q < f_a; ++q ) U += L.tab()[static_cast<uint32_t>(IP[i0_a+q])*stride + pc];
-#endif
+					uint64_t U = tabR(ip_a*stride + pc);
+					for ( uint32_t q = 1; q < f_a; ++q ) U += tabR(static_cast<uint32_t>(IP[i0_a+q])*stride + pc);
 					if ( U < FW_THRES_FEAS ) { ok = false; FEAS_ITERS(t,len,j+1) break; }
 					sum += U;
 					if ( j == 0 ) f1 = U;
@@ -1230,17 +1465,7 @@ struct FastEngine
 				uint32_t const o = base + dacc_popc64(okb & mydir & ltmask);
 				if ( o < CT::wcap )
 				{
-					if ( rev )
-					{
-						L.wR_lo()[o] = static_cast<uint32_t>(sum); L.wR_hi()[o] = static_cast<uint16_t>(sum>>32);
-						L.wR1_lo()[o] = static_cast<uint32_t>(f1); L.wR1_hi()[o] = static_cast<uint8_t>(f1>>32);
-					}
-					else
-					{
-						L.wF_lo()[o] = static_cast<uint32_t>(sum); L.wF_hi()[o] = static_cast<uint16_t>(sum>>32);
-						L.wF1_lo()[o] = static_cast<uint32_t>(f1); L.wF1_hi()[o] = static_cast<uint8_t>(f1>>32);
-						L.wFl_lo()[o] = static_cast<uint32_t>(fl); L.wFl_hi()[o] = static_cast<uint8_t>(fl>>32);
-					}
+					if ( rev ) putR(o,sum,f1); else putF(o,sum,f1,fl);
 				}
 			}
 			if ( act )
@@ -1266,11 +1491,73 @@ struct FastEngine
 	}
 	// weights of feasible (stretch, position) entry i.  A node weight is a sum of at most 255 table words (< 2^40), a
 	// feasible stretch has at most nrows <= 64 nodes (< 2^46)
-	DEV uint64_t wuF(uint32_t const i) const { return L.wF_lo()[i] | (static_cast<uint64_t>(L.wF_hi()[i])<<32); }
-	DEV uint64_t w1F(uint32_t const i) const { return L.wF1_lo()[i] | (static_cast<uint64_t>(L.wF1_hi()[i])<<32); }   // first node at the start position
-	DEV uint64_t wlF(uint32_t const i) const { return L.wFl_lo()[i] | (static_cast<uint64_t>(L.wFl_hi()[i])<<32); }   // last node at the end position
-	DEV uint64_t wuR(uint32_t const i) const { return L.wR_lo()[i] | (static_cast<uint64_t>(L.wR_hi()[i])<<32); }
-	DEV uint64_t w1R(uint32_t const i) const { return L.wR1_lo()[i] | (static_cast<uint64_t>(L.wR1_hi()[i])<<32); }   // last node (first in reverse direction)
+	// One record per feasible (stretch, position) entry.  Forward: whole stretch (w), its first node at the start position
+	// (w1), its last node at the end position (wl); reverse: whole stretch and its last node (= first in reverse direction).
+	// gw tiers: 16 byte records in the workgroup's global slab (one load per lookup); legacy tiers: split LDS arrays.
+	struct WF { uint64_t w, w1, wl; };
+	struct WR { uint64_t w, w1; };
+	DEV WF recF(uint32_t const i) const
+	{
+		WF r;
+		if constexpr ( GW )
+		{
+			G4 const v = reinterpret_cast<G4 const *>(gslab + FastLds<CT>::g_wF)[i];
+			r.w = v.x | (static_cast<uint64_t>(v.w & 0xFFFFu)<<32); r.w1 = v.y | (static_cast<uint64_t>((v.w>>16)&0xFFu)<<32); r.wl = v.z | (static_cast<uint64_t>(v.w>>24)<<32);
+		}
+		else
+		{
+			r.w = L.wF_lo()[i] | (static_cast<uint64_t>(L.wF_hi()[i])<<32);
+			r.w1 = L.wF1_lo()[i] | (static_cast<uint64_t>(L.wF1_hi()[i])<<32);
+			r.wl = L.wFl_lo()[i] | (static_cast<uint64_t>(L.wFl_hi()[i])<<32);
+		}
+		return r;
+	}
+	DEV WR recR(uint32_t const i) const
+	{
+		WR r;
+		if constexpr ( GW )
+		{
+			G4 const v = reinterpret_cast<G4 const *>(gslab + FastLds<CT>::g_wR)[i];
+			r.w = v.x | (static_cast<uint64_t>(v.z & 0xFFFFu)<<32); r.w1 = v.y | (static_cast<uint64_t>((v.z>>16)&0xFFu)<<32);
+		}
+		else
+		{
+			r.w = L.wR_lo()[i] | (static_cast<uint64_t>(L.wR_hi()[i])<<32);
+			r.w1 = L.wR1_lo()[i] | (static_cast<uint64_t>(L.wR1_hi()[i])<<32);
+		}
+		return r;
+	}
+	DEV void putF(uint32_t const o, uint64_t const sum, uint64_t const f1, uint64_t const fl) const
+	{
+		if constexpr ( GW )
+		{
+			G4 v; v.x = static_cast<uint32_t>(sum); v.y = static_cast<uint32_t>(f1); v.z = static_cast<uint32_t>(fl);
+			v.w = (static_cast<uint32_t>(sum>>32)&0xFFFFu) | ((static_cast<uint32_t>(f1>>32)&0xFFu)<<16) | ((static_cast<uint32_t>(fl>>32)&0xFFu)<<24);
+			reinterpret_cast<G4 *>(gslab + FastLds<CT>::g_wF)[o] = v;
+		}
+		else
+		{
+			L.wF_lo()[o] = static_cast<uint32_t>(sum); L.wF_hi()[o] = static_cast<uint16_t>(sum>>32);
+			L.wF1_lo()[o] = static_cast<uint32_t>(f1); L.wF1_hi()[o] = static_cast<uint8_t>(f1>>32);
+			L.wFl_lo()[o] = static_cast<uint32_t>(fl); L.wFl_hi()[o] = static_cast<uint8_t>(fl>>32);
+		}
+	}
+	DEV void putR(uint32_t const o, uint64_t const rsum, uint64_t const r1) const
+	{
+		if constexpr ( GW )
+		{
+			G4 v; v.x = static_cast<uint32_t>(rsum); v.y = static_cast<uint32_t>(r1);
+			v.z = (static_cast<uint32_t>(rsum>>32)&0xFFFFu) | ((static_cast<uint32_t>(r1>>32)&0xFFu)<<16); v.w = 0;
+			reinterpret_cast<G4 *>(gslab + FastLds<CT>::g_wR)[o] = v;
+		}
+		else
+		{
+			L.wR_lo()[o] = static_cast<uint32_t>(rsum); L.wR_hi()[o] = static_cast<uint16_t>(rsum>>32);
+			L.wR1_lo()[o] = static_cast<uint32_t>(r1); L.wR1_hi()[o] = static_cast<uint8_t>(r1>>32);
+		}
+	}
+	DEV uint64_t wuF(uint32_t const i) const { return recF(i).w; }
+	DEV uint64_t wuR(uint32_t const i) const { return recR(i).w; }
 	// fixed-point weight of a single node at (reverse) position p
 	DEV uint64_t nodeU(uint32_t const z, uint32_t const p, bool const rev) const
 	{
@@ -1278,11 +1565,7 @@ struct FastEngine
 		uint32_t const i0 = L.nps()[z], f = L.nfreq()[z];
 		LDSQ uint8_t const * IP = rev ? L.irpos() : L.ipos();
 		uint64_t u = 0;
-#if defined(DACC_TAB_GLOBAL)
-		for ( uint32_t q = 0; q < f; ++q ) u += tabAt<true>(static_cast<uint32_t>(IP[i0+q]),p,nrows+1);
-#else
-		for ( uint32_t q = 0; q < f; ++q ) u += L.tab()[static_cast<uint32_t>(IP[i0+q])*(nrows+1) + p];
-#endif
+		for ( uint32_t q = 0; q < f; ++q ) u += tabR(static_cast<uint32_t>(IP[i0+q])*(nrows+1) + p);
 		return u;
 	}
 	DEV int32_t sfFind(uint32_t const s, uint32_t const p) const
@@ -1313,7 +1596,8 @@ struct FastEngine
 			uint32_t const ia = L.woffR()[i] + dacc_popc64(mA & ((1ull<<pa)-1));
 			uint32_t const pb = pa-shift;
 			uint32_t const ib = L.woffR()[b] + dacc_popc64(mB & ((1ull<<pb)-1));
-			uint64_t const lweight = wuR(ib) + (wuR(ia) - w1R(ia));
+			WR const ra = recR(ia);
+			uint64_t const lweight = wuR(ib) + (ra.w - ra.w1);
 			weight = lweight > weight ? lweight : weight;
 		}
 		return weight >= FW_THRES_01;
@@ -1513,14 +1797,14 @@ struct FastEngine
 	struct REnum { ChunkList<RNW> C; uint32_t nrp, narp, lastk; };
 	// extendReversePath :4058-4105 with the parent's fields and the feasible entry sfo = csfFind(s,ppos) in registers
 	// (checkReversePathFeasiblePosition :4130-4159 looks the same entry up again: the check position is the parent's)
-	DEV int32_t extendReversePath(REnum & R, uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl, int32_t const sfo, uint64_t const wr)
+	DEV int32_t extendReversePath(REnum & R, uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl, int32_t const sfo, uint64_t const wr, uint64_t const wr1)
 	{
 		uint32_t const slot = clEnsure<RCH>(R.C,R.nrp,L.ctr()+0,CT::rccap/RCH);
 		if ( slot == ~0u ) { over(512|0x4000); return -1; }
 		uint32_t const slen = L.sslen()[s];
 		uint64_t weight = pw; uint32_t baselen = pbl;
 		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wr : 0; }
-		else { baselen += slen-1; if ( sfo >= 0 ) weight += wr - w1R(sfo); }
+		else { baselen += slen-1; if ( sfo >= 0 ) weight += wr - wr1; }
 		uint32_t const npos = ppos + slen-1;
 		if ( baselen > 255 || npos > 255 || plen+1 > 255 ) { over(2048); return -1; }
 		++R.nrp;
@@ -1568,9 +1852,10 @@ struct FastEngine
 				for ( int32_t sx = byLastNext(V,it); sx >= 0; sx = byLastNext(V,it) )
 				{
 					int32_t const sfo = csfFind(sx,ppos);
-					uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
+					WR rr; rr.w = 0; rr.w1 = 0; if ( sfo >= 0 ) rr = recR(sfo);
+					uint64_t const wr = rr.w;
 					if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;     // the new path would be dropped right away
-					int32_t const rpe = extendReversePath(R,rp,sx,ppos,plen,pw,bl,sfo,wr);
+					int32_t const rpe = extendReversePath(R,rp,sx,ppos,plen,pw,bl,sfo,wr,rr.w1);
 					if ( rpe < 0 ) return;
 					if ( nrpst >= rpstcap ) { over(512|0x8000); return; }
 					ipush<false>(rpst,nrpst,static_cast<id_t>(rpe),W);
@@ -1587,9 +1872,10 @@ struct FastEngine
 					if ( linkOk(a,b) )
 					{
 						int32_t const sfo = csfFind(a,ppos);
-						uint64_t const wr = sfo >= 0 ? wuR(sfo) : 0;
+						WR rr; rr.w = 0; rr.w1 = 0; if ( sfo >= 0 ) rr = recR(sfo);
+						uint64_t const wr = rr.w;
 						if ( !(sfo >= 0 && wr >= FW_THRES_05) ) continue;
-						int32_t const rpe = extendReversePath(R,rp,a,ppos,plen,pw,bl,sfo,wr);
+						int32_t const rpe = extendReversePath(R,rp,a,ppos,plen,pw,bl,sfo,wr,rr.w1);
 						if ( rpe < 0 ) return;
 						if ( nrpst >= rpstcap ) { over(512|0x8000); return; }
 						ipush<false>(rpst,nrpst,static_cast<id_t>(rpe),W);
@@ -1722,14 +2008,14 @@ struct FastEngine
 	// enumeration instead of one per base length, same heap arrays, same pop order among equal weights.
 	struct FEnum { ChunkList<FNW> C; uint32_t np, nfpop; uint64_t fmaxw, ffm, m0, m1; };
 	DEV int32_t extendPath(FEnum & F, uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl,
-		int32_t const sfo, uint64_t const wf, uint32_t & npos, uint32_t & nbl, uint64_t & nw)
+		int32_t const sfo, uint64_t const wf, uint64_t const wf1, uint32_t & npos, uint32_t & nbl, uint64_t & nw)
 	{
 		uint32_t const slot = clEnsure<FCH>(F.C,F.np,L.ctr()+1,CT::fcap/FCH);
 		if ( slot == ~0u ) { over(512|0x10000); return -1; }
 		uint32_t const slen = L.sslen()[s];
 		uint64_t weight = pw; uint32_t baselen = pbl;
 		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wf : 0; }
-		else { baselen += slen-1; if ( sfo >= 0 ) weight += wf - w1F(sfo); }
+		else { baselen += slen-1; if ( sfo >= 0 ) weight += wf - wf1; }
 		npos = ppos + (slen-1); nbl = baselen; nw = weight;
 		if ( baselen > 127 || npos > 255 || plen+1 > 255 ) { over(2048); return -1; }
 		++F.np;
@@ -1749,7 +2035,7 @@ struct FastEngine
 				int32_t const sfo = sfFind(sx,0);
 				uint64_t const wf = sfo >= 0 ? wuF(sfo) : 0;
 				uint32_t npos, nbl; uint64_t nw;
-				int32_t const id = extendPath(F,0,sx,0,0,0,0,sfo,wf,npos,nbl,nw);
+				int32_t const id = extendPath(F,0,sx,0,0,0,0,sfo,wf,0,npos,nbl,nw);
 				if ( id < 0 ) return;
 				if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64);
 			}
@@ -1800,7 +2086,7 @@ struct FastEngine
 					uint32_t const pfront = L.nv()[lastn];
 					uint32_t const o = clSlot<FCH>(F.C,F.nfpop);
 					L.fp_id()[o] = path; L.fp_front()[o] = pfront; L.fp_cl()[o] = ppos; F.ffm |= 1ull << (pfront & 63);
-					L.fp_adj()[o] = psfo >= 0 ? (pw - wlF(psfo)) : pw;
+					L.fp_adj()[o] = psfo >= 0 ? (pw - recF(psfo).wl) : pw;
 					if ( pw > F.fmaxw ) F.fmaxw = pw;
 					++F.nfpop;
 				}
@@ -1811,11 +2097,12 @@ struct FastEngine
 					{
 						uint32_t const s = sx;
 						int32_t const sfo = sfFind(s,ppos);
-						uint64_t const eweight = sfo >= 0 ? wuF(sfo) : 0;
+						WF fr; fr.w = 0; fr.w1 = 0; fr.wl = 0; if ( sfo >= 0 ) fr = recF(sfo);
+						uint64_t const eweight = fr.w;
 						if ( eweight >= FW_THRES_01 )
 						{
 							uint32_t npos, nbl; uint64_t nw;
-							int32_t const ep = extendPath(F,path,s,ppos,plen,pw,pbl,sfo,eweight,npos,nbl,nw);
+							int32_t const ep = extendPath(F,path,s,ppos,plen,pw,pbl,sfo,eweight,fr.w1,npos,nbl,nw);
 							if ( ep < 0 ) return;
 							if ( nw >= FW_THRES_01 && static_cast<int64_t>(npos) + k <= lmax )
 							{
@@ -2201,6 +2488,34 @@ struct FastEngine
 		wv_sync();
 	}
 
+	// gw layout: the enumeration pools lie over the build-phase arrays (region S); S goes to the workgroup's global slab
+	// before the enumerations and comes back after the pairs (candidate errors need the pattern masks, the next
+	// activation state the successor tables, the next traversal all of it)
+	DEV void spillS()
+	{
+		if constexpr ( GW )
+		{
+			typedef FastLds<CT> LL;
+			LDSQ G4 const * const src = reinterpret_cast<LDSQ G4 const *>(L.base + LL::sbase);
+			G4 * const dst = reinterpret_cast<G4 *>(gslab + LL::g_spill);
+			wv_sync();
+			for ( uint32_t i = lane; i < LL::sbytes/16u; i += WSZ ) dst[i] = src[i];
+			wv_sync();
+		}
+	}
+	DEV void restoreS()
+	{
+		if constexpr ( GW )
+		{
+			typedef FastLds<CT> LL;
+			LDSQ G4 * const dst = reinterpret_cast<LDSQ G4 *>(L.base + LL::sbase);
+			G4 const * const src = reinterpret_cast<G4 const *>(gslab + LL::g_spill);
+			wv_sync();
+			for ( uint32_t i = lane; i < LL::sbytes/16u; i += WSZ ) dst[i] = src[i];
+			wv_sync();
+		}
+	}
+
 	// ================= traverse (:4496-5170) for one activation state =================
 	// (first, last) candidate pairs: the reverse blocks of all last k-mers and the forward trees of a batch of first
 	// k-mers are enumerated with one lane each, the score intervals of NPL pairs at a time are popped with one lane per
@@ -2371,6 +2686,7 @@ struct FastEngine
 		PROF(*this,17)
 		computeStretchFeasLanes(0,npool);
 		flags = wv_or(flags); if ( flags ) return false;
+		spillS();
 		PROF(*this,9)
 
 		// ---- reverse blocks of all last k-mer candidates, lane = candidate ----
@@ -2523,8 +2839,12 @@ struct FastEngine
 						break;
 					}
 					// middle piece of a stretch split twice: appended to the pool (kept, candidates may refer to it)
+					FSTAT_ADD(25,1);
 					uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
 					if ( npool+1 > CT::scap || npool+1 > 250 ) { over(32); return false; }
+					// gw layout: the node tables the feasibility of the new piece reads are spilled at this point (7 of 7976
+					// windows of config 2 need a middle piece): such a window goes to the next tier
+					if ( GW ) { over(32); return false; }
 					if ( lane == 0 ) { makePiece(npool,par,ma,mb); L.ppos()[npool] = basePos(npool); }
 					wv_sync();
 					computeStretchFeas<true>(npool,npool+1);
@@ -2537,6 +2857,7 @@ struct FastEngine
 			if ( restart ) continue;
 			fstart += nb; pskip = 0;
 		}
+		restoreS();
 		PROF(*this,12)
 		// CDH -> CH -> ACC (:5099-5136) leaves the kept candidates in descending weight order.  With pairwise distinct
 		// weights that order does not depend on the heaps: one lane per candidate counts the heavier ones and stores its
@@ -2814,6 +3135,15 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
 	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
+	E.gslab = 0; E.gtab = FB.tab32;
+	if ( CT::gw )
+	{
+#if defined(DACC_EMUL)
+		E.gslab = FB.gslab;
+#else
+		E.gslab = FB.gslab + static_cast<uint64_t>(blockIdx.x)*FB.gstride;
+#endif
+	}
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
 #if defined(DACC_EMUL)
 	g_fstats.clear();
@@ -3006,6 +3336,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 			out.status = WS_OK; out.conslen = bestlen; out.minrate = minrate;
 			PROF_T0
 			uint32_t nops = 0;
+			wv_sync();      // the alignment scratch may lie over the candidate buffers the lanes have just read (gw layout)
 			if ( lane == 0 ) nops = E.alignAndEmit(best,bestlen);
 			wv_sync();
 			nops = wv_bcast(nops,0);

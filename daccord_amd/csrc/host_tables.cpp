@@ -130,6 +130,10 @@ void buildHostTables(HostTables & H, uint32_t const w, double const p_i, double 
 	for ( uint32_t i = 0; i < nrows; ++i )
 		for ( uint32_t pos = 0; pos < nsup; ++pos )
 			H.dpsq_vst[static_cast<size_t>(pos)*nrows+i] = H.dpsq_vs[static_cast<size_t>(i)*nsup+pos];
+	H.tab32.assign(static_cast<size_t>(nrows+1)*(nsup+1),0);
+	for ( uint32_t pos = 0; pos < nsup; ++pos )
+		for ( uint32_t i = 0; i < nrows; ++i )
+			H.tab32[static_cast<size_t>(pos)*(nrows+1)+i] = static_cast<uint32_t>(H.dpsq_vst[static_cast<size_t>(pos)*nrows+i]);
 	// Vsupport: rows whose support covers read position pos (two monotone pointers, OffsetLikely.hpp:83-92)
 	H.suplo.resize(nsup); H.suphi.resize(nsup);
 	uint32_t j = 0, k = 0;

@@ -26,7 +26,7 @@ struct WaveEmu
 	enum { NL = 64, STACK = 512*1024 };
 	void * sp[NL]; void * mainsp;
 	std::vector<uint8_t> stacks;
-	uint64_t val[2][NL]; uint32_t tag[2][NL];
+	uint64_t val[2][NL]; uint32_t tag[2][NL]; int line[2][NL];      // line: call site of the collective in the kernel headers (diagnostics)
 	uint64_t seq[NL];
 	bool done[NL];
 	int cur;
@@ -109,48 +109,48 @@ static inline void wave_run(std::function<void()> const & body)
 static inline int wv_lane() { return wave_emu().cur; }
 
 // rendezvous of all lanes with a 64-bit operand each; afterwards V[l] holds lane l's operand
-static inline uint64_t const * wave_collect(uint64_t const v, uint32_t const tag)
+static inline uint64_t const * wave_collect(uint64_t const v, uint32_t const tag, int const line = 0)
 {
 	WaveEmu & W = wave_emu();
 	int const me = W.cur;
 	uint64_t const q = W.seq[me]++;
 	int const b = q & 1;
-	W.val[b][me] = v; W.tag[b][me] = tag;
+	W.val[b][me] = v; W.tag[b][me] = tag; W.line[b][me] = line;
 	// wait until every lane has deposited for round q: lanes run in order, so after one full cycle of yields all have
 	wave_emu_yield();
 	for ( int i = 0; i < WaveEmu::NL; ++i )
 	{
 		if ( W.seq[i] < q+1 && W.done[i] ) { std::fprintf(stderr,"[wave emu] lane %d ended while lane %d waits in a collective (tag %u)\n",i,me,tag); std::abort(); }
-		if ( W.seq[i] < q+1 || W.tag[b][i] != tag ) { std::fprintf(stderr,"[wave emu] divergent collective: lane %d tag %u seq %llu vs lane %d tag %u seq %llu\n",me,tag,(unsigned long long)q,i,W.tag[b][i],(unsigned long long)W.seq[i]); std::abort(); }
+		if ( W.seq[i] < q+1 || W.tag[b][i] != tag || (line && W.line[b][i] && W.line[b][i] != line) ) { std::fprintf(stderr,"[wave emu] divergent collective: lane %d tag %u seq %llu (source line %d) vs lane %d tag %u seq %llu (source line %d)\n",me,tag,(unsigned long long)q,line,i,W.tag[b][i],(unsigned long long)W.seq[i],W.line[b][i]); std::abort(); }
 	}
 	return W.val[b];
 }
 
-static inline void wv_sync() { wave_collect(0,1); }
-static inline uint32_t wv_scan_excl(uint32_t v, uint32_t & total)
+static inline void wv_sync(int const _ln = __builtin_LINE()) { wave_collect(0,1,_ln); }
+static inline uint32_t wv_scan_excl(uint32_t v, uint32_t & total, int const _ln = __builtin_LINE())
 {
-	int const me = wv_lane(); uint64_t const * V = wave_collect(v,2);
+	int const me = wv_lane(); uint64_t const * V = wave_collect(v,2,_ln);
 	uint32_t pre = 0, tot = 0; for ( int i = 0; i < 64; ++i ) { if ( i < me ) pre += static_cast<uint32_t>(V[i]); tot += static_cast<uint32_t>(V[i]); }
 	total = tot; return pre;
 }
-static inline uint32_t wv_scan_flag(bool p, uint32_t & total) { return wv_scan_excl(p ? 1u : 0u,total); }
-static inline uint32_t wv_sum(uint32_t v) { uint64_t const * V = wave_collect(v,3); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s += static_cast<uint32_t>(V[i]); return s; }
-static inline uint64_t wv_sum64(uint64_t v) { uint64_t const * V = wave_collect(v,4); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s += V[i]; return s; }
-static inline uint32_t wv_max(uint32_t v) { uint64_t const * V = wave_collect(v,5); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s = static_cast<uint32_t>(V[i]) > s ? static_cast<uint32_t>(V[i]) : s; return s; }
-static inline uint64_t wv_max64(uint64_t v) { uint64_t const * V = wave_collect(v,6); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s = V[i] > s ? V[i] : s; return s; }
-static inline uint64_t wv_min64(uint64_t v) { uint64_t const * V = wave_collect(v,7); uint64_t s = ~0ull; for ( int i = 0; i < 64; ++i ) s = V[i] < s ? V[i] : s; return s; }
-static inline int wv_any(int p) { uint64_t const * V = wave_collect(p ? 1 : 0,8); int r = 0; for ( int i = 0; i < 64; ++i ) r |= (V[i] != 0); return r; }
-static inline uint32_t wv_or(uint32_t v) { uint64_t const * V = wave_collect(v,9); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s |= static_cast<uint32_t>(V[i]); return s; }
-static inline uint64_t wv_or64(uint64_t v) { uint64_t const * V = wave_collect(v,10); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s |= V[i]; return s; }
-static inline uint64_t wv_ballot(int p) { uint64_t const * V = wave_collect(p ? 1 : 0,11); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) if ( V[i] ) s |= 1ull<<i; return s; }
+static inline uint32_t wv_scan_flag(bool p, uint32_t & total, int const _ln = __builtin_LINE()) { return wv_scan_excl(p ? 1u : 0u,total,_ln); }
+static inline uint32_t wv_sum(uint32_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,3,_ln); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s += static_cast<uint32_t>(V[i]); return s; }
+static inline uint64_t wv_sum64(uint64_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,4,_ln); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s += V[i]; return s; }
+static inline uint32_t wv_max(uint32_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,5,_ln); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s = static_cast<uint32_t>(V[i]) > s ? static_cast<uint32_t>(V[i]) : s; return s; }
+static inline uint64_t wv_max64(uint64_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,6,_ln); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s = V[i] > s ? V[i] : s; return s; }
+static inline uint64_t wv_min64(uint64_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,7,_ln); uint64_t s = ~0ull; for ( int i = 0; i < 64; ++i ) s = V[i] < s ? V[i] : s; return s; }
+static inline int wv_any(int p, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(p ? 1 : 0,8,_ln); int r = 0; for ( int i = 0; i < 64; ++i ) r |= (V[i] != 0); return r; }
+static inline uint32_t wv_or(uint32_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,9,_ln); uint32_t s = 0; for ( int i = 0; i < 64; ++i ) s |= static_cast<uint32_t>(V[i]); return s; }
+static inline uint64_t wv_or64(uint64_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,10,_ln); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) s |= V[i]; return s; }
+static inline uint64_t wv_ballot(int p, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(p ? 1 : 0,11,_ln); uint64_t s = 0; for ( int i = 0; i < 64; ++i ) if ( V[i] ) s |= 1ull<<i; return s; }
 static inline uint64_t wv_lanemask_lt() { return (1ull << wv_lane()) - 1ull; }
-static inline uint32_t wv_bcast(uint32_t v, int src) { uint64_t const * V = wave_collect(v,12); return static_cast<uint32_t>(V[src]); }
-static inline uint64_t wv_bcast64(uint64_t v, int src) { uint64_t const * V = wave_collect(v,13); return V[src]; }
-static inline uint32_t wv_uni(uint32_t v) { uint64_t const * V = wave_collect(v,14); return static_cast<uint32_t>(V[0]); }
-static inline uint64_t wv_uni64(uint64_t v) { uint64_t const * V = wave_collect(v,15); return V[0]; }
+static inline uint32_t wv_bcast(uint32_t v, int src, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,12,_ln); return static_cast<uint32_t>(V[src]); }
+static inline uint64_t wv_bcast64(uint64_t v, int src, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,13,_ln); return V[src]; }
+static inline uint32_t wv_uni(uint32_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,14,_ln); return static_cast<uint32_t>(V[0]); }
+static inline uint64_t wv_uni64(uint64_t v, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,15,_ln); return V[0]; }
 // value of lane `src` (per-lane source): __shfl
-static inline uint32_t wv_shfl(uint32_t v, int src) { uint64_t const * V = wave_collect(v,16); return static_cast<uint32_t>(V[src & 63]); }
-static inline uint64_t wv_shfl64(uint64_t v, int src) { uint64_t const * V = wave_collect(v,17); return V[src & 63]; }
+static inline uint32_t wv_shfl(uint32_t v, int src, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,16,_ln); return static_cast<uint32_t>(V[src & 63]); }
+static inline uint64_t wv_shfl64(uint64_t v, int src, int const _ln = __builtin_LINE()) { uint64_t const * V = wave_collect(v,17,_ln); return V[src & 63]; }
 static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline void atomicOrFlag(uint32_t * f) { *f |= 1u; }
 // LDS / global atomics of the device code (lanes never run concurrently here)

@@ -1,4 +1,5 @@
-"""Summarise the rocprofv3 --pmc passes of scripts/gpu_pmc_r2.sh into profiles/r02_pmc_summary.json.
+"""Summarise the rocprofv3 --pmc passes (scripts/gpu_pmc.sh) into profiles/<tag>_pmc_summary.json (tag: last argument, default r03).
+The summary records the hash of daccord_amd/csrc it was collected on; bench.py quotes it only while that hash matches.
 
 Per kernel (mean over its launches in the pass): HBM traffic = 2*FETCH_SIZE + WRITE_SIZE (KB -> bytes; FETCH_SIZE is
 doubled on gfx950, MI355X_MICROARCH.md HBM section; separate passes), issue fractions from the SQ counters
@@ -25,7 +26,10 @@ def load(d):
 def main():
     root, reads, readlen, cov, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4]), int(sys.argv[5])
     clock_ghz = float(sys.argv[6]) if len(sys.argv) > 6 else 2.4
-    out = {"workload": {"reads": reads, "readlen": readlen, "coverage": cov, "k": k}, "kernels": {},
+    tag = sys.argv[7] if len(sys.argv) > 7 else "r03"
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from daccord_amd import build as _b
+    out = {"workload": {"reads": reads, "readlen": readlen, "coverage": cov, "k": k}, "csrc_hash": _b.csrc_hash(), "kernels": {},
            "note": "rocprofv3 --pmc, one pass per counter group (FETCH_SIZE | WRITE_SIZE | SQ_*), mean per launch; traffic = 2*FETCH_SIZE + WRITE_SIZE (KB->bytes)"}
     F, dF = load(os.path.join(root, "pmc_FETCH_SIZE")); W, dW = load(os.path.join(root, "pmc_WRITE_SIZE")); S, dS = load(os.path.join(root, "pmc_SQ_WAVE_CYCLES"))
     mean = lambda v: sum(v) / len(v) if v else 0.0
@@ -49,7 +53,7 @@ def main():
             e["resident_waves_per_cu"] = round(4.0 * wc / (ms * 1e-3 * clock_ghz * 1e9 * 256), 2) if ms else None
             e["sq"] = {c: mean(v) for c, v in s.items()}
         out["kernels"][kn] = e
-    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc_summary.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "%s_pmc_summary.json" % tag), "w"), indent=1)
     print(json.dumps({k: {a: b for a, b in v.items() if a != "sq"} for k, v in out["kernels"].items()}, indent=1))
 
 main()

@@ -148,7 +148,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
 		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data(); WB.prof = 0; WB.pregen = 0;
 		FastBatch FB[3];
-		std::vector<uint8_t> lds[3];
+		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3];
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
 		bool tierok[3];
@@ -172,6 +172,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		for ( int t = 0; t < 3; ++t )
 		{
 			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].retry = 0; FB[t].gearly = 0;
+			gslab[t].assign(BP.ftier[t].gbytes+64,0); FB[t].gslab = gslab[t].data(); FB[t].gstride = 0; FB[t].tab32 = c->H.tab32.data();
 			lds[t].resize(BP.ftier[t].ldsbytes+64);
 			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftier[t].tabcap;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
@@ -197,6 +198,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			{
 				// debugging aid: no window may depend on what an earlier window (or kernel) left in LDS
 				std::memset(lds[t].data(),atoi(getenv("DACC_EMUL_POISON")),lds[t].size());
+				std::memset(gslab[t].data(),atoi(getenv("DACC_EMUL_POISON")),gslab[t].size());
 				loadTables(t);
 			}
 			int rc = -1;
@@ -231,7 +233,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		}
 		// the library's launch on the second stream (k_window_long): tier 5 (strings of up to 128 bases) first, the generic
 		// engine for what it cannot hold
-		FastBatch FBL; FBL.W = WB; FBL.W.pregen = 0; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0;
+		FastBatch FBL; FBL.W = WB; FBL.W.pregen = 0; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0; FBL.gslab = 0; FBL.gstride = 0; FBL.tab32 = c->H.tab32.data();
 		std::vector<uint8_t> ldsL(BP.ftierL.ldsbytes+64);
 		bool const longok = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap;
 		auto loadTablesL = [&]() { wave_run([&]() { FastLds< FastTier<5> > L; L.base = ldsL.data(); fast_load_tables(L,BP.ftierL.nrows,BP.ftierL.nsup,T,c->H.dpsq_vst.data()); }); };
