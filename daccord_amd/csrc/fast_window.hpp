@@ -78,12 +78,12 @@ template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 0, 
 #else
 template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 #endif
-// DACC_T2_WCAP: experiment hook (scripts/r3_prepare_variants.sh): 1040 weights make tier 2 81 808 bytes, which still fits twice
-// into 160 KB if LDS is handed out in granules of 1280 bytes or less (unverified; 992 -> 80 512 bytes is what was measured)
-#ifndef DACC_T2_WCAP
-#define DACC_T2_WCAP 992
+// tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
+#if defined(DACC_T2_LEGACY)
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = 992, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+#else
+template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 1024, scap = 232, lcap = 1280, wcap = 1536, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 #endif
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = DACC_T2_WCAP, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
 template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
@@ -428,7 +428,8 @@ struct FastLds<CT,true>
 	FLD(lscr,uint8_t,lscrbytes,e_cseq)
 	FLD(siq,FSI,CT::siqcap,e_cseq)
 	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
-	static constexpr uint32_t uB = fcmax(e_consL,e_lscr);
+	// (the scratch tables of the stretch construction need 6 bytes per node: the region is at least that long)
+	static constexpr uint32_t uB = fcmax(fcmax(e_consL,e_lscr),xbase + 6u*CT::ncap + 16u);
 	static constexpr uint32_t xbytes = uB - xbase;
 	// raw stretches: over the pattern masks and weight offsets, which the feasibility writes later
 	FLD(tfirst,uint16_t,CT::scap,o_maskF)

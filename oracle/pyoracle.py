@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 from daccord_amd._structs import (DaccParams, DaccOverlap, DaccPile, DaccFragment, DaccWindowResult)  # noqa: E402
 
-_SO = os.path.join(_HERE, "liboracle.so")
+_SO = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")      # ORACLE_LIB: a separately built copy (scripts/exposure_report.py)
 
 
 def build(force=False):

@@ -50,6 +50,10 @@ def main():
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 6
     tmp = os.path.join(ROOT, "gpurun_out", "exposure"); os.makedirs(tmp, exist_ok=True)
+    # a private build of the oracle (the switches are compiled in; other test runs may have the shared copy loaded)
+    so = os.path.join(tmp, "liboracle_sw.so")
+    subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", so, os.path.join(ROOT, "oracle", "oracle_capi.cpp")])
+    os.environ["ORACLE_LIB"] = so
     res = []
     for i, (name, env) in enumerate(VARIANTS):
         out = os.path.join(tmp, "v%02d.npz" % i)
