@@ -204,7 +204,7 @@ struct BatchPlan
 		// A batch whose windows are mostly too deep for tier 1 (coverage of 40x and more) starts in the deep tier instead
 		deep = 2*ndeepwin > nwindows;
 		ftier[0] = deep ? fastCapsOf< FastTier<4> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
-		ftier[1] = fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup);
+		ftier[1] = deep ? fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<6> >(tab_nrows,tab_nsup);
 		ftierL = fastCapsOf< FastTier<5> >(tab_nrows,tab_nsup);
 		ftier[2] = fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;

@@ -613,7 +613,8 @@ static int runDevice(dacc_ctx * c)
 					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
 					if ( t == 0 && BP.deep ) hipLaunchKernelGGL(k_window_fast<4>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
-					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( t == 1 && BP.deep ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<6>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					list = c->d_retry[t].p;
 					if ( !early )
@@ -828,7 +829,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);
 		if ( c->tierL_ok && BP.ftierL.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_long),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftierL.ldsbytes));
-		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<2>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
+		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<2>) : reinterpret_cast<const void *>(k_window_fast<6>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
 		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = boundByArena(wg < 512 ? wg : 512,BP.caps.bytes,8);
 		c->win_grid = c->retry_grid;

@@ -76,7 +76,7 @@ template<int TIER> struct FastTier;
 #if defined(DACC_T1_LEGACY)
 template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 #else
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96 }; };
 #endif
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 #if defined(DACC_T2_LEGACY)
@@ -84,6 +84,12 @@ template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 0, 
 #else
 template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 1024, scap = 232, lcap = 1280, wcap = 1536, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 #endif
+// tier 6 (second slot of SHALLOW batches since round 3, gw layout, 36 KB = 4 wavefronts per CU): what tier 1 hands on at 20x
+// are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
+// tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep
+// tier 2 (64 strings, 2048 instances) behind the deep tier.
+template<> struct FastTier<6> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 900, scap = 192, lcap = 1024, wcap = 1536, rccap = 192, fcap = 256, siqcap = 96, blcap = 96 }; };
+
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
 template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
@@ -795,6 +801,7 @@ struct FastEngine
 			L.sinfo()[z] = order | (n<<8) | (act<<11);
 		}
 		wv_sync();
+		sfresh = true;      // S has been rebuilt (instances / nodes / successors of this pass): the next traversal spills all of it
 	}
 	// after buildNodes: no first k-mer candidate, or none of the last k-mer candidates (count >= 3/4 of the best, :4774-4784)
 	// is a node of the filtered graph
@@ -828,6 +835,7 @@ struct FastEngine
 			L.sinfo()[z] = (L.sinfo()[z] & 0x7FF) | (a<<11);
 		}
 		wv_sync();
+		sdirty = true;
 		return true;
 	}
 
@@ -2492,15 +2500,23 @@ struct FastEngine
 	// gw layout: the enumeration pools lie over the build-phase arrays (region S); S goes to the workgroup's global slab
 	// before the enumerations and comes back after the pairs (candidate errors need the pattern masks, the next
 	// activation state the successor tables, the next traversal all of it)
+	// Only the part of S the pools cover is copied.  The spilled image stays valid for the following traversals of the same
+	// pass (only the successor flags change between them, addNextFromHeap): sfresh = the build phase has rewritten S,
+	// sdirty = the successor flags have changed since the last spill.
+	bool sfresh, sdirty;
 	DEV void spillS()
 	{
 		if constexpr ( GW )
 		{
 			typedef FastLds<CT> LL;
+			constexpr uint32_t plen = ((LL::upool - LL::sbase + 15u) & ~15u) < LL::sbytes ? ((LL::upool - LL::sbase + 15u) & ~15u) : LL::sbytes;
+			constexpr uint32_t si0 = (LL::o_sinfo - LL::sbase) & ~15u, si1 = ((LL::e_sinfo - LL::sbase + 15u) & ~15u) < plen ? ((LL::e_sinfo - LL::sbase + 15u) & ~15u) : plen;
 			LDSQ G4 const * const src = reinterpret_cast<LDSQ G4 const *>(L.base + LL::sbase);
 			G4 * const dst = reinterpret_cast<G4 *>(gslab + LL::g_spill);
 			wv_sync();
-			for ( uint32_t i = lane; i < LL::sbytes/16u; i += WSZ ) dst[i] = src[i];
+			if ( sfresh ) { for ( uint32_t i = lane; i < plen/16u; i += WSZ ) dst[i] = src[i]; }
+			else if ( sdirty && si0 < si1 ) { for ( uint32_t i = si0/16u + lane; i < si1/16u; i += WSZ ) dst[i] = src[i]; }
+			sfresh = false; sdirty = false;
 			wv_sync();
 		}
 	}
@@ -2509,10 +2525,11 @@ struct FastEngine
 		if constexpr ( GW )
 		{
 			typedef FastLds<CT> LL;
+			constexpr uint32_t plen = ((LL::upool - LL::sbase + 15u) & ~15u) < LL::sbytes ? ((LL::upool - LL::sbase + 15u) & ~15u) : LL::sbytes;
 			LDSQ G4 * const dst = reinterpret_cast<LDSQ G4 *>(L.base + LL::sbase);
 			G4 const * const src = reinterpret_cast<G4 const *>(gslab + LL::g_spill);
 			wv_sync();
-			for ( uint32_t i = lane; i < LL::sbytes/16u; i += WSZ ) dst[i] = src[i];
+			for ( uint32_t i = lane; i < plen/16u; i += WSZ ) dst[i] = src[i];
 			wv_sync();
 		}
 	}
@@ -3136,7 +3153,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
 	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
-	E.gslab = 0; E.gtab = FB.tab32;
+	E.gslab = 0; E.gtab = FB.tab32; E.sfresh = true; E.sdirty = false;
 	if ( CT::gw )
 	{
 #if defined(DACC_EMUL)

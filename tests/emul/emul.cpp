@@ -183,7 +183,8 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			wave_run([&]() {
 				if ( t == 0 && BP.deep ) { FastLds< FastTier<4> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
 				else if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
-				else if ( t == 1 ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+				else if ( t == 1 && BP.deep ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+				else if ( t == 1 ) { FastLds< FastTier<6> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 				else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 			});
 		};
@@ -206,7 +207,8 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				int r;
 				if ( t == 0 && BP.deep ) r = processWindowFast< FastTier<4> >(FB[0],wdx,lds[0].data(),resume);
 				else if ( t == 0 ) r = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),resume);
-				else if ( t == 1 ) r = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),resume);
+				else if ( t == 1 && BP.deep ) r = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),resume);
+				else if ( t == 1 ) r = processWindowFast< FastTier<6> >(FB[1],wdx,lds[1].data(),resume);
 				else r = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),resume);
 				if ( wv_lane() == 0 ) rc = r;
 			});

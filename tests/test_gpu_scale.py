@@ -24,7 +24,7 @@ def _golden(name):
         return json.load(f)
 
 
-@pytest.mark.parametrize("name", ["cfg1k8", "cfg4", "cfg5", "cfg2"])
+@pytest.mark.parametrize("name", ["cfg1k8", "cfg4", "cfg4b", "cfg5", "cfg3", "cfg2", "cfg2s"])
 def test_scale_case_matches_oracle_digests(name):
     G = _golden(name)
     case = CASES[name]
@@ -40,9 +40,9 @@ def test_scale_case_matches_oracle_digests(name):
         print("%s %s: %d windows, %d bases, window kernel %.1f ms, tiers handed on %s"
               % (name, run["params"], len(w), len(bx), t.window_ms, list(t.tier_out)))
         assert len(w) == run["nwindows"]
-        if name == "cfg4":
+        if name in ("cfg4", "cfg4b"):
             # deep piles start in the deep tier; only windows with more than 250 stretches are left to the generic engine
-            assert t.tier_out[0] < 0.2 * len(w) and t.tier_out[2] <= 100, list(t.tier_out)
+            assert t.tier_out[0] < 0.2 * len(w) and t.tier_out[2] <= 100 * max(1, len(w) // 50000), list(t.tier_out)
         pd = pile_digests(fx, bx, sel, engine.fasta)
         badp = [i for i, (a, b) in enumerate(zip(pd, run["pile_sha256"])) if a != b]
         assert badp == [], ("piles whose FASTA differs from the oracle's", run["params"], len(badp), badp[:10])
