@@ -75,24 +75,39 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # test hook (tests/test_gpu_bench_ranks.py): DACC_BENCH_ONE_DEVICE=1 runs every rank on device 0 over gloo, so that the
+    # N > 1 code path of this very script can be exercised on a box with a single GPU; never set by the driver
+    one_device = os.environ.get("DACC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = "gloo" if one_device else "nccl"
+    gdev = "cpu" if one_device else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from daccord_amd import engine, shard
     from daccord_amd._structs import default_params
     from daccord_amd.synth import SynthData
 
-    # one synthetic data set, the same on every rank; rank g corrects the -J g,G part of it
+    # one synthetic data set; rank g corrects the -J g,G part of it (A-read range rule of
+    # src/daccord.cpp:1156-1183 over [0, total_reads)).  Every rank generates all READS (B reads are arbitrary; the 2-bit
+    # store is replicated per GPU) but only the overlaps / piles of ITS A reads: the records are identical to those of the
+    # full set (daccord_amd/synth: aread_range), so N ranks do 1/N of the setup each instead of all of it N times.
     total_reads = args.reads * world if args.scaling == "weak" else args.reads
     genome = int(total_reads * args.readlen / args.coverage)
     ncpu = os.cpu_count() or 1
     t0 = time.time()
     skw = dict(ins_frac=1 / 3.0, del_frac=1 / 3.0, sub_frac=1 / 3.0) if args.ont else {}
-    d = SynthData(genome, total_reads, args.readlen, seed=args.seed, nthreads=max(1, ncpu // max(world, 1)), **skw)
-    ovl, allpiles = engine.pile_select(d.ovl, d.piles)
-    piles = shard.shard_piles(allpiles, rank, world)
+    arange = shard.shard_range(0, total_reads, rank, world)
+    d = SynthData(genome, total_reads, args.readlen, seed=args.seed, nthreads=max(1, ncpu // max(world, 1)),
+                  aread_range=(arange if world > 1 else None), **skw)
+    ovl, piles = engine.pile_select(d.ovl, d.piles)
+    npiles_total = total_reads            # one pile per A read, pile index = A read id
     tgen = time.time() - t0
 
     p = default_params(k=args.k, device=local_rank)
@@ -110,7 +125,7 @@ def main():
         E.rerun()
         fr, ba = E.collect()
         # the only communication of a step: corrected fragments of all ranks to rank 0 (RCCL gather; no-op at N=1)
-        gathered[0], gathered[1] = shard.gather_fragments(fr, ba, device="cuda")
+        gathered[0], gathered[1] = shard.gather_fragments(fr, ba, device=gdev)
 
     for _ in range(args.warmup):
         step()
@@ -131,8 +146,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    nb = torch.tensor([float(len(bases))], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
+    nb = torch.tensor([float(len(bases))], dtype=torch.float64, device=gdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nb, op=dist.ReduceOp.SUM)
@@ -183,13 +198,14 @@ def main():
             pass
         res = {
             "metric": "corrected Mbase/s (whole node), synthetic 20x PacBio piles",
-            "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u64+f64", "data": "synthetic",
             "config": {"workload": "synthetic %d A-reads x %d b x %.0fx%s, 15%% error (%s), k=%d, w=40, a=10, tspace=100"
                        % (total_reads, args.readlen, args.coverage, " (%d per GPU)" % args.reads if args.scaling == "weak" and world > 1 else "",
                           "ins/del/sub 1/3 each" if args.ont else "ins 80/del 13.3/sub 6.7", args.k),
-                       "piles_total": int(len(allpiles)), "piles_rank0": int(len(piles)), "overlaps_total": int(len(ovl)), "windows_rank0": int(t.nwindows),
+                       "piles_total": int(npiles_total), "piles_rank0": int(len(piles)), "overlaps_rank0": int(len(ovl)), "windows_rank0": int(t.nwindows),
                        "trace_blocks_rank0": int(t.nblocks), "corrected_bases_total": int(total_bases),
                        "sharding": "one data set, A-read ranges as -J g,G (daccord.cpp:1156-1183), no data-path collective; RCCL gather of corrected fragments per step"},
             "roofline": roof,
@@ -202,7 +218,7 @@ def main():
             for i in range(0, len(fr), 256):
                 h.update(engine.fasta(fr[i:i + 256], ba, start_well=well).encode()); well += len(fr[i:i + 256])
             return h.hexdigest()
-        par = {"gpu_fasta_sha256_all": fasta_sha256(allfr, allba), "piles_all": int(len(allpiles))}
+        par = {"gpu_fasta_sha256_all": fasta_sha256(allfr, allba), "piles_all": int(npiles_total)}
         # The oracle's committed digests (build container, tests/golden/make_golden_scale.py): piles STRATIFIED over the whole
         # batch -- the first 62, 125 around each of the seven interior boundaries of the eight per-XCD window queues, the last
         # 125 (scale_cfg2s.json) -- and, if present, the first 1000 piles (scale_cfg2.json); default workload only.  Other
@@ -215,7 +231,7 @@ def main():
             GG = json.load(open(gold)); G = GG["runs"][0]; spec = GG["spec"]
             ranges = spec.get("pile_ranges") or [[spec["first"], spec["first"] + spec["npiles"]]]
             idx = np.concatenate([np.arange(a, b) for a, b in ranges])
-            areads = allpiles["aread"][idx]
+            areads = idx                 # pile index = A read id in the synthetic sets
             sel = allfr[np.isin(allfr["aread"], areads)]
             h = fasta_sha256(sel, allba)
             out = {"fixture": "tests/golden/scale_%s.json" % name, "piles_compared": int(len(idx)), "pile_ranges": ranges,
@@ -238,8 +254,8 @@ def main():
         # the only quality figure that does not depend on the oracle ----
         try:
             from daccord_amd import checkconsensus
-            nacc = min(len(allpiles), 200)
-            lim = int(allpiles[nacc - 1]["aread"])
+            nacc = min(npiles_total, 200)
+            lim = nacc - 1
             _, acc = checkconsensus.check(allfr[allfr["aread"] <= lim], allba, d.genome, d.truth, d.rlen)
             acc["sample"] = "first %d reads, every fragment aligned to the true sequence of its read interval" % nacc
             acc["raw_read_erate"] = 0.15
@@ -304,6 +320,39 @@ def main():
                 "note": "the oracle follows the reference and recomputes stretches, feasibility and both path enumerations for every "
                         "(first,last) k-mer pair; the GPU path caches them per k-mer, so the ratio is not like for like",
             }
+            # like for like: the SAME algorithm as the kernels (cached enumerations, tiers, reachability prune) compiled for the
+            # host -- the 1-lane build of the kernel headers that the CPU tests use (tests/emul) -- one context per thread on
+            # all usable cores over a bounded sample of the same batch.  GPU / this = what the chip buys for this algorithm.
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import emul_lib
+                from concurrent.futures import ThreadPoolExecutor
+                nl = min(len(piles) - first, max(nthr, nthr * 6))
+                chunks = [piles[first + i:first + nl:nthr] for i in range(nthr)]
+                def work(ch):
+                    if len(ch) == 0:
+                        return 0, b""
+                    Em = emul_lib.Emul(p); Em.set_error_profile(*d.error_profile()); Em.load_db(d.bps, d.boff, d.rlen)
+                    fe, be = Em.run(ch, ovl, d.trace)
+                    return len(be), hashlib.sha256(engine.fasta(fe, be).encode()).digest()
+                emul_lib.lib(1)
+                tc = time.perf_counter()
+                with ThreadPoolExecutor(nthr) as ex:
+                    outs = list(ex.map(work, chunks))
+                tl = time.perf_counter() - tc
+                same = True
+                for ch, (nbs, dg) in zip(chunks, outs):
+                    if len(ch):
+                        g = frags[np.isin(frags["aread"], ch["aread"])]
+                        same = same and hashlib.sha256(engine.fasta(g, bases).encode()).digest() == dg
+                lb = sum(o[0] for o in outs)
+                res["cpu_baseline"]["like_for_like"] = {
+                    "value": round(lb / tl / 1e6, 5), "unit": "Mbase/s", "cores": nthr, "kind": "port",
+                    "what": "the kernels' own algorithm (tests/emul: kernel headers compiled as a 1-lane wavefront, g++ -O2), one context per thread",
+                    "sample": "%d piles of the same batch behind pile %d, %.1f s" % (nl, first, tl),
+                    "identical_to_gpu_on_sample": bool(same), "gpu_over_this": round(value / max(lb / tl / 1e6, 1e-12), 1)}
+            except Exception as ex:
+                res["cpu_baseline"]["like_for_like"] = {"error": repr(ex)[:200]}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

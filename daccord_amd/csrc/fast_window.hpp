@@ -552,8 +552,9 @@ static inline void feasit_dump()
 	fprintf(f,"%zu %llu %llu %llu %llu\n",it.size(),(unsigned long long)tot,(unsigned long long)lock,(unsigned long long)locksorted,(unsigned long long)lockcls);
 	g_feasit.clear();
 }
-#define FEAS_ITERS(t,len,n) { g_feasit.it.push_back(n); g_feasit.ln.push_back(len); }
-#define FEAS_DUMP() feasit_dump();
+static inline bool feasit_on() { static int on = -1; if ( on < 0 ) on = getenv("DACC_EMUL_FEAS") ? 1 : 0; return on == 1; }      // single threaded design aid only
+#define FEAS_ITERS(t,len,n) { if ( feasit_on() ) { g_feasit.it.push_back(n); g_feasit.ln.push_back(len); } }
+#define FEAS_DUMP() { if ( feasit_on() ) feasit_dump(); }
 #else
 #define FEAS_ITERS(t,len,n)
 #define FEAS_DUMP()
@@ -581,7 +582,7 @@ struct FastEngine
 
 #if defined(DACC_EMUL)
 	// emulation only: DACC_EMUL_OVER=1 reports where a tier overflowed
-	DEV void over_(uint32_t b, int line) { flags |= b; static char const * ov = getenv("DACC_EMUL_OVER"); if ( ov ) fprintf(stderr,"[over] tier maxs=%d line %d bits 0x%x nn=%u n0=%u npool=%u nF=%u nL=%u nwF=%u nwR=%u rstop=%u\n",int(CT::maxs),line,b,nn,n0,npool,nF,nL,nwF,nwR,rstop); }
+	DEV void over_(uint32_t b, int line) { flags |= b; static char const * ov = getenv("DACC_EMUL_OVER"); if ( ov ) fprintf(stderr,"[over] tier maxs=%d line %d bits 0x%x nn=%u n0=%u npool=%u nF=%u nL=%u nwF=%u nwR=%u rstop=%u\n",int(CT::maxs)*10000+int(CT::ncap),line,b,nn,n0,npool,nF,nL,nwF,nwR,rstop); }
 	#define over(b) over_(b,__LINE__)
 #else
 	DEV void over(uint32_t b) { flags |= b; }

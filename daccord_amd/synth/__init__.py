@@ -13,7 +13,7 @@ class SynthParams(C.Structure):
     _fields_ = [("genome_len", C.c_uint64), ("nreads", C.c_uint32), ("read_len", C.c_uint32),
                 ("p_ins", C.c_double), ("p_del", C.c_double), ("p_sub", C.c_double),
                 ("min_overlap", C.c_uint32), ("tspace", C.c_int32), ("seed", C.c_uint64),
-                ("nthreads", C.c_int32), ("reserved", C.c_int32)]
+                ("nthreads", C.c_int32), ("reserved", C.c_int32), ("afirst", C.c_uint32), ("alast", C.c_uint32)]
 
 
 def build(force=False):
@@ -42,10 +42,13 @@ class SynthData:
     """Host-side synthetic data set: 2-bit read store + overlaps + trace points + piles."""
 
     def __init__(self, genome_len, nreads, read_len, erate=0.15, ins_frac=0.8, del_frac=0.1333333333, sub_frac=0.0666666667,
-                 min_overlap=1000, tspace=100, seed=1, nthreads=None):
+                 min_overlap=1000, tspace=100, seed=1, nthreads=None, aread_range=None):
+        """aread_range = (first, last): overlaps and piles only for these A reads (every read of the set is generated, B reads
+        are arbitrary); the records are identical to the corresponding ones of the full set."""
         lib = _load()
         p = SynthParams(genome_len, nreads, read_len, erate * ins_frac, erate * del_frac, erate * sub_frac,
-                        min_overlap, tspace, seed, nthreads or (os.cpu_count() or 1), 0)
+                        min_overlap, tspace, seed, nthreads or (os.cpu_count() or 1), 0,
+                        aread_range[0] if aread_range else 0, aread_range[1] if aread_range else 0)
         self.p_ins, self.p_del, self.p_sub = p.p_ins, p.p_del, p.p_sub
         self.tspace = tspace
         self._h = lib.synth_generate(C.byref(p))

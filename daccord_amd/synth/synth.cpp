@@ -64,6 +64,7 @@ typedef struct synth_params
 	uint64_t genome_len; uint32_t nreads; uint32_t read_len;
 	double p_ins, p_del, p_sub;
 	uint32_t min_overlap; int32_t tspace; uint64_t seed; int32_t nthreads; int32_t reserved;
+	uint32_t afirst, alast;      // overlaps / piles only for the A reads in [afirst,alast) (alast == 0: all); every read is generated either way
 } synth_params;
 
 void * synth_generate(synth_params const * P)
@@ -138,10 +139,11 @@ void * synth_generate(synth_params const * P)
 	std::vector< std::vector<uint16_t> > PT(P->nreads);
 	int const nth = P->nthreads > 0 ? P->nthreads : 1;
 	int64_t const ts = P->tspace;
+	int64_t const a_lo = P->alast ? static_cast<int64_t>(P->afirst) : 0, a_hi = P->alast ? std::min<int64_t>(P->alast,P->nreads) : static_cast<int64_t>(P->nreads);
 	#ifdef _OPENMP
 	#pragma omp parallel for schedule(dynamic,8) num_threads(nth)
 	#endif
-	for ( int64_t a = 0; a < static_cast<int64_t>(P->nreads); ++a )
+	for ( int64_t a = a_lo; a < a_hi; ++a )
 	{
 		SynthRead const & A = S->reads[a];
 		std::vector<uint32_t> partners;
@@ -249,7 +251,7 @@ void * synth_generate(synth_params const * P)
 			PO[a].push_back(O);
 		}
 	}
-	for ( uint32_t a = 0; a < P->nreads; ++a )
+	for ( uint32_t a = static_cast<uint32_t>(a_lo); a < static_cast<uint32_t>(a_hi); ++a )
 	{
 		dacc_pile pile; pile.aread = a; pile.novl = PO[a].size(); pile.first_ovl = S->ovl.size();
 		uint64_t const tbase = wide ? S->trace.size()/2 : S->trace.size();      // offsets count trace values

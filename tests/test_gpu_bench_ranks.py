@@ -1,0 +1,41 @@
+"""The N > 1 path of bench.py itself (VERDICT r02 task 6): two ranks launched exactly as the driver launches them
+(python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...), in weak and in strong scaling mode, must return
+the FASTA of the N = 1 run over the same reads: per-rank overlap generation, -J sharding, gather in rank order, sequential
+well numbers.  The test box has ONE GPU, so the ranks share device 0 and talk over gloo (DACC_BENCH_ONE_DEVICE=1, a hook that
+only changes the device ordinal and the backend); on a multi-GPU node the same script runs one rank per GPU over RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(n, reads, scaling):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    common = ["--reads", str(reads), "--readlen", "5000", "--steps", "1", "--warmup", "0", "--no-cpu", "--scaling", scaling]
+    env = dict(os.environ, DACC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if n == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + common
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_two_ranks_weak_and_strong_equal_one_rank():
+    one = _run(1, 240, "weak")
+    weak = _run(2, 120, "weak")            # 2 x 120 reads = the same 240 read set
+    strong = _run(2, 240, "strong")
+    assert one["n_gpus"] == 1 and weak["n_gpus"] == 2 and weak["ranks"] == 2 and strong["ranks"] == 2
+    assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    d1 = one["parity"]["gpu_fasta_sha256_all"]
+    assert weak["parity"]["gpu_fasta_sha256_all"] == d1 and strong["parity"]["gpu_fasta_sha256_all"] == d1
+    assert weak["config"]["corrected_bases_total"] == one["config"]["corrected_bases_total"] == strong["config"]["corrected_bases_total"]
+    assert weak["config"]["piles_rank0"] == 120 and strong["config"]["piles_rank0"] == 120 and one["config"]["piles_rank0"] == 240
