@@ -74,35 +74,42 @@ template<int TIER> struct FastTier;
 // round trips of the first almost completely (profiles/r03a_occupancy_experiment.md), so LDS bytes per window decide the
 // throughput: tier 1 is 26.3 KB = 6 wavefronts per CU with (almost) the capacities it had at 53.8 KB = 3 per CU.
 #if defined(DACC_T1_LEGACY)
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 640, scap = 112, lcap = 768, wcap = 600, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 #else
-template<> struct FastTier<1> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96 }; };
 #endif
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 #if defined(DACC_T2_LEGACY)
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = 992, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = 992, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 #else
-template<> struct FastTier<2> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 1024, scap = 232, lcap = 1280, wcap = 1536, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 1024, scap = 232, lcap = 1280, wcap = 1536, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
 #endif
 // tier 6 (second slot of SHALLOW batches since round 3, gw layout, 36 KB = 4 wavefronts per CU): what tier 1 hands on at 20x
 // are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
 // tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep
 // tier 2 (64 strings, 2048 instances) behind the deep tier.
-template<> struct FastTier<6> { typedef uint8_t id_t; enum : uint32_t { gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 900, scap = 192, lcap = 1024, wcap = 1536, rccap = 192, fcap = 256, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 900, scap = 192, lcap = 1024, wcap = 1536, rccap = 192, fcap = 256, siqcap = 96, blcap = 96 }; };
 
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
-template<> struct FastTier<3> { typedef uint16_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+#if defined(DACC_T3_LEGACY)
+template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2112, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+#else
+// gw layout and 16 bit STRETCH ids since round 3: what the legacy tier 3 handed to the generic engine at 54x were windows with
+// more than 250 stretches (13 of 19 per 60 000 windows) or more than 2112 feasible weights (5 of 19), and each of them cost the
+// generic engine seconds (685 such windows were 92 % of a 2000-pile 54x batch, profiles/r03c_bench_54x_2000piles.log)
+template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+#endif
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
 // small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
 // has about a hundred nodes, while the 55 strings of a window carry 1500 k-mer instances.
-template<> struct FastTier<4> { typedef uint8_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<4> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
 
 // tier 5 (one wavefront per CU, only for the windows the pre-scan found): B strings of up to 128 bases (string stride 128,
 // two words per pattern mask); everything else as tier 3 with 64 strings.  Window strings of more than 64 bases are rare
 // at the default window (a few per ten million windows of config 2) but each of them costs the generic engine seconds.
-template<> struct FastTier<5> { typedef uint16_t id_t; enum : uint32_t { gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<5> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -131,6 +138,8 @@ struct FastLds<CT,false>
 	// ---- live during the whole window ----
 	static_assert(CT::lstr == 64 || CT::lstr == 128,"string stride: one or two 64 bit words per pattern mask");
 	static constexpr uint32_t pw = CT::lstr/64;      // words per pattern mask
+	typedef uint8_t sid_t;      // stretch ids are 8 bits in the legacy layout
+	static_assert(sizeof(typename CT::sid_t) == 1,"16 bit stretch ids need the gw layout");
 	FLD(str,uint8_t,CT::maxs*CT::lstr,0)
 	FLD(slen,uint8_t,CT::maxs,e_str)
 	FLD(peq,uint64_t,CT::maxs*4*pw,e_slen)      // pattern masks of string j: words 4*pw*j + pw*symbol + word
@@ -325,6 +334,7 @@ struct FastLds<CT,true>
 	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
 	static_assert(CT::lstr == 64,"the gw layout holds strings of up to 64 bases");
 	static constexpr uint32_t pw = CT::lstr/64;
+	typedef typename CT::sid_t sid_t;      // stretch ids: 8 bits (at most 250 stretches) or 16 bits
 	// ---- P ----
 	FLD(slen,uint8_t,CT::maxs,0)
 	FLD(suplo8,uint8_t,FSUPCAP,e_slen)
@@ -337,7 +347,7 @@ struct FastLds<CT,true>
 	FLD(sstack,uint16_t,3*24,e_vln)
 	FLD(chain,uint8_t,64,e_sstack)
 	FLD(nv,uint32_t,CT::ncap,e_chain)
-	FLD(npred,uint8_t,CT::ncap,e_nv)
+	FLD(npred,sid_t,CT::ncap,e_nv)
 	FLD(bestL,uint8_t,MAXCONS,e_npred)
 	static constexpr uint32_t sbase = (e_bestL + 15u) & ~15u;
 	// ---- S (spilled while the pools are live) ----
@@ -357,7 +367,7 @@ struct FastLds<CT,true>
 	// ---- enumeration pools: overlay of S ----
 	FLD(rc_w,uint64_t,CT::rccap,sbase)
 	FLD(rc_parent,typename CT::id_t,CT::rccap,e_rc_w)
-	FLD(rc_stretch,uint8_t,CT::rccap,e_rc_parent)
+	FLD(rc_stretch,sid_t,CT::rccap,e_rc_parent)
 	FLD(rc_pos,uint8_t,CT::rccap,e_rc_stretch)
 	FLD(rc_len,uint8_t,CT::rccap,e_rc_pos)
 	FLD(rc_baselen,uint8_t,CT::rccap,e_rc_len)
@@ -373,7 +383,7 @@ struct FastLds<CT,true>
 	FLD(rfmask,uint64_t,CT::fnc+1,e_rtmask)
 	FLD(f_w,uint64_t,CT::fcap,e_rfmask)
 	FLD(f_parent,typename CT::id_t,CT::fcap,e_f_w)
-	FLD(f_stretch,uint8_t,CT::fcap,e_f_parent)
+	FLD(f_stretch,sid_t,CT::fcap,e_f_parent)
 	FLD(f_pos,uint8_t,CT::fcap,e_f_stretch)
 	FLD(f_baselen,uint8_t,CT::fcap,e_f_pos)
 	FLD(f_len,uint8_t,CT::fcap,e_f_baselen)
@@ -409,22 +419,22 @@ struct FastLds<CT,true>
 	FLD(woffF,uint16_t,CT::scap,e_maskR)
 	FLD(woffR,uint16_t,CT::scap,e_woffF)
 	FLD(links,uint16_t,CT::lcap,e_woffR)
-	FLD(lhead,uint8_t,CT::ncap,e_links)
+	FLD(lhead,sid_t,CT::ncap,e_links)
 	FLD(lord,uint32_t,CT::scap,e_lhead)
-	FLD(ppos,uint8_t,CT::scap,e_lord)
+	FLD(ppos,sid_t,CT::scap,e_lord)
 	FLD(fkmer,uint32_t,CT::fnc,e_ppos)
 	FLD(lkmer,uint32_t,CT::fnc,e_fkmer)
 	FLD(fnode,uint16_t,CT::fnc,e_lkmer)
 	FLD(lnode,uint16_t,CT::fnc,e_fnode)
-	FLD(parF,uint8_t,CT::fnc,e_lnode)
+	FLD(parF,sid_t,CT::fnc,e_lnode)
 	FLD(posF,uint8_t,CT::fnc,e_parF)
-	FLD(parL,uint8_t,CT::fnc,e_posF)
+	FLD(parL,sid_t,CT::fnc,e_posF)
 	FLD(posL,uint8_t,CT::fnc,e_parL)
-	FLD(pieF,uint8_t,CT::fnc,e_posL)
-	FLD(pieL,uint8_t,CT::fnc,e_pieF)
+	FLD(pieF,sid_t,CT::fnc,e_posL)
+	FLD(pieL,sid_t,CT::fnc,e_pieF)
 	static constexpr uint32_t xbase = (e_pieL + 15u) & ~15u;
 	FLD(cdh,FCC,16,xbase)
-	FLD(cseq,uint8_t,18*FSEQCAP,e_cdh)
+	FLD(cseq,sid_t,18*FSEQCAP,e_cdh)
 	FLD(ch,FCC,16,e_cseq)
 	FLD(acc,FCC,16,e_ch)
 	FLD(accerr,uint32_t,16,e_acc)
@@ -435,7 +445,7 @@ struct FastLds<CT,true>
 	FLD(siq,FSI,CT::siqcap,e_cseq)
 	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
 	// (the scratch tables of the stretch construction need 6 bytes per node: the region is at least that long)
-	static constexpr uint32_t uB = fcmax(fcmax(e_consL,e_lscr),xbase + 6u*CT::ncap + 16u);
+	static constexpr uint32_t uB = fcmax(fcmax(fcmax(e_consL,e_lscr),xbase + 6u*CT::ncap + 16u),xbase + (2u*CT::scap+2u)*2u + 8u + 8u*CT::scap + 16u);
 	static constexpr uint32_t xbytes = uB - xbase;
 	// raw stretches: over the pattern masks and weight offsets, which the feasibility writes later
 	FLD(tfirst,uint16_t,CT::scap,o_maskF)
@@ -450,11 +460,9 @@ struct FastLds<CT,true>
 	FLD(albot,uint16_t,MAXCONS+1,e_almv)
 	FLD(alops,uint8_t,2*MAXCONS+2*64+8,e_albot)
 	static_assert(e_alops <= uB,"final alignment scratch");
-	static constexpr uint32_t taskbytes = ((2*CT::scap+2)*2 + 2*(2*CT::scap) + 15u) & ~15u;
 	FLD(toff,uint16_t,2*CT::scap+2,xbase)
-	FLD(ulo,uint8_t,2*CT::scap,e_toff)
-	FLD(uhi,uint8_t,2*CT::scap,e_ulo)
-	static_assert(e_uhi <= uB,"feasibility tasks");
+	FLD(urec,uint32_t,2*CT::scap,e_toff)      // unit at position q of the processing order: lo | unit << 7
+	static_assert(e_urec <= uB,"feasibility tasks");
 	static_assert(6u*CT::ncap + 16u <= xbytes,"predecessor counts and walking table must fit the scratch");
 	static_assert(3u*CT::ncap + 16u <= xbytes && 2u*CT::ncap + CT::scap + 8u <= xbytes,"interior node table / reachability scratch");
 	HDEV LDSQ uint32_t * xcnt32() const { return reinterpret_cast<LDSQ uint32_t *>(base + xbase); }
@@ -566,6 +574,8 @@ template<typename CT>
 struct FastEngine
 {
 	typedef typename CT::id_t id_t;      // path ids inside one enumeration
+	typedef typename CT::sid_t sid_t;    // stretch ids (pool ids of the stretches and pieces of a traversal)
+	enum : uint32_t { SB = 8u*sizeof(sid_t), SMASK = (1u<<SB)-1u, SNONE = SMASK, SMAX = CT::smax };      // SNONE: no stretch (SNONE of the 8 bit tiers)
 	FastLds<CT> L; DevTables T; DevParams P;
 	uint32_t nrows, nsup;
 	uint64_t const * vst;        // [nsup][nrows] fixed-point model table in HBM
@@ -984,11 +994,13 @@ struct FastEngine
 		return len;
 	}
 	// (first, ext, len desc, last) packed into 56 bits: Stretch::operator< (node ids ascend with k-mer value)
+	// (8 bit stretch ids: four 14 bit fields = 56 bits next to the id; 16 bit ids: four 12 bit fields = 48 bits)
+	enum : uint32_t { KF = (sizeof(sid_t) == 1 ? 14u : 12u), KFMAX = (1u<<KF)-1u };
 	DEV static uint64_t sortKey(uint32_t first, uint32_t ext, uint32_t len, uint32_t last)
 	{
-		return (static_cast<uint64_t>(first)<<42) | (static_cast<uint64_t>(ext)<<28) | (static_cast<uint64_t>(0x3FFF-len)<<14) | last;
+		return (static_cast<uint64_t>(first)<<(3*KF)) | (static_cast<uint64_t>(ext)<<(2*KF)) | (static_cast<uint64_t>(KFMAX-len)<<KF) | last;
 	}
-	DEV uint64_t poolKey(uint32_t const s) const { return sortKey(L.sfirst()[s],L.links()[L.slink()[s]+1],L.sslen()[s],L.slast()[s]); }
+	DEV uint64_t poolKey(uint32_t const s) const { uint32_t const len = L.sslen()[s]; return sortKey(L.sfirst()[s],L.links()[L.slink()[s]+1],len < KFMAX ? len : KFMAX,L.slast()[s]); }
 
 	// raw stretches of the current activation state, sorted by Stretch::operator< (pool ids 0..n0-1)
 	DEV void computeBaseStretches()
@@ -1006,7 +1018,7 @@ struct FastEngine
 			base += tot;
 		}
 		uint32_t const ns = base;
-		if ( ns + 2 > CT::scap || ns > 250 || nn >= 0x3FFF ) { over(32); n0 = 0; return; }
+		if ( ns + 2 > CT::scap || ns > SMAX || nn >= KFMAX ) { over(32); n0 = 0; return; }
 		wv_sync();
 		// walk every stretch once: the nodes go to a scratch slot of WSLOT entries per stretch in the (not yet used) weight
 		// arrays and are compacted into `links` below; a stretch without a slot or longer than it is walked a second time
@@ -1056,23 +1068,23 @@ struct FastEngine
 		wv_sync();
 		uint32_t const p2 = next_pow2(ns < 2 ? 2 : ns);
 		for ( uint32_t q = lane; q < p2; q += WSZ )
-			L.skey()[q] = q < ns ? ((sortKey(L.tfirst()[q],L.links()[L.tlink()[q]+1],L.tslen()[q],L.tlast()[q])<<8) | q) : ~0ull;
+			L.skey()[q] = q < ns ? ((sortKey(L.tfirst()[q],L.links()[L.tlink()[q]+1],L.tslen()[q] < KFMAX ? L.tslen()[q] : KFMAX,L.tlast()[q])<<SB) | q) : ~0ull;
 		wv_sync();
 		wv_sort_keys<fcpow2(CT::scap)>(L.skey(),ns);
 		// distinct (first,ext) by construction; a duplicate would need stretchesUnique's tie handling -> generic engine
 		uint32_t dup = 0;
 		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
-			if ( q && (L.skey()[q]>>36) == (L.skey()[q-1]>>36) ) dup = 1;
-			uint32_t const raw = L.skey()[q]&0xFF;
+			if ( q && (L.skey()[q]>>(SB+2*KF)) == (L.skey()[q-1]>>(SB+2*KF)) ) dup = 1;
+			uint32_t const raw = L.skey()[q]&SMASK;
 			L.sfirst()[q] = L.tfirst()[raw]; L.slast()[q] = L.tlast()[raw]; L.sslen()[q] = L.tslen()[raw]; L.slink()[q] = L.tlink()[raw];
 		}
 		if ( wv_any(dup) ) { over(32); n0 = 0; return; }
 		n0 = ns;
 		wv_sync();
 		// lookup by first node (base order is sorted by it) and by last node (ordered by (last, id))
-		for ( uint32_t z = lane; z < nn; z += WSZ ) { L.npred()[z] = 0xFF; L.lhead()[z] = 0xFF; }
-		for ( uint32_t q = lane; q < p2; q += WSZ ) L.skey()[q] = q < ns ? ((static_cast<uint64_t>(L.slast()[q])<<8) | q) : ~0ull;
+		for ( uint32_t z = lane; z < nn; z += WSZ ) { L.npred()[z] = SNONE; L.lhead()[z] = SNONE; }
+		for ( uint32_t q = lane; q < p2; q += WSZ ) L.skey()[q] = q < ns ? ((static_cast<uint64_t>(L.slast()[q])<<SB) | q) : ~0ull;
 		wv_sync();
 		for ( uint32_t q = lane; q < ns; q += WSZ ) if ( q == 0 || L.sfirst()[q-1] != L.sfirst()[q] ) L.npred()[L.sfirst()[q]] = q;
 		wv_sort_keys<fcpow2(CT::scap)>(L.skey(),ns);
@@ -1080,7 +1092,7 @@ struct FastEngine
 		{
 			uint64_t const e = L.skey()[q];
 			L.lord()[q] = static_cast<uint32_t>(e);
-			if ( q == 0 || (L.skey()[q-1]>>8) != (e>>8) ) L.lhead()[e>>8] = q;
+			if ( q == 0 || (L.skey()[q-1]>>SB) != (e>>SB) ) L.lhead()[e>>SB] = q;
 		}
 		wv_sync();
 	}
@@ -1101,7 +1113,7 @@ struct FastEngine
 		while ( cl < nmlast && static_cast<uint32_t>((~L.mlast()[cl])>>32) >= lastthres ) ++cl;
 		nF = cf; npool = n0;
 		if ( nF > FNC ) { nL = cl; over(8); return; }
-		for ( uint32_t i = lane; i < nF; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mfirst()[i]); L.fkmer()[i] = km; int32_t const z = findNode(km); L.fnode()[i] = z < 0 ? 0xFFFF : z; L.parF()[i] = FNOPAR; L.pieF()[i] = FNOPAR; }
+		for ( uint32_t i = lane; i < nF; i += WSZ ) { uint32_t const km = static_cast<uint32_t>(~L.mfirst()[i]); L.fkmer()[i] = km; int32_t const z = findNode(km); L.fnode()[i] = z < 0 ? 0xFFFF : z; L.parF()[i] = SNONE; L.pieF()[i] = SNONE; }
 		// Last k-mer candidates that are not nodes of the (filtered) graph are left out: their reverse enumeration is empty
 		// (prepareTraverse starts from the node of `last`), so none of their pairs can offer a candidate, and the pairs of
 		// the others keep their relative order.  In deep piles most strings end in a k-mer of their own, the list of
@@ -1115,7 +1127,7 @@ struct FastEngine
 				int32_t const z = i < cl ? findNode(km) : -1;
 				uint32_t tot; uint32_t const pre = wv_scan_flag(z >= 0,tot);
 				uint32_t const o = nl + pre;
-				if ( z >= 0 && o < FNC ) { L.lkmer()[o] = km; L.lnode()[o] = z; L.parL()[o] = FNOPAR; L.pieL()[o] = FNOPAR; }
+				if ( z >= 0 && o < FNC ) { L.lkmer()[o] = km; L.lnode()[o] = z; L.parL()[o] = SNONE; L.pieL()[o] = SNONE; }
 				nl += tot;
 			}
 			nL = nl;
@@ -1151,9 +1163,9 @@ struct FastEngine
 		wv_sync();
 		{
 			uint32_t cnt = 0;
-			for ( uint32_t c = 0; c < nF; ++c ) cnt += (L.parF()[c] != FNOPAR);
-			for ( uint32_t c = 0; c < nL; ++c ) cnt += (L.parL()[c] != FNOPAR);
-			if ( n0 + 2*cnt + 1 > CT::scap || n0 + 2*cnt + 1 > 250 ) { over(32); return; }
+			for ( uint32_t c = 0; c < nF; ++c ) cnt += (L.parF()[c] != SNONE);
+			for ( uint32_t c = 0; c < nL; ++c ) cnt += (L.parL()[c] != SNONE);
+			if ( n0 + 2*cnt + 1 > CT::scap || n0 + 2*cnt + 1 > SMAX ) { over(32); return; }
 		}
 		{
 			// pieces of the candidates that split a stretch, one lane per candidate (first k-mers, then last k-mers): two
@@ -1164,8 +1176,8 @@ struct FastEngine
 				uint32_t const c = c0 + lane;
 				bool const isF = c < nF, act = c < nF + nL;
 				uint32_t const ci = isF ? c : c - nF;
-				uint32_t const par = act ? (isF ? L.parF()[ci] : L.parL()[ci]) : static_cast<uint32_t>(FNOPAR);
-				bool const has = act && par != FNOPAR;
+				uint32_t const par = act ? (isF ? L.parF()[ci] : L.parL()[ci]) : static_cast<uint32_t>(SNONE);
+				bool const has = act && par != SNONE;
 				uint32_t tot; uint32_t const pre = wv_scan_flag(has,tot);
 				if ( has )
 				{
@@ -1205,7 +1217,7 @@ struct FastEngine
 		{
 			uint32_t const z = L.fnode()[c], par = L.parF()[c];
 			if ( z == 0xFFFF ) continue;
-			if ( par == FNOPAR ) seedN[z] = 1; else reachN[L.slast()[par]] = 1;
+			if ( par == SNONE ) seedN[z] = 1; else reachN[L.slast()[par]] = 1;
 		}
 		wv_sync();
 		while ( true )
@@ -1225,7 +1237,7 @@ struct FastEngine
 		{
 			uint32_t const z = L.lnode()[c], par = L.parL()[c];
 			if ( z == 0xFFFF ) continue;
-			if ( par == FNOPAR ) ok |= reachN[z];
+			if ( par == SNONE ) ok |= reachN[z];
 			else
 			{
 				ok |= vis[par];      // entered through its first node
@@ -1343,6 +1355,11 @@ struct FastEngine
 	// evaluated 64 at a time, a stretch after the other in each direction, so that the feasible ones can be appended to
 	// the weight lists with a ballot.  Same sums in the same order as computeStretchFeas, entries in ascending start
 	// position.  The loads of a node (link -> node -> first instance -> table) run ahead of the table reads.
+	DEV auto unitRecords() const
+	{
+		if constexpr ( GW ) return L.urec();
+		else { static_assert(2*CT::scap < 512,"unit ids are packed into 9 bits of a 16 bit record"); return reinterpret_cast<LDSQ uint16_t *>(L.ulo()); }
+	}
 	DEV void computeStretchFeasLanes(uint32_t const sfrom, uint32_t const sto)
 	{
 		PROFX_T0
@@ -1354,8 +1371,8 @@ struct FastEngine
 		// the units gives the same weights: a unit's entries stay consecutive and ascending in its own list, only the place
 		// of the list in the weight arrays changes.  Position q of the order holds (lo | unit << 7) in the bytes of ulo/uhi.
 		enum { NCHU = (2*CT::scap + WSZ - 1)/WSZ, NCLS = 12 };
-		static_assert(2*CT::scap < 512,"unit ids are packed into 9 bits");
-		LDSQ uint16_t * const urec = reinterpret_cast<LDSQ uint16_t *>(L.ulo());
+		// (legacy layout: 16 bit records over the bytes of ulo / uhi, at most 511 units; gw layout: 32 bit records)
+		auto const urec = unitRecords();
 		uint32_t ulo_r[NCHU], uw_r[NCHU], ucls_r[NCHU], upos_r[NCHU];
 		#pragma unroll
 		for ( uint32_t cc = 0; cc < NCHU; ++cc )
@@ -1401,7 +1418,7 @@ struct FastEngine
 		for ( uint32_t cc = 0; cc < NCHU; ++cc )
 		{
 			uint32_t const u = cc*WSZ + lane;
-			if ( u < nu ) { urec[upos_r[cc]] = static_cast<uint16_t>(ulo_r[cc] | (u << 7)); L.toff()[upos_r[cc]] = static_cast<uint16_t>(uw_r[cc]); }
+			if ( u < nu ) { urec[upos_r[cc]] = ulo_r[cc] | (u << 7); L.toff()[upos_r[cc]] = static_cast<uint16_t>(uw_r[cc]); }
 		}
 		wv_sync();
 		uint32_t tbase = 0;
@@ -1636,15 +1653,15 @@ struct FastEngine
 		uint64_t const m0 = 0ull - static_cast<uint64_t>(i == 0), m1 = 0ull - static_cast<uint64_t>(i == 1), m2 = 0ull - static_cast<uint64_t>(i == 2), m3 = 0ull - static_cast<uint64_t>(i == 3);
 		return (V.e0 & m0) | (V.e1 & m1) | (V.e2 & m2) | (V.e3 & m3);
 	}
-	DEV static uint32_t vAdd(uint64_t const e) { return static_cast<uint32_t>(e) & 0xFF; }
-	DEV static uint32_t vPos(uint64_t const e) { return static_cast<uint32_t>(e>>8) & 0xFF; }
-	DEV static uint32_t vFn(uint64_t const e) { return static_cast<uint32_t>(e>>16) & 0xFFFF; }
-	DEV static uint32_t vLn(uint64_t const e) { return static_cast<uint32_t>(e>>32) & 0xFFFF; }
+	DEV static uint32_t vAdd(uint64_t const e) { return static_cast<uint32_t>(e) & SMASK; }
+	DEV static uint32_t vPos(uint64_t const e) { return static_cast<uint32_t>(e>>SB) & SMASK; }
+	DEV static uint32_t vFn(uint64_t const e) { return static_cast<uint32_t>(e>>(2*SB)) & 0xFFFF; }
+	DEV static uint32_t vLn(uint64_t const e) { return static_cast<uint32_t>(e>>(2*SB+16)) & 0xFFFF; }
 	DEV void viewAdd(View & V, uint32_t const s) const
 	{
 		uint32_t const pos = L.ppos()[s];
 		uint64_t const key = poolKey(s);
-		uint64_t const ne = s | (static_cast<uint64_t>(pos)<<8) | (static_cast<uint64_t>(L.sfirst()[s])<<16) | (static_cast<uint64_t>(L.slast()[s])<<32);
+		uint64_t const ne = s | (static_cast<uint64_t>(pos)<<SB) | (static_cast<uint64_t>(L.sfirst()[s])<<(2*SB)) | (static_cast<uint64_t>(L.slast()[s])<<(2*SB+16));
 		// keep the insertions sorted by (position, key)
 		uint32_t i = V.nadd;
 		#define DACC_VSHIFT(Q,PE,DST) if ( i == Q ) { uint64_t const pe = PE; if ( vPos(pe) > pos || (vPos(pe) == pos && poolKey(vAdd(pe)) > key) ) { DST = pe; i = Q-1; } }
@@ -1679,8 +1696,8 @@ struct FastEngine
 		{
 			while ( it.a < V.nadd && vLn(viewE(V,it.a)) != it.target ) ++it.a;
 			uint32_t const e = it.i < n0 ? L.lord()[it.i] : 0xFFFFFFFFu;
-			bool const haveb = (e>>8) == it.target;
-			uint32_t const sx = e & 0xFF;
+			bool const haveb = (e>>SB) == it.target;
+			uint32_t const sx = e & SMASK;
 			if ( it.a < V.nadd && ( !haveb || vPos(viewE(V,it.a)) <= sx ) ) return vAdd(viewE(V,it.a++));
 			if ( !haveb ) return -1;
 			++it.i;
@@ -1833,7 +1850,7 @@ struct FastEngine
 			uint32_t const slot = clEnsure<RCH>(R.C,0,L.ctr()+0,CT::rccap/RCH);
 			if ( slot == ~0u ) { over(512|0x4000); return; }
 			R.nrp = 1;
-			L.rc_parent()[slot] = 0; L.rc_stretch()[slot] = 0xFF; L.rc_len()[slot] = 0; L.rc_pos()[slot] = 0; L.rc_w()[slot] = 0; L.rc_baselen()[slot] = k;
+			L.rc_parent()[slot] = 0; L.rc_stretch()[slot] = SNONE; L.rc_len()[slot] = 0; L.rc_pos()[slot] = 0; L.rc_w()[slot] = 0; L.rc_baselen()[slot] = k;
 			rpst[nrpst++] = slot;
 		}
 		LDSQ uint64_t const * W = L.rc_w();
@@ -2164,7 +2181,7 @@ struct FastEngine
 	// candidates spell the same string iff their sequences are equal (nodes are distinct k-mers and every edge lies on
 	// exactly one stretch of the view), so the duplicate test of traverse (:5098-5110) compares sequences; strings are
 	// decoded once, for the final candidates (decodePathPair :4267-4300).
-	DEV uint32_t buildSeq(uint32_t const path, uint32_t const rp, LDSQ uint8_t * dst, uint32_t & conslen)
+	DEV uint32_t buildSeq(uint32_t const path, uint32_t const rp, LDSQ sid_t * dst, uint32_t & conslen)
 	{
 		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[rp];
 		if ( nf + nr > FSEQCAP ) { over(4096); return ~0u; }
@@ -2181,7 +2198,7 @@ struct FastEngine
 		}
 		return nf+nr;
 	}
-	DEV uint32_t decodeSeq(LDSQ uint8_t const * seq, uint32_t const n, LDSQ uint8_t * dst) const
+	DEV uint32_t decodeSeq(LDSQ sid_t const * seq, uint32_t const n, LDSQ uint8_t * dst) const
 	{
 		uint32_t o = 0;
 		uint32_t const firstv = L.nv()[L.sfirst()[seq[0]]];
@@ -2232,31 +2249,38 @@ struct FastEngine
 	// one candidate offered to the candidate heap CDH (:5049-5092, including the shrink quirk); false: stop (error)
 	DEV bool offerCandidate(uint64_t const weight, uint32_t const path, uint32_t const rp, uint32_t & pn)
 	{
-		LDSQ uint8_t * cur = L.cseq() + 16*FSEQCAP; LDSQ uint8_t * prev = L.cseq() + 17*FSEQCAP;
+		LDSQ sid_t * cur = L.cseq() + 16*FSEQCAP; LDSQ sid_t * prev = L.cseq() + 17*FSEQCAP;
 		FSTAT_ADD(18,1);
 		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
 		uint32_t conslen = 0;
 		uint32_t const n = buildSeq(path,rp,cur,conslen);
 		if ( n == ~0u ) return false;
-		// sequences are compared and copied as six 64 bit words (the slots are 48 bytes, 8 byte aligned; bytes behind a
-		// sequence's length are never looked at): one round of loads instead of one per stretch
-		static_assert(FSEQCAP == 48 && (FastLds<CT>::o_cseq & 7) == 0,"candidate sequences are moved as six 64 bit words");
+		// sequences are compared and copied as 64 bit words (a slot is FSEQCAP ids, 8 byte aligned; ids behind a sequence's
+		// length are never looked at): one round of loads instead of one per stretch
+		enum : uint32_t { SW = FSEQCAP*sizeof(sid_t)/8u, IPW = 8u/sizeof(sid_t) };      // words per slot, ids per word
+		static_assert((FSEQCAP*sizeof(sid_t)) % 8 == 0 && (FastLds<CT>::o_cseq & 7) == 0,"candidate sequences are moved as 64 bit words");
 		LDSQ uint64_t const * cur8 = reinterpret_cast<LDSQ uint64_t const *>(cur);
 		LDSQ uint64_t * prev8 = reinterpret_cast<LDSQ uint64_t *>(prev);
-		uint64_t const c0 = cur8[0], c1 = cur8[1], c2 = cur8[2], c3 = cur8[3], c4 = cur8[4], c5 = cur8[5];
+		uint64_t cw[SW];
+		#pragma unroll
+		for ( uint32_t q = 0; q < SW; ++q ) cw[q] = cur8[q];
 		if ( n == pn )
 		{
-			uint64_t const p0 = prev8[0], p1 = prev8[1], p2 = prev8[2], p3 = prev8[3], p4 = prev8[4], p5 = prev8[5];
-			// bytes [0,n) equal <=> the xor of every word, cut to the bytes below n, is zero
-			#define DACC_SEQDIFF(q_,c_,p_) ( n > 8*(q_) ? ( ((c_)^(p_)) & ( n >= 8*(q_)+8 ? ~0ull : ((1ull << (8*(n-8*(q_))))-1) ) ) : 0ull )
-			uint64_t const diff = DACC_SEQDIFF(0,c0,p0) | DACC_SEQDIFF(1,c1,p1) | DACC_SEQDIFF(2,c2,p2) | DACC_SEQDIFF(3,c3,p3) | DACC_SEQDIFF(4,c4,p4) | DACC_SEQDIFF(5,c5,p5);
-			#undef DACC_SEQDIFF
+			// ids [0,n) equal <=> the xor of every word, cut to the ids below n, is zero
+			uint64_t diff = 0;
+			#pragma unroll
+			for ( uint32_t q = 0; q < SW; ++q )
+			{
+				uint64_t const pq = prev8[q];
+				uint64_t const m = n >= IPW*q+IPW ? ~0ull : ( n > IPW*q ? ((1ull << (8u*sizeof(sid_t)*(n-IPW*q)))-1ull) : 0ull );
+				diff |= (cw[q]^pq) & m;
+			}
 			if ( diff == 0 ) return true;
 		}
 		uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
 		LDSQ uint64_t * dst8 = reinterpret_cast<LDSQ uint64_t *>(L.cseq() + FSEQCAP*slot);
-		prev8[0] = c0; prev8[1] = c1; prev8[2] = c2; prev8[3] = c3; prev8[4] = c4; prev8[5] = c5;
-		dst8[0] = c0; dst8[1] = c1; dst8[2] = c2; dst8[3] = c3; dst8[4] = c4; dst8[5] = c5;
+		#pragma unroll
+		for ( uint32_t q = 0; q < SW; ++q ) { prev8[q] = cw[q]; dst8[q] = cw[q]; }
 		pn = n;
 		FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
 		FSTAT_ADD(19,1);
@@ -2551,24 +2575,24 @@ struct FastEngine
 	{
 		viewClear(V);
 		uint32_t const sl = L.parL()[li];
-		if ( sl != FNOPAR ) { viewRemove(V,sl); viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieL()[li]+1); }
+		if ( sl != SNONE ) { viewRemove(V,sl); viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieL()[li]+1); }
 	}
 	DEV void viewOfFirst(View & V, uint32_t const fi) const
 	{
 		viewClear(V);
 		uint32_t const sf = L.parF()[fi];
-		if ( sf != FNOPAR ) { viewRemove(V,sf); viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
+		if ( sf != SNONE ) { viewRemove(V,sf); viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
 	}
 	// are the cached enumerations of (fi, li) valid for the pair?  bit 0: reverse block, bit 1: forward tree, bit 2: both
 	// candidates split the same stretch
 	DEV uint32_t classifyPair(uint32_t const fi, uint32_t const li, int64_t const lmax) const
 	{
 		uint32_t const sf = L.parF()[fi], sl = L.parL()[li];
-		if ( sf != FNOPAR && sf == sl ) return 4;
+		if ( sf != SNONE && sf == sl ) return 4;
 		int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
 		int32_t const lastnode = L.lnode()[li] == 0xFFFF ? -1 : L.lnode()[li];
 		bool rcached, fcached;
-		if ( sf == FNOPAR ) rcached = true;
+		if ( sf == SNONE ) rcached = true;
 		else
 		{
 			uint64_t const tm = L.rtmask()[li];
@@ -2576,7 +2600,7 @@ struct FastEngine
 			rcached = !((tm >> (L.slast()[sf]&63))&1) && !((tm >> (fn&63))&1);
 			if ( !rcached ) rcached = reverseUnaffected(L.rbase()[li],L.rn()[li],lastnode,sf,fn,lmax);
 		}
-		if ( sl == FNOPAR ) fcached = true;
+		if ( sl == SNONE ) fcached = true;
 		else
 		{
 			uint64_t const tm = L.ftm()[fi];
@@ -2649,8 +2673,8 @@ struct FastEngine
 			}
 			else
 			{
-				if ( sf != FNOPAR ) { viewRemove(V,sf); viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
-				if ( sl != FNOPAR ) { viewRemove(V,sl); viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieL()[li]+1); }
+				if ( sf != SNONE ) { viewRemove(V,sf); viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
+				if ( sl != SNONE ) { viewRemove(V,sl); viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieL()[li]+1); }
 			}
 			uint32_t const rsave = L.ctr()[0], fsave = L.ctr()[1];
 			uint32_t sbase = L.rbase()[li], nacc2 = L.rn()[li]; uint64_t rfm = L.rfmask()[li];
@@ -2860,7 +2884,7 @@ struct FastEngine
 					// middle piece of a stretch split twice: appended to the pool (kept, candidates may refer to it)
 					FSTAT_ADD(25,1);
 					uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
-					if ( npool+1 > CT::scap || npool+1 > 250 ) { over(32); return false; }
+					if ( npool+1 > CT::scap || npool+1 > SMAX ) { over(32); return false; }
 					// gw layout: the node tables the feasibility of the new piece reads are spilled at this point (7 of 7976
 					// windows of config 2 need a middle piece): such a window goes to the next tier
 					if ( GW ) { over(32); return false; }
