@@ -42,14 +42,14 @@ __global__ void k_prep(PrepBatch B)
 	}
 }
 
-// one lane per tspace block, one wavefront per workgroup; the column checkpoints and the current segment of every lane
-// live in the workgroup's dynamic LDS (traceSlots(maxcols) slots of 34 bytes per lane)
+// one lane per tspace block, one wavefront per workgroup; the column checkpoints of every lane go to the workgroup's global
+// slab, the segment the traceback is in lives in the workgroup's dynamic LDS (TRACE2_LDS = 19.6 KB: 8 wavefronts per CU)
 __global__ void __launch_bounds__(64) k_trace(TraceBatch B)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_trace[];
-	uint32_t const slots = traceSlots(B.maxcols);
-	TraceStoreLds st;
-	st.w = (LDSQ uint64_t *)lds_trace; st.sc = (LDSQ uint16_t *)(lds_trace + static_cast<size_t>(slots)*4*64*8); st.lane = threadIdx.x;
+	TraceStoreGL st;
+	st.g = B.slab + static_cast<size_t>(blockIdx.x)*traceSlabWords(B.maxcols);
+	st.w = (LDSQ uint64_t *)lds_trace; st.sc = (LDSQ uint16_t *)(lds_trace + static_cast<size_t>(T2S+1)*4*64*8); st.lane = threadIdx.x;
 	for ( uint64_t task = static_cast<uint64_t>(blockIdx.x)*64 + threadIdx.x; task < B.nblocks; task += static_cast<uint64_t>(gridDim.x)*64 )
 		traceBlock(B,task,st);
 }
@@ -384,6 +384,23 @@ struct DevBuf
 	void release() { if ( p ) hipFree(p); p = 0; cap = 0; }
 };
 
+// pinned host buffer (the symbol stream of a batch comes back at PCIe speed instead of through a pageable staging copy)
+template<typename T>
+struct HostBuf
+{
+	T * p; size_t cap;
+	HostBuf() : p(0), cap(0) {}
+	hipError_t ensure(size_t n)
+	{
+		if ( n <= cap ) return hipSuccess;
+		if ( p ) { hipHostFree(p); p = 0; cap = 0; }
+		hipError_t const e = hipHostMalloc(reinterpret_cast<void **>(&p),n*sizeof(T),hipHostMallocDefault);
+		if ( e == hipSuccess ) cap = n;
+		return e;
+	}
+	void release() { if ( p ) hipHostFree(p); p = 0; cap = 0; }
+};
+
 }
 
 struct dacc_ctx
@@ -406,14 +423,14 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab;
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
-	int env_nofast, env_sched, env_tiers, env_dbgretry;     // debugging knobs, read once in dacc_create
+	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<int32_t> pile_status; std::vector<std::string> pile_errors; std::string pile_errors_joined;
-	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; std::vector<uint8_t> h_outsym;
+	std::vector<uint32_t> h_nfrag; std::vector<VoteFragment> h_frags; HostBuf<uint8_t> h_outsym;
 	dacc_timing timing;
 };
 
@@ -448,6 +465,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 7;      // bit t enables LDS tier t+1
+		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
 		char const * dr = getenv("DACC_DEBUG_RETRY"); c->env_dbgretry = (dr && dr[0] == '1');
 	}
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
@@ -468,7 +486,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release();
+	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
 	delete c;
@@ -553,7 +571,7 @@ static int runDevice(dacc_ctx * c)
 		TB.P = c->P; TB.bps = c->d_bps.p; TB.boff = c->d_boff.p; TB.rlen = c->d_rlen.p;
 		TB.piles = c->d_piles.p; TB.ovl = c->d_ovl.p; TB.ovl_pile = c->d_ovl_pile.p; TB.trace = c->d_trace.p;
 		TB.blk_ovl = c->d_blk_ovl.p; TB.blk_b0 = c->d_blk_b0.p; TB.nblocks = BP.nblocks; TB.wt_b = c->d_wt_b.p; TB.wt_e = c->d_wt_e.p;
-		TB.maxcols = BP.maxcols; TB.trace_bytes = c->trace_bytes; TB.errflag = c->d_err.p + 2;
+		TB.maxcols = BP.maxcols; TB.trace_bytes = c->trace_bytes; TB.errflag = c->d_err.p + 2; TB.slab = c->d_trslab.p;
 		if ( c->tr_words == 2 ) hipLaunchKernelGGL(k_trace,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB);
 		else if ( c->tr_words == 4 ) hipLaunchKernelGGL(k_trace_wide<4>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
 		else hipLaunchKernelGGL(k_trace_wide<8>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
@@ -651,7 +669,7 @@ static int runDevice(dacc_ctx * c)
 	HIPCHK(hipEventRecord(c->ev[2],s));
 	uint32_t herr[4] = {0,0,0,0};
 	size_t const symbytes = 2*BP.npos + 64*BP.piles.size() + 64;
-	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); c->h_outsym.resize(symbytes);
+	c->h_nfrag.resize(BP.piles.size()); c->h_frags.resize(BP.nfragslots+1); HIPCHK(c->h_outsym.ensure(symbytes));
 	auto voteAndFetch = [&]() -> int
 	{
 		HIPCHK(hipMemsetAsync(c->d_pilebad.p,0,BP.piles.size()+1,s));
@@ -671,7 +689,7 @@ static int runDevice(dacc_ctx * c)
 		{
 			HIPCHK(hipMemcpyAsync(c->h_nfrag.data(),c->d_nfrag.p,BP.piles.size()*sizeof(uint32_t),hipMemcpyDeviceToHost,s));
 			HIPCHK(hipMemcpyAsync(c->h_frags.data(),c->d_frags.p,BP.nfragslots*sizeof(VoteFragment),hipMemcpyDeviceToHost,s));
-			HIPCHK(hipMemcpyAsync(c->h_outsym.data(),c->d_outsym.p,symbytes,hipMemcpyDeviceToHost,s));
+			HIPCHK(hipMemcpyAsync(c->h_outsym.p,c->d_outsym.p,symbytes,hipMemcpyDeviceToHost,s));
 		}
 		HIPCHK(hipEventRecord(c->ev[4],s));
 		HIPCHK(hipStreamSynchronize(s));
@@ -727,7 +745,7 @@ static int runDevice(dacc_ctx * c)
 		{
 			VoteFragment const & F = c->h_frags[BP.fragbase[pi]+f];
 			dacc_fragment g; g.aread = BP.piles[pi].aread; g.first = F.first; g.last = F.last; g.len = F.len; g.seq_off = c->bases.size();
-			for ( uint32_t i = 0; i < F.len; ++i ) c->bases.push_back("ACGTDacgt"[c->h_outsym[F.off+i]]);
+			c->bases.append(reinterpret_cast<char const *>(c->h_outsym.p)+F.off,F.len);
 			c->frags.push_back(g);
 		}
 	float ms = 0;
@@ -773,7 +791,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		// one byte trace values); a batch with a longer block runs the four word kernel, which sizes its lanes to the LDS
 		c->tr_words = (c->par.tspace <= 128 && BP.maxcols <= 928) ? 2 : (c->par.tspace <= 256 ? 4 : 8);
 		c->tr_lanes = 64;
-		if ( c->tr_words == 2 ) c->tr_lds = traceSlots(BP.maxcols)*64u*34u;
+		if ( c->tr_words == 2 ) c->tr_lds = TRACE2_LDS;
 		else
 		{
 			// wide blocks: as many lanes per wavefront as have room for their column checkpoints
@@ -789,10 +807,13 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_wide<8>),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
 		}
 		uint64_t percu = (160*1024) / (c->tr_lds ? c->tr_lds : 1); if ( percu > 8 ) percu = 8; if ( percu < 1 ) percu = 1;
-		uint64_t g = (BP.nblocks+c->tr_lanes-1)/c->tr_lanes, gmax = 256*percu*4;
+		// two word kernel: exactly the resident workgroups (grid stride over the blocks), so that the checkpoint slabs
+		// (53 KB per workgroup at a B span of 160) stay in the L2 / Infinity Cache
+		uint64_t g = (BP.nblocks+c->tr_lanes-1)/c->tr_lanes, gmax = 256*percu*(c->tr_words == 2 ? 1 : 4);
 		if ( g > gmax ) g = gmax;
 		if ( g < 1 ) g = 1;
 		c->tr_grid = g;
+		if ( c->tr_words == 2 ) HIPCHK(c->d_trslab.ensure(static_cast<size_t>(g)*traceSlabWords(BP.maxcols)));
 	}
 	// window kernel geometry + arenas
 	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
@@ -809,6 +830,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	if ( c->usefast )
 	{
 		// LDS tiers: floor(160 KiB / ldsbytes) wavefronts per CU; a tier whose table overlay cannot hold the model table is skipped
+		if ( c->env_lds_t1 > BP.ftier[0].ldsbytes && c->env_lds_t1 <= 160*1024 ) BP.ftier[0].ldsbytes = c->env_lds_t1;
 		for ( int t = 0; t < 3; ++t )
 		{
 			FastCaps const & F = BP.ftier[t];

@@ -1278,8 +1278,28 @@ struct FastEngine
 		if ( GT ) return (pc < nrows && pos < nsup) ? static_cast<uint32_t>(vst[pos*nrows+pc]) : 0u;
 		else return tabR(pos*stride+pc);
 	}
-	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions; GT: read the table from HBM
-	// (middle pieces created while the LDS copy is overlaid by the enumeration pools) ----
+	// Element of a build-phase array (region S of the gw layout) while the enumeration pools lie over it: the part of S the
+	// pools cover is in the workgroup's global slab at that time (spillS), the rest is still in LDS.  `off` = byte offset of
+	// the element in the LDS layout.  Legacy layout: plain LDS read.
+	template<typename TT> DEV TT sGet(uint32_t const off) const
+	{
+		if constexpr ( GW )
+		{
+			typedef FastLds<CT> LL;
+			constexpr uint32_t plen = ((LL::upool - LL::sbase + 15u) & ~15u) < LL::sbytes ? ((LL::upool - LL::sbase + 15u) & ~15u) : LL::sbytes;
+			uint32_t const r = off - LL::sbase;
+			if ( r < plen ) return *reinterpret_cast<TT const *>(gslab + LL::g_spill + r);
+		}
+		return *reinterpret_cast<LDSQ TT const *>(L.base + off);
+	}
+	DEV uint32_t sRange(uint32_t const z) const { return sGet<uint32_t>(FastLds<CT>::o_nrange + 4u*z); }
+	DEV uint32_t sNps(uint32_t const z) const { return sGet<uint16_t>(FastLds<CT>::o_nps + 2u*z); }
+	DEV uint32_t sNfreq(uint32_t const z) const { return sGet<uint8_t>(FastLds<CT>::o_nfreq + z); }
+	DEV uint32_t sIpos(uint32_t const i) const { return sGet<uint8_t>(FastLds<CT>::o_ipos + i); }
+	DEV uint32_t sIrpos(uint32_t const i) const { return sGet<uint8_t>(FastLds<CT>::o_irpos + i); }
+	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions; GT: read the table from HBM.  Only
+	// used for the middle piece of a stretch that a pair splits twice, created while the enumeration pools are live: the
+	// LDS copy of the table (legacy layout) and the node tables (gw layout: region S, read through sGet) are overlaid ----
 	template<bool GT>
 	DEV void computeStretchFeas(uint32_t const sfrom, uint32_t const sto)
 	{
@@ -1299,21 +1319,21 @@ struct FastEngine
 				// two stretch nodes per round and direction: their index, node and first-instance loads are independent and
 				// issued together; a node has at least one instance, further instances (rare for large k) follow in a tail loop
 				#define DACC_NODE(Z,IP,P,U,RNG) \
-					uint32_t const RNG = L.nrange()[Z]; \
-					{ uint32_t const i0_ = L.nps()[Z], f_ = L.nfreq()[Z]; \
+					uint32_t const RNG = sRange(Z); \
+					{ uint32_t const i0_ = sNps(Z), f_ = sNfreq(Z); \
 					  uint32_t const pc_ = (P) < nrows ? (P) : nrows; \
-					  U = tabAt<GT>(IP[i0_],pc_,stride); \
-					  for ( uint32_t q_ = 1; q_ < f_; ++q_ ) U += tabAt<GT>(IP[i0_+q_],pc_,stride); }
+					  U = tabAt<GT>(IP(i0_),pc_,stride); \
+					  for ( uint32_t q_ = 1; q_ < f_; ++q_ ) U += tabAt<GT>(IP(i0_+q_),pc_,stride); }
 				uint32_t j = 0;
 				for ( ; j+1 < len; j += 2 )
 				{
 					uint32_t const p0 = Pp+j, p1 = p0+1;
 					uint32_t const zf0 = Lk[j], zf1 = Lk[j+1], zr0 = Lk[len-1-j], zr1 = Lk[len-2-j];
 					uint64_t uf0, uf1, ur0, ur1;
-					DACC_NODE(zf0,L.ipos(),p0,uf0,gf0)
-					DACC_NODE(zr0,L.irpos(),p0,ur0,gr0)
-					DACC_NODE(zf1,L.ipos(),p1,uf1,gf1)
-					DACC_NODE(zr1,L.irpos(),p1,ur1,gr1)
+					DACC_NODE(zf0,sIpos,p0,uf0,gf0)
+					DACC_NODE(zr0,sIrpos,p0,ur0,gr0)
+					DACC_NODE(zf1,sIpos,p1,uf1,gf1)
+					DACC_NODE(zr1,sIrpos,p1,ur1,gr1)
 					ok = ok & (p0 >= (gf0&0xFF)) & (p0 < ((gf0>>8)&0xFF)) & (uf0 >= FW_THRES_FEAS) & (p1 >= (gf1&0xFF)) & (p1 < ((gf1>>8)&0xFF)) & (uf1 >= FW_THRES_FEAS);
 					okr = okr & (p0 >= ((gr0>>16)&0xFF)) & (p0 < (gr0>>24)) & (ur0 >= FW_THRES_FEAS) & (p1 >= ((gr1>>16)&0xFF)) & (p1 < (gr1>>24)) & (ur1 >= FW_THRES_FEAS);
 					sum += uf0; sum += uf1; rsum += ur0; rsum += ur1;
@@ -1325,8 +1345,8 @@ struct FastEngine
 					uint32_t const p0 = Pp+j;
 					uint32_t const zf0 = Lk[j], zr0 = Lk[len-1-j];
 					uint64_t uf0, ur0;
-					DACC_NODE(zf0,L.ipos(),p0,uf0,gf0)
-					DACC_NODE(zr0,L.irpos(),p0,ur0,gr0)
+					DACC_NODE(zf0,sIpos,p0,uf0,gf0)
+					DACC_NODE(zr0,sIrpos,p0,ur0,gr0)
 					ok = ok & (p0 >= (gf0&0xFF)) & (p0 < ((gf0>>8)&0xFF)) & (uf0 >= FW_THRES_FEAS);
 					okr = okr & (p0 >= ((gr0>>16)&0xFF)) & (p0 < (gr0>>24)) & (ur0 >= FW_THRES_FEAS);
 					sum += uf0; rsum += ur0;
@@ -2885,9 +2905,9 @@ struct FastEngine
 					FSTAT_ADD(25,1);
 					uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
 					if ( npool+1 > CT::scap || npool+1 > SMAX ) { over(32); return false; }
-					// gw layout: the node tables the feasibility of the new piece reads are spilled at this point (7 of 7976
-					// windows of config 2 need a middle piece): such a window goes to the next tier
-					if ( GW ) { over(32); return false; }
+					// (gw layout: the node tables the feasibility of the new piece reads are spilled at this point; the rare
+					// computeStretchFeas reads them from the slab.  While every gw tier handed such a window on instead, 4412 of
+					// the 10^7 windows of config 2 ended in the generic engine and took longer there than all the others together.)
 					if ( lane == 0 ) { makePiece(npool,par,ma,mb); L.ppos()[npool] = basePos(npool); }
 					wv_sync();
 					computeStretchFeas<true>(npool,npool+1);

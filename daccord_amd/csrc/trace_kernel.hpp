@@ -36,6 +36,7 @@ struct TraceBatch
 	uint32_t maxcols;     // largest B span of a block in the batch
 	uint32_t trace_bytes; // 1 (tspace <= 125) or 2 bytes per trace value
 	uint32_t * errflag;
+	uint64_t * slab;      // two word kernel: checkpoint slabs, traceSlabWords(maxcols) 64 bit words per workgroup
 };
 
 // write P(x) into the window tables of overlap o where x is a window start / end
@@ -85,33 +86,58 @@ DEV void emitBoundary(TraceBatch const & B, DevPile const & pile, DevOvl const &
 struct TCol { uint64_t pv0, mv0, pv1, mv1; uint32_t score; };
 
 // Column stores.  The forward pass keeps only every TRS-th column (checkpoints); the traceback, which walks the columns
-// downwards, recomputes the TRS columns of a segment from its checkpoint when it enters the segment.  A thread therefore
-// needs ncp + TRS column slots instead of one per column, which fits LDS: nothing of the alignment matrix goes to HBM.
-enum { TRS = 16 };
-// device: slots of the 64 lanes of a wavefront interleaved, word q of slot e of lane l at (e*4+q)*64 + l (no bank conflicts
-// whatever slot a lane is at)
-struct TraceStoreLds
+// downwards, recomputes the TRS columns of a segment from its checkpoint when it enters the segment.
+//
+// Two word kernel (k_trace, tspace <= 128; round 3): the CHECKPOINTS of a lane go to a global scratch slab of its workgroup
+// (coalesced 512 byte rows, written once and read once per block; the slabs of all resident workgroups stay in the L2 /
+// Infinity Cache), only the segment being walked (its checkpoint + T2S recomputed columns) is in LDS: 19.6 KB per wavefront =
+// 8 wavefronts per CU.  With checkpoints AND segment in LDS (58.7 KB, rounds 1-2) two wavefronts shared a CU -- two of its
+// four SIMDs had no wavefront at all -- and the kernel, which is a chain of dependent 64 bit VALU operations per lane, ran
+// at 39 % VALU issue per resident wavefront.
+enum { TRS = 16 };      // wide kernels (k_trace_wide): checkpoints and segment in LDS
+enum { T2S = 8 };       // two word kernel: columns per segment
+// segment slots of the 64 lanes of a wavefront interleaved, word q of slot e of lane l at (e*4+q)*64 + l (no bank conflicts
+// whatever slot a lane is at); slot 0 = the segment's checkpoint column, slot u = column g*T2S+u
+struct TraceStoreGL
 {
+	enum : uint32_t { SEG = T2S };
+	uint64_t * g;                 // this workgroup's slab: word q (0-3 vectors, 4 score) of checkpoint e of lane l at (e*5+q)*64 + l
 	LDSQ uint64_t * w; LDSQ uint16_t * sc; uint32_t lane;
-	DEV void put(uint32_t const e, TCol const & c) const
+	DEV void putCp(uint32_t const e, TCol const & c) const
 	{
-		LDSQ uint64_t * p = w + (e*4)*64 + lane;
-		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1; sc[e*64+lane] = static_cast<uint16_t>(c.score);
+		uint64_t * p = g + (e*5)*64 + lane;
+		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1; p[256] = c.score;
 	}
-	DEV TCol get(uint32_t const e) const
+	DEV TCol getCp(uint32_t const e) const
 	{
-		LDSQ uint64_t const * p = w + (e*4)*64 + lane;
-		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; c.score = sc[e*64+lane]; return c;
+		uint64_t const * p = g + (e*5)*64 + lane;
+		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; c.score = static_cast<uint32_t>(p[256]); return c;
+	}
+	DEV void putSeg(uint32_t const u, TCol const & c) const
+	{
+		LDSQ uint64_t * p = w + (u*4)*64 + lane;
+		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1; sc[u*64+lane] = static_cast<uint16_t>(c.score);
+	}
+	DEV TCol getSeg(uint32_t const u) const
+	{
+		LDSQ uint64_t const * p = w + (u*4)*64 + lane;
+		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; c.score = sc[u*64+lane]; return c;
 	}
 };
-// host emulation: plain arrays of one thread
+// host emulation: plain arrays of one thread (cp: traceCheckpoints(maxcols) columns, seg: T2S+1 columns)
 struct TraceStoreMem
 {
-	uint64_t * w; uint16_t * sc;
-	void put(uint32_t const e, TCol const & c) const { w[e*4] = c.pv0; w[e*4+1] = c.mv0; w[e*4+2] = c.pv1; w[e*4+3] = c.mv1; sc[e] = static_cast<uint16_t>(c.score); }
-	TCol get(uint32_t const e) const { TCol c; c.pv0 = w[e*4]; c.mv0 = w[e*4+1]; c.pv1 = w[e*4+2]; c.mv1 = w[e*4+3]; c.score = sc[e]; return c; }
+	enum : uint32_t { SEG = T2S };
+	TCol * cp; TCol * seg;
+	void putCp(uint32_t const e, TCol const & c) const { cp[e] = c; }
+	TCol getCp(uint32_t const e) const { return cp[e]; }
+	void putSeg(uint32_t const u, TCol const & c) const { seg[u] = c; seg[u].score = static_cast<uint16_t>(c.score); }
+	TCol getSeg(uint32_t const u) const { return seg[u]; }
 };
-HDEV uint32_t traceSlots(uint32_t const maxcols) { return maxcols/TRS + 1 + TRS; }     // checkpoints 0,TRS,2*TRS,.. + one segment
+HDEV uint32_t traceSlots(uint32_t const maxcols) { return maxcols/TRS + 1 + TRS; }     // wide kernels: checkpoints 0,TRS,2*TRS,.. + one segment
+HDEV uint32_t traceCheckpoints(uint32_t const maxcols) { return maxcols/T2S + 1; }     // two word kernel: checkpoints per lane (global slab)
+HDEV uint32_t traceSlabWords(uint32_t const maxcols) { return traceCheckpoints(maxcols)*5u*64u; }      // 64 bit words per workgroup
+enum : uint32_t { TRACE2_LDS = (T2S+1)*64*34 };      // LDS bytes of a wavefront of k_trace
 
 // Myers / Hyyro column step: C = column c -> column c+1 for B symbol tc
 DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, uint64_t const mask0, uint64_t const mask1, bool const two, uint64_t const top)
@@ -140,7 +166,7 @@ DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, uint64_t co
 	}
 }
 
-// task = block id; ST = column store of this thread (traceSlots(B.maxcols) slots)
+// task = block id; ST = column store of this thread (traceCheckpoints(B.maxcols) checkpoints, ST::SEG+1 segment columns)
 template<typename ST>
 DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 {
@@ -172,9 +198,9 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 	uint64_t const mask1 = (m <= 64) ? 0ull : ((m == 128) ? ~0ull : ((1ull<<(m-64))-1));
 	bool const two = m > 64;
 	uint64_t const top = two ? (1ull<<(m-65)) : (1ull<<(m-1));
-	uint32_t const ncp = B.maxcols/TRS + 1;     // slots [0,ncp): checkpoints, [ncp,ncp+TRS): columns g*TRS+1 .. g*TRS+TRS of the loaded segment
+	constexpr uint32_t TRS = ST::SEG;      // columns per segment (shadows the wide kernels' constant)
 	TCol C; C.pv0 = mask0; C.mv0 = 0; C.pv1 = mask1; C.mv1 = 0; C.score = m;
-	st.put(0,C);
+	st.putCp(0,C);
 	// B symbols are fetched TRS at a time (independent loads, one wait) and kept packed 2 bits each
 	#define DACC_LOADB(c0_,cnt_,dst_) { dst_ = 0; _Pragma("unroll") for ( uint32_t u = 0; u < TRS; ++u ) if ( u < (cnt_) ) dst_ |= static_cast<uint32_t>(readBase(B.bps,boffs,brl,inv,b0+(c0_)+u)) << (2*u); }
 	for ( uint32_t c0 = 0; c0 < n; c0 += TRS )
@@ -182,7 +208,7 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 		uint32_t const cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
 		uint32_t bb; DACC_LOADB(c0,cnt,bb)
 		for ( uint32_t u = 0; u < cnt; ++u ) traceStep(peq,(bb>>(2*u))&3,C,mask0,mask1,two,top);
-		if ( cnt == TRS ) st.put(c0/TRS+1,C);
+		if ( cnt == TRS ) st.putCp(c0/TRS+1,C);
 	}
 	// window boundaries are rare among the A positions: x is a window start iff x % a == 0 or x == l-w, a window end iff
 	// (x-w) % a == 0 or x == l; x % a is tracked incrementally (no division per step)
@@ -199,13 +225,14 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 		if ( !(i && j && (j-1)/TRS == static_cast<uint32_t>(g)) ) continue;
 		uint32_t bseg;
 		{
-			TCol R = st.get(g);
+			TCol R = st.getCp(g);
+			st.putSeg(0,R);
 			uint32_t const c0 = g*TRS, cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
 			DACC_LOADB(c0,cnt,bseg)
 			for ( uint32_t u = 0; u < cnt; ++u )
 			{
 				traceStep(peq,(bseg>>(2*u))&3,R,mask0,mask1,two,top);
-				st.put(ncp + u,R);
+				st.putSeg(u+1,R);
 			}
 		}
 		while ( i && j && (j-1)/TRS == static_cast<uint32_t>(g) )
@@ -213,7 +240,7 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 			bool done = false;
 			{
 				// D[i-1][j-1] = bottom(j-1) - sum of vertical deltas of rows i..m in column j-1
-				TCol const q = ((j-1) % TRS) ? st.get(ncp + (j-2) % TRS) : st.get((j-1)/TRS);
+				TCol const q = st.getSeg((j-1) - g*TRS);      // column j-1: slot 0 is the segment's checkpoint
 				uint32_t const sh = i-1;
 				int32_t sum;
 				if ( sh < 64 ) sum = dacc_popc64(q.pv0>>sh) + dacc_popc64(q.pv1) - dacc_popc64(q.mv0>>sh) - dacc_popc64(q.mv1);
@@ -232,8 +259,7 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 			{
 				uint32_t const r = i-1;
 				uint64_t cp0, cp1;
-				if ( j % TRS ) { TCol const cj = st.get(ncp + (j-1) % TRS); cp0 = cj.pv0; cp1 = cj.pv1; }
-				else { TCol const cj = st.get(j/TRS); cp0 = cj.pv0; cp1 = cj.pv1; }
+				{ TCol const cj = st.getSeg(j - g*TRS); cp0 = cj.pv0; cp1 = cj.pv1; }      // column j (j-1 lies in segment g, so j <= g*TRS+TRS)
 				bool const plus = (r < 64) ? ((cp0>>r)&1) : ((cp1>>(r-64))&1);
 				if ( plus )
 				{

@@ -36,6 +36,13 @@ struct VoteBatch
 	uint8_t const * pilebad;  // per pile: dropped (a window could not be processed), 0 = no such list
 };
 
+// output letter of a vote winner: 0-3 = ACGT, 4 = D, 5-8 = acgt (lower case: producefull fill).  The symbol stream is
+// ASCII on the device so that the host copies fragments instead of translating 10^8 symbols per batch.
+DEV uint8_t voteSym(uint32_t const best)
+{
+	return static_cast<uint8_t>(best < 4 ? ((0x54474341u >> (8*best)) & 0xFFu) : (best == 4 ? 0x44u : ((0x74676361u >> (8*(best-5))) & 0xFFu)));
+}
+
 DEV uint32_t pileNpos(DevPile const & pile) { return (pile.l > pile.rl ? pile.l : pile.rl) + 1; }
 
 // ASCII code used as the vote tie-break (std::greater<pair<count,char>>, HandleContext.hpp:2695)
@@ -170,7 +177,7 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 		}
 		if ( depth > static_cast<int32_t>(ld) ) C.c4 += depth-ld;
 		uint32_t best;
-		if ( colWinner(C,best) ) { if ( out ) out[no] = best; ++no; }
+		if ( colWinner(C,best) ) { if ( out ) out[no] = voteSym(best); ++no; }
 	}
 	// apre == 0 column
 	uint32_t const l0 = B.ld0[pile.posbase+p];
@@ -191,7 +198,7 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 			colAdd(C,5+b,1);
 		}
 		uint32_t best;
-		if ( colWinner(C,best) ) { if ( out ) out[no] = best; ++no; }
+		if ( colWinner(C,best) ) { if ( out ) out[no] = voteSym(best); ++no; }
 	}
 	return no;
 }

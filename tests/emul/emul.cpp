@@ -112,7 +112,8 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		TB.blk_ovl = blk_ovl.data(); TB.blk_b0 = blk_b0.data(); TB.nblocks = BP.nblocks;
 		TB.wt_b = wt_b.data(); TB.wt_e = wt_e.data();
 		std::vector<uint64_t> colw(traceSlots(BP.maxcols)*4); std::vector<uint16_t> colsc(traceSlots(BP.maxcols));
-		TraceStoreMem st; st.w = colw.data(); st.sc = colsc.data();
+		std::vector<TCol> cps(traceCheckpoints(BP.maxcols)), segs(T2S+1);
+		TraceStoreMem st; st.cp = cps.data(); st.seg = segs.data();
 		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag;
 		if ( P.tspace <= 128 && BP.maxcols <= 928 ) for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);   // as the library chooses (capi.hip: tr_words)
 		else
@@ -327,7 +328,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		{
 			VoteFragment const & F = vf[BP.fragbase[pi]+f];
 			dacc_fragment g; g.aread = pile.aread; g.first = F.first; g.last = F.last; g.len = F.len; g.seq_off = c->bases.size();
-			for ( uint32_t i = 0; i < F.len; ++i ) c->bases.push_back("ACGTDacgt"[outsym[F.off+i]]);
+			for ( uint32_t i = 0; i < F.len; ++i ) c->bases.push_back(static_cast<char>(outsym[F.off+i]));
 			c->frags.push_back(g);
 		}
 	}
