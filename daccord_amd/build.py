@@ -14,12 +14,13 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 
 def csrc_hash():
-    """SHA-256 (16 hex digits) over the kernel and host sources: recorded with PMC summaries (scripts/pmc_summarize.py) so
-    that bench.py quotes counters only when they were collected on the very code it is running."""
+    """SHA-256 (16 hex digits) over the DEVICE sources (capi.hip and the kernel headers): recorded with PMC summaries
+    (scripts/pmc_summarize.py) so that bench.py quotes counters only when they were collected on the very kernels it is
+    running.  Host-only sources (host_*.cpp, the front end) do not change what the counters measure and are left out."""
     import hashlib
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
+        if f.endswith((".hip", ".hpp")):
             h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
 

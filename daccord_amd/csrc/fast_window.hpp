@@ -98,7 +98,7 @@ template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint8_t sid_t; en
 // gw layout and 16 bit STRETCH ids since round 3: what the legacy tier 3 handed to the generic engine at 54x were windows with
 // more than 250 stretches (13 of 19 per 60 000 windows) or more than 2112 feasible weights (5 of 19), and each of them cost the
 // generic engine seconds (685 such windows were 92 % of a 2000-pile 54x batch, profiles/r03c_bench_54x_2000piles.log)
-template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128 }; };
 #endif
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
@@ -164,7 +164,10 @@ struct FastLds<CT,false>
 	FLD(vln,uint16_t,8,e_vfn)
 	FLD(sstack,uint16_t,3*24,e_vln)
 	FLD(chain,uint8_t,64,e_sstack)
-	static constexpr uint32_t ubase = e_chain;
+	FLD(midpar,uint16_t,8,e_chain)          // middle pieces of twice-split stretches: parent stretch, node range [midA,midB]
+	FLD(midA,uint8_t,8,e_midpar)
+	FLD(midB,uint8_t,8,e_midA)
+	static constexpr uint32_t ubase = e_midB;
 	// ---- overlay A: build phase ----
 	FLD(pre,uint64_t,CT::precap,ubase)
 	FLD(lastk,uint64_t,keycap,e_pre)
@@ -346,7 +349,10 @@ struct FastLds<CT,true>
 	FLD(vln,uint16_t,8,e_vfn)
 	FLD(sstack,uint16_t,3*24,e_vln)
 	FLD(chain,uint8_t,64,e_sstack)
-	FLD(nv,uint32_t,CT::ncap,e_chain)
+	FLD(midpar,uint16_t,8,e_chain)          // middle pieces of twice-split stretches: parent stretch, node range [midA,midB]
+	FLD(midA,uint8_t,8,e_midpar)
+	FLD(midB,uint8_t,8,e_midA)
+	FLD(nv,uint32_t,CT::ncap,e_midB)
 	FLD(npred,sid_t,CT::ncap,e_nv)
 	FLD(bestL,uint8_t,MAXCONS,e_npred)
 	static constexpr uint32_t sbase = (e_bestL + 15u) & ~15u;
@@ -401,10 +407,11 @@ struct FastLds<CT,true>
 	FLD(ctr,uint32_t,4,e_poutn)
 	FLD(rchx,uint8_t,32,e_ctr)
 	static constexpr uint32_t upool = e_rchx;
-	static_assert(upool <= send,"the enumeration pools must fit the build-phase arrays they overlay");
+	// (pools larger than the build-phase arrays run on into a gap in front of the overlays: tier 3, whose reverse pool is sized
+	// for the 72 last k-mer candidates of a 54x pile -- 256 chunks of 8 paths, the most an 8 bit chunk id can name)
 	FLD(rchb,uint8_t,(CT::fnc < 64 ? CT::fnc : 64u)*32,o_fchb)
 	static_assert(e_rchb <= o_pout,"reverse chunk lists must fit the per first k-mer tables");
-	static constexpr uint32_t ubase = send;
+	static constexpr uint32_t ubase = fcmax(send,(upool + 15u) & ~15u);
 	// ---- overlay A: build phase ----
 	FLD(pre,uint64_t,CT::precap,ubase)
 	FLD(lastk,uint64_t,keycap,e_pre)
@@ -1190,6 +1197,51 @@ struct FastEngine
 			npool = id;
 		}
 		wv_sync();
+		// Middle pieces.  A first and a last k-mer candidate that lie strictly inside the SAME stretch at different nodes make a
+		// pair whose stretch set holds three parts of that stretch (split at first, then at last: splitStretches :2772-2841 applied
+		// twice); the part between the two nodes belongs to no candidate alone.  Every such pair is replayed on its exact stretch
+		// set (classifyPair: 4), so the middle pieces a traversal will need are known here: they join the pool now and get their
+		// feasibility with all other stretches, while the node tables are still in LDS.  (Until round 3 they were appended when
+		// their pair came up, with a feasibility pass of their own that read the model table from HBM -- which the gw layout
+		// cannot do, its node tables are spilled then, and whose registers cost the gw tiers their second wavefront per SIMD.)
+		nmid = 0; midbase = npool;
+		{
+			uint64_t pm = 0;
+			for ( uint32_t c = lane; c < nF; c += WSZ ) { uint32_t const par = L.parF()[c]; if ( par != SNONE ) pm |= 1ull << (par & 63u); }
+			pm = wv_or64(pm);
+			uint32_t hit = 0;
+			for ( uint32_t c = lane; c < nL; c += WSZ ) { uint32_t const par = L.parL()[c]; if ( par != SNONE && ((pm >> (par & 63u)) & 1ull) ) hit = 1; }
+			if ( wv_any(hit) )
+			{
+				uint32_t nm = 0;
+				if ( lane == 0 )
+				{
+					for ( uint32_t f = 0; f < nF && nm <= MIDCAP; ++f )
+					{
+						uint32_t const pf = L.parF()[f];
+						if ( pf == SNONE ) continue;
+						for ( uint32_t l = 0; l < nL && nm <= MIDCAP; ++l )
+						{
+							if ( L.parL()[l] != pf ) continue;
+							uint32_t const a = L.posF()[f], b = L.posL()[l];
+							if ( a == b ) continue;
+							uint32_t const lo = a < b ? a : b, hi = a < b ? b : a;
+							uint32_t m = 0;
+							while ( m < nm && !(L.midpar()[m] == pf && L.midA()[m] == lo && L.midB()[m] == hi) ) ++m;
+							if ( m < nm ) continue;
+							if ( nm < MIDCAP ) { L.midpar()[nm] = pf; L.midA()[nm] = lo; L.midB()[nm] = hi; }
+							++nm;      // MIDCAP+1: more middle pieces than the list holds
+						}
+					}
+				}
+				wv_sync();
+				nm = wv_bcast(nm,0);
+				if ( nm > MIDCAP || npool + nm > CT::scap || npool + nm > SMAX ) { over(32); return; }
+				if ( static_cast<uint32_t>(lane) < nm ) makePiece(npool+lane,L.midpar()[lane],L.midA()[lane],L.midB()[lane]);
+				nmid = nm; npool += nm;
+				wv_sync();
+			}
+		}
 		for ( uint32_t id = n0 + lane; id < npool; id += WSZ ) L.ppos()[id] = basePos(id);
 		wv_sync();
 
@@ -1273,101 +1325,6 @@ struct FastEngine
 		if constexpr ( GW ) return gtab[idx];
 		else return L.tab()[idx];
 	}
-	template<bool GT> DEV uint32_t tabAt(uint32_t const pos, uint32_t const pc, uint32_t const stride) const
-	{
-		if ( GT ) return (pc < nrows && pos < nsup) ? static_cast<uint32_t>(vst[pos*nrows+pc]) : 0u;
-		else return tabR(pos*stride+pc);
-	}
-	// Element of a build-phase array (region S of the gw layout) while the enumeration pools lie over it: the part of S the
-	// pools cover is in the workgroup's global slab at that time (spillS), the rest is still in LDS.  `off` = byte offset of
-	// the element in the LDS layout.  Legacy layout: plain LDS read.
-	template<typename TT> DEV TT sGet(uint32_t const off) const
-	{
-		if constexpr ( GW )
-		{
-			typedef FastLds<CT> LL;
-			constexpr uint32_t plen = ((LL::upool - LL::sbase + 15u) & ~15u) < LL::sbytes ? ((LL::upool - LL::sbase + 15u) & ~15u) : LL::sbytes;
-			uint32_t const r = off - LL::sbase;
-			if ( r < plen ) return *reinterpret_cast<TT const *>(gslab + LL::g_spill + r);
-		}
-		return *reinterpret_cast<LDSQ TT const *>(L.base + off);
-	}
-	DEV uint32_t sRange(uint32_t const z) const { return sGet<uint32_t>(FastLds<CT>::o_nrange + 4u*z); }
-	DEV uint32_t sNps(uint32_t const z) const { return sGet<uint16_t>(FastLds<CT>::o_nps + 2u*z); }
-	DEV uint32_t sNfreq(uint32_t const z) const { return sGet<uint8_t>(FastLds<CT>::o_nfreq + z); }
-	DEV uint32_t sIpos(uint32_t const i) const { return sGet<uint8_t>(FastLds<CT>::o_ipos + i); }
-	DEV uint32_t sIrpos(uint32_t const i) const { return sGet<uint8_t>(FastLds<CT>::o_irpos + i); }
-	// ---- stretch feasibility for pool ids [sfrom,sto), lanes = candidate positions; GT: read the table from HBM.  Only
-	// used for the middle piece of a stretch that a pair splits twice, created while the enumeration pools are live: the
-	// LDS copy of the table (legacy layout) and the node tables (gw layout: region S, read through sGet) are overlaid ----
-	template<bool GT>
-	DEV void computeStretchFeas(uint32_t const sfrom, uint32_t const sto)
-	{
-		uint32_t const stride = nrows+1;
-		uint64_t const ltmask = wv_lanemask_lt();
-		for ( uint32_t s = sfrom; s < sto; ++s )
-		{
-			uint32_t const len = L.sslen()[s];
-			LDSQ uint16_t const * Lk = L.links() + L.slink()[s];
-			uint64_t mF = 0, mR = 0;
-			uint32_t bF = nwF, bR = nwR;
-			for ( uint32_t c = 0; c < nrows; c += WSZ )
-			{
-				uint32_t const Pp = c + lane;
-				bool ok = Pp < nrows, okr = ok;
-				uint64_t sum = 0, rsum = 0, f1 = 0, fl = 0, r1 = 0;
-				// two stretch nodes per round and direction: their index, node and first-instance loads are independent and
-				// issued together; a node has at least one instance, further instances (rare for large k) follow in a tail loop
-				#define DACC_NODE(Z,IP,P,U,RNG) \
-					uint32_t const RNG = sRange(Z); \
-					{ uint32_t const i0_ = sNps(Z), f_ = sNfreq(Z); \
-					  uint32_t const pc_ = (P) < nrows ? (P) : nrows; \
-					  U = tabAt<GT>(IP(i0_),pc_,stride); \
-					  for ( uint32_t q_ = 1; q_ < f_; ++q_ ) U += tabAt<GT>(IP(i0_+q_),pc_,stride); }
-				uint32_t j = 0;
-				for ( ; j+1 < len; j += 2 )
-				{
-					uint32_t const p0 = Pp+j, p1 = p0+1;
-					uint32_t const zf0 = Lk[j], zf1 = Lk[j+1], zr0 = Lk[len-1-j], zr1 = Lk[len-2-j];
-					uint64_t uf0, uf1, ur0, ur1;
-					DACC_NODE(zf0,sIpos,p0,uf0,gf0)
-					DACC_NODE(zr0,sIrpos,p0,ur0,gr0)
-					DACC_NODE(zf1,sIpos,p1,uf1,gf1)
-					DACC_NODE(zr1,sIrpos,p1,ur1,gr1)
-					ok = ok & (p0 >= (gf0&0xFF)) & (p0 < ((gf0>>8)&0xFF)) & (uf0 >= FW_THRES_FEAS) & (p1 >= (gf1&0xFF)) & (p1 < ((gf1>>8)&0xFF)) & (uf1 >= FW_THRES_FEAS);
-					okr = okr & (p0 >= ((gr0>>16)&0xFF)) & (p0 < (gr0>>24)) & (ur0 >= FW_THRES_FEAS) & (p1 >= ((gr1>>16)&0xFF)) & (p1 < (gr1>>24)) & (ur1 >= FW_THRES_FEAS);
-					sum += uf0; sum += uf1; rsum += ur0; rsum += ur1;
-					if ( j == 0 ) { f1 = uf0; r1 = ur0; }
-					fl = uf1;
-				}
-				if ( j < len )
-				{
-					uint32_t const p0 = Pp+j;
-					uint32_t const zf0 = Lk[j], zr0 = Lk[len-1-j];
-					uint64_t uf0, ur0;
-					DACC_NODE(zf0,sIpos,p0,uf0,gf0)
-					DACC_NODE(zr0,sIrpos,p0,ur0,gr0)
-					ok = ok & (p0 >= (gf0&0xFF)) & (p0 < ((gf0>>8)&0xFF)) & (uf0 >= FW_THRES_FEAS);
-					okr = okr & (p0 >= ((gr0>>16)&0xFF)) & (p0 < (gr0>>24)) & (ur0 >= FW_THRES_FEAS);
-					sum += uf0; rsum += ur0;
-					if ( j == 0 ) { f1 = uf0; r1 = ur0; }
-					fl = uf0;
-				}
-				#undef DACC_NODE
-				uint64_t const bf = wv_ballot(ok), br = wv_ballot(okr);
-				uint32_t const pre = dacc_popc64(bf & ltmask), prer = dacc_popc64(br & ltmask);
-				if ( ok && bF+pre < CT::wcap ) putF(bF+pre,sum,f1,fl);
-				if ( okr && bR+prer < CT::wcap ) putR(bR+prer,rsum,r1);
-				mF |= bf << c; mR |= br << c;
-				bF += dacc_popc64(bf); bR += dacc_popc64(br);
-			}
-			if ( bF > CT::wcap || bR > CT::wcap ) { over(128); return; }
-			if ( lane == 0 ) { L.maskF()[s] = mF; L.maskR()[s] = mR; L.woffF()[s] = nwF; L.woffR()[s] = nwR; }
-			nwF = bF; nwR = bR;
-		}
-		wv_sync();
-	}
-
 	// ---- stretch feasibility, one LANE per (stretch, direction, start position) ----
 	// The wavefront-per-stretch form above walks the stretches one after the other with lanes = start positions and leaves
 	// most lanes idle (few positions survive the node supports).  Here one lane per (stretch, direction) first intersects
@@ -2586,7 +2543,8 @@ struct FastEngine
 	// order.  A pair whose cached enumerations may be touched by the other k-mer's split (rare) is enumerated on its
 	// exact stretch set by lane 0 at its place in that order.
 	enum { NPL = 32, RPSTL = 32, PM_SKIP = 0xF0, PM_SERIAL = 0xF1, PM_EXACT = 0xE0 };
-	uint32_t pl_midA, pl_midB, pl_midpar; bool pl_midready;
+	enum : uint32_t { MIDCAP = 8 };
+	uint32_t nmid, midbase;              // middle pieces of this activation state: pool ids midbase .. midbase+nmid-1
 	uint32_t rstop;                      // sorted reverse entries used by the cached blocks
 	uint64_t roundT0;                    // lightest weight of the (full) candidate heap when the current round of pairs began
 	uint32_t nsiq, ncdh, nacc;
@@ -2630,7 +2588,7 @@ struct FastEngine
 		return (rcached ? 1u : 0u) | (fcached ? 2u : 0u);
 	}
 	// lane 0: pairs [q, n) of the round starting at pair p0 of the batch that starts at candidate fstart, in order.
-	// returns 0 when the round is done, 1 when pair q needs the middle piece [pl_midA,pl_midB] of stretch pl_midpar,
+	// returns 0 when the round is done,
 	// 2 when the forward tree of the exact pair q found no pool space next to the trees of the batch (alone: the batch
 	// holds the tree of this first k-mer only)
 	// live: bit q set for the pairs of the round that are not PM_SKIP (most pairs share no junction k-mer and are skipped:
@@ -2681,14 +2639,12 @@ struct FastEngine
 				if ( pf == pl ) { viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieF()[fi]+1); }
 				else
 				{
-					if ( !pl_midready )
-					{
-						pl_midpar = sf; pl_midA = pf < pl ? pf : pl; pl_midB = pf < pl ? pl : pf;
-						return 1;
-					}
-					pl_midready = false;
+					// the middle piece of this pair is in the pool (findCandidatesAndPieces)
+					uint32_t const lo = pf < pl ? pf : pl, hi = pf < pl ? pl : pf;
+					uint32_t m = 0;
+					while ( m+1 < nmid && !(L.midpar()[m] == sf && L.midA()[m] == lo && L.midB()[m] == hi) ) ++m;
 					if ( pf < pl ) { viewAdd(V,L.pieF()[fi]); viewAdd(V,L.pieL()[li]+1); } else { viewAdd(V,L.pieL()[li]); viewAdd(V,L.pieF()[fi]+1); }
-					viewAdd(V,npool-1);   // the middle piece just appended to the pool
+					viewAdd(V,midbase+m);
 				}
 			}
 			else
@@ -2804,7 +2760,6 @@ struct FastEngine
 		PROF(*this,11)
 
 		// ---- batches of forward trees (lane = first k-mer candidate) and their pairs ----
-		pl_midready = false;
 		uint32_t fstart = 0, bw = WSZ, pskip = 0;
 		while ( fstart < nF )
 		{
@@ -2901,19 +2856,7 @@ struct FastEngine
 						if ( lane == 0 ) pcount(28,1);
 						break;
 					}
-					// middle piece of a stretch split twice: appended to the pool (kept, candidates may refer to it)
-					FSTAT_ADD(25,1);
-					uint32_t const par = wv_bcast(pl_midpar,0), ma = wv_bcast(pl_midA,0), mb = wv_bcast(pl_midB,0);
-					if ( npool+1 > CT::scap || npool+1 > SMAX ) { over(32); return false; }
-					// (gw layout: the node tables the feasibility of the new piece reads are spilled at this point; the rare
-					// computeStretchFeas reads them from the slab.  While every gw tier handed such a window on instead, 4412 of
-					// the 10^7 windows of config 2 ended in the generic engine and took longer there than all the others together.)
-					if ( lane == 0 ) { makePiece(npool,par,ma,mb); L.ppos()[npool] = basePos(npool); }
-					wv_sync();
-					computeStretchFeas<true>(npool,npool+1);
-					flags = wv_or(flags); if ( flags ) return false;
-					++npool;
-					if ( lane == 0 ) pl_midready = true;
+					break;      // (req is 0 or 2: the middle pieces of twice-split stretches are in the pool before the pairs start)
 				}
 				PROF(*this,7)
 			}
@@ -3196,7 +3139,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 #endif
 	if ( B.pregen && ((B.pregen[widx>>5] >> (widx&31)) & 1) ) return FW_DONE;      // the generic engine has this window (a string longer than 64 bases)
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
-	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pl_midA = E.pl_midB = E.pl_midpar = 0; E.pl_midready = false;
+	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.nmid = 0; E.midbase = 0;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.gslab = 0; E.gtab = FB.tab32; E.sfresh = true; E.sdirty = false;
 	if ( CT::gw )

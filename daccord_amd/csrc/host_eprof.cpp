@@ -48,12 +48,85 @@ struct Store
 	}
 };
 
-// global alignment of a[0,m) and b[0,n); operations appended to ops in forward order; returns the distance
+// global alignment of a[0,m) and b[0,n); operations appended to ops in forward order; returns the distance.
+// Up to 128 first-string symbols (every trace block at tspace <= 128 and every 40 base window) the matrix is computed bit
+// parallel (Myers / Hyyro, columns = second string, two 64 bit words of vertical deltas per column, all columns kept) and the
+// traceback reads D[i-1][j-1] and the vertical delta at (i,j) out of the column words -- the same recurrence, the same
+// traceback rule and therefore the same operations as the cell-by-cell form below, which remains for longer first strings
+// (the estimator spent 22 s of 8 host threads on 1024 piles in the cell-by-cell form, almost all of it here).
 struct Dp
 {
 	std::vector<uint16_t> D; std::vector<uint8_t> rev;
+	std::vector<uint64_t> col; std::vector<int32_t> sc;
+	uint32_t runBits(uint8_t const * a, uint32_t const m, uint8_t const * b, uint32_t const n, std::vector<uint8_t> * ops, uint64_t * cnt)
+	{
+		uint64_t peq[4][2] = {{0,0},{0,0},{0,0},{0,0}};
+		for ( uint32_t i = 0; i < m; ++i ) peq[a[i]&3][i>>6] |= 1ull<<(i&63);
+		uint64_t const mask0 = (m >= 64) ? ~0ull : ((1ull<<m)-1);
+		uint64_t const mask1 = (m <= 64) ? 0ull : ((m == 128) ? ~0ull : ((1ull<<(m-64))-1));
+		bool const two = m > 64;
+		uint64_t const top = two ? (1ull<<(m-65)) : (1ull<<(m-1));
+		col.resize(static_cast<size_t>(n+1)*4); sc.resize(n+1);
+		uint64_t pv0 = mask0, mv0 = 0, pv1 = mask1, mv1 = 0; int32_t score = m;
+		col[0] = pv0; col[1] = mv0; col[2] = pv1; col[3] = mv1; sc[0] = score;
+		for ( uint32_t j = 1; j <= n; ++j )
+		{
+			uint32_t const c = b[j-1]&3;
+			uint64_t const Eq0 = peq[c][0], Eq1 = peq[c][1];
+			uint64_t const Xv0 = Eq0 | mv0;
+			uint64_t const Xh0 = (((Eq0 & pv0) + pv0) ^ pv0) | Eq0;
+			uint64_t Ph0 = mv0 | ~(Xh0 | pv0);
+			uint64_t Mh0 = pv0 & Xh0;
+			uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
+			if ( !two ) { if ( Ph0 & top ) ++score; else if ( Mh0 & top ) --score; }
+			Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
+			pv0 = (Mh0 | ~(Xv0 | Ph0)) & mask0; mv0 = (Ph0 & Xv0) & mask0;
+			if ( two )
+			{
+				uint64_t const Eq1c = Eq1 | mhc;
+				uint64_t const Xv1 = Eq1 | mv1;
+				uint64_t const Xh1 = (((Eq1c & pv1) + pv1) ^ pv1) | Eq1c;
+				uint64_t Ph1 = mv1 | ~(Xh1 | pv1);
+				uint64_t Mh1 = pv1 & Xh1;
+				if ( Ph1 & top ) ++score; else if ( Mh1 & top ) --score;
+				Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
+				pv1 = (Mh1 | ~(Xv1 | Ph1)) & mask1; mv1 = (Ph1 & Xv1) & mask1;
+			}
+			uint64_t * q = &col[static_cast<size_t>(j)*4]; q[0] = pv0; q[1] = mv0; q[2] = pv1; q[3] = mv1; sc[j] = score;
+		}
+		rev.clear();
+		uint32_t i = m, j = n; int32_t d = score;
+		while ( i || j )
+		{
+			bool done = false;
+			if ( i && j )
+			{
+				// D[i-1][j-1] = bottom(j-1) - sum of the vertical deltas of rows i..m in column j-1
+				uint64_t const * q = &col[static_cast<size_t>(j-1)*4];
+				uint32_t const sh = i-1;
+				int32_t sum;
+				if ( sh < 64 ) sum = __builtin_popcountll(q[0]>>sh) + __builtin_popcountll(q[2]) - __builtin_popcountll(q[1]>>sh) - __builtin_popcountll(q[3]);
+				else sum = __builtin_popcountll(q[2]>>(sh-64)) - __builtin_popcountll(q[3]>>(sh-64));
+				int32_t const dd = sc[j-1] - sum;
+				bool const eq = a[i-1] == b[j-1];
+				if ( dd + (eq ? 0 : 1) == d ) { rev.push_back(eq ? OP_MATCH : OP_MISMATCH); --i; --j; d = dd; done = true; }
+			}
+			if ( !done && i )
+			{
+				uint64_t const * q = &col[static_cast<size_t>(j)*4];
+				uint32_t const r = i-1;
+				bool const plus = (r < 64) ? ((q[0]>>r)&1) : ((q[2]>>(r-64))&1);     // D[i][j] = D[i-1][j] + 1
+				if ( plus ) { rev.push_back(OP_DEL); --i; --d; done = true; }
+			}
+			if ( !done ) { rev.push_back(OP_INS); --j; --d; }
+		}
+		if ( ops ) ops->insert(ops->end(),rev.rbegin(),rev.rend());
+		if ( cnt ) for ( size_t x = 0; x < rev.size(); ++x ) ++cnt[rev[x]];
+		return static_cast<uint32_t>(score);
+	}
 	uint32_t run(uint8_t const * a, uint32_t const m, uint8_t const * b, uint32_t const n, std::vector<uint8_t> * ops, uint64_t * cnt)
 	{
+		if ( m >= 1 && m <= 128 && n >= 1 ) return runBits(a,m,b,n,ops,cnt);
 		uint32_t const W = n+1;
 		D.resize(static_cast<size_t>(m+1)*W);
 		for ( uint32_t j = 0; j <= n; ++j ) D[j] = j;
@@ -97,15 +170,25 @@ static inline void advanceOps(std::vector<uint8_t> const & ops, size_t & pos, ui
 	}
 }
 
-// does the string contain some q-mer twice?  (KmerRepeatDetector(q).detect)
-static bool repeatsQmer(uint8_t const * s, uint32_t const n, uint32_t const q, std::vector<uint32_t> & tmp)
+// does the string contain some q-mer twice?  (KmerRepeatDetector(q).detect)  One bit per q-mer (q = 7: 2 KB), cleared again
+// through the list of the q-mers seen (a sort of the q-mers per string was a quarter of the estimator's time)
+static bool repeatsQmer(uint8_t const * s, uint32_t const n, uint32_t const q, std::vector<uint32_t> & tmp, std::vector<uint64_t> & bits)
 {
 	if ( n < q+1 ) return false;
+	if ( bits.size() != ((1ull<<(2*q))+63)/64 ) bits.assign(((1ull<<(2*q))+63)/64,0);
 	tmp.clear(); uint32_t v = 0; uint32_t const mask = (1u<<(2*q))-1;
-	for ( uint32_t i = 0; i < n; ++i ) { v = ((v<<2)|s[i]) & mask; if ( i+1 >= q ) tmp.push_back(v); }
-	std::sort(tmp.begin(),tmp.end());
-	for ( size_t i = 1; i < tmp.size(); ++i ) if ( tmp[i] == tmp[i-1] ) return true;
-	return false;
+	bool rep = false;
+	for ( uint32_t i = 0; i < n && !rep; ++i )
+	{
+		v = ((v<<2)|s[i]) & mask;
+		if ( i+1 >= q )
+		{
+			uint64_t const b = 1ull<<(v&63);
+			if ( bits[v>>6] & b ) rep = true; else { bits[v>>6] |= b; tmp.push_back(v); }
+		}
+	}
+	for ( size_t i = 0; i < tmp.size(); ++i ) bits[tmp[i]>>6] = 0;
+	return rep;
 }
 
 // The k = 8 graph of one window restricted to k-mers of frequency >= 2, and its trivial traversal.
@@ -113,7 +196,7 @@ struct TrivialGraph
 {
 	struct Node { uint32_t v, freq, nsa; uint8_t ord[4]; uint8_t ns; };     // successors by (freq,symbol) descending, nsa of them active
 	std::vector<Node> N; std::vector<int32_t> id;                           // id[k-mer] = node or -1
-	std::vector<uint64_t> inst; std::vector<uint32_t> lastk;
+	std::vector<uint32_t> lastk, touched, nodev; std::vector<uint16_t> cnt, cnt0;      // cnt / cnt0: occurrences (all / at position 0) per k-mer
 	struct Str { uint32_t first, ext, last, len, off; };
 	std::vector<Str> S; std::vector<uint32_t> L; std::vector<uint8_t> mark;
 	TrivialGraph() : id(1u<<(2*EK),-1) {}
@@ -138,7 +221,9 @@ struct TrivialGraph
 	// those nodes, last = most frequent final k-mer of a string (both: first maximum in ascending k-mer order)
 	bool build(std::vector< std::pair<uint8_t const *,uint32_t> > const & M, uint32_t & first, uint32_t & last)
 	{
-		clearIds(); N.clear(); inst.clear(); lastk.clear();
+		clearIds(); N.clear(); lastk.clear(); touched.clear();
+		if ( cnt.empty() ) { cnt.assign(1u<<(2*EK),0); cnt0.assign(1u<<(2*EK),0); }
+		// occurrences per k-mer and occurrences at position 0 (16 bit k-mers: direct tables, cleared through `touched`)
 		for ( size_t j = 0; j < M.size(); ++j )
 		{
 			uint32_t const n = M[j].second; if ( n < EK ) continue;
@@ -146,22 +231,27 @@ struct TrivialGraph
 			for ( uint32_t i = 0; i < n; ++i )
 			{
 				v = ((v<<2)|M[j].first[i]) & KM;
-				if ( i+1 >= EK ) { uint32_t const pos = i+1-EK; inst.push_back((static_cast<uint64_t>(v)<<32) | pos); if ( i+1 == n ) lastk.push_back(v); }
+				if ( i+1 >= EK )
+				{
+					if ( cnt[v]++ == 0 ) touched.push_back(v);
+					if ( i+1 == EK ) ++cnt0[v];
+					if ( i+1 == n ) lastk.push_back(v);
+				}
 			}
 		}
-		std::sort(inst.begin(),inst.end()); std::sort(lastk.begin(),lastk.end());
+		std::sort(lastk.begin(),lastk.end());
+		// nodes = k-mers seen at least twice, in ascending k-mer order
+		nodev.clear();
+		for ( size_t i = 0; i < touched.size(); ++i ) if ( cnt[touched[i]] >= 2 ) nodev.push_back(touched[i]);
+		std::sort(nodev.begin(),nodev.end());
 		uint32_t bestc = 0; first = 0;
-		for ( size_t l = 0; l < inst.size(); )
+		for ( size_t i = 0; i < nodev.size(); ++i )
 		{
-			size_t h = l; uint32_t c0 = 0;
-			while ( h < inst.size() && (inst[h]>>32) == (inst[l]>>32) ) { if ( (inst[h]&0xFFFFFFFFu) == 0 ) ++c0; ++h; }
-			if ( h-l >= 2 )
-			{
-				Node x; x.v = inst[l]>>32; x.freq = h-l; x.nsa = 0; x.ns = 0; id[x.v] = N.size(); N.push_back(x);
-				if ( c0 > bestc ) { bestc = c0; first = x.v; }
-			}
-			l = h;
+			Node x; x.v = nodev[i]; x.freq = cnt[x.v]; x.nsa = 0; x.ns = 0; id[x.v] = N.size(); N.push_back(x);
+			uint32_t const c0 = cnt0[x.v];
+			if ( c0 > bestc ) { bestc = c0; first = x.v; }
 		}
+		for ( size_t i = 0; i < touched.size(); ++i ) { cnt[touched[i]] = 0; cnt0[touched[i]] = 0; }
 		uint32_t bestl = 0; last = 0;
 		for ( size_t l = 0; l < lastk.size(); )
 		{
@@ -253,7 +343,7 @@ struct Acc { uint64_t cnt[4]; uint64_t usable, unusable; std::vector<double> elo
 struct Worker
 {
 	Store const & R; int32_t tspace; bool twodb; uint64_t maxalign;
-	Dp dp; TrivialGraph G; std::vector<uint32_t> tmp; std::vector<uint8_t> ra, cons;
+	Dp dp; TrivialGraph G; std::vector<uint32_t> tmp; std::vector<uint64_t> qbits; std::vector<uint8_t> ra, cons;
 	std::vector< std::vector<uint8_t> > rb, ops;
 	Worker(Store const & r, int32_t ts, bool two, uint64_t ma) : R(r), tspace(ts), twodb(two), maxalign(ma) {}
 
@@ -315,7 +405,7 @@ struct Worker
 			}
 			if ( M.size() < 3 ) continue;
 			bool rep = false;
-			for ( size_t i = 0; i < M.size(); ++i ) rep = repeatsQmer(M[i].first,M[i].second,EK-1,tmp) || rep;
+			for ( size_t i = 0; i < M.size(); ++i ) rep = rep || repeatsQmer(M[i].first,M[i].second,EK-1,tmp,qbits);
 			if ( rep ) { ++A.unusable; continue; }
 			++A.usable;
 			uint32_t first, last;

@@ -254,3 +254,23 @@ def test_long_strings_make_long_stretches():
     fe, be = E.run(piles[:2], ovl, tr, trace_bytes=2)
     assert windows_equal(O.windows(), E.windows()) == []
     assert frags_equal(fo, bo, fe, be) and len(bo) > 3000
+
+
+def test_twice_split_stretch_stays_in_the_lds_tiers():
+    """A (first, last) k-mer pair that splits one stretch at two different nodes needs the MIDDLE piece of that stretch, whose
+    feasibility is computed while the enumeration pools lie over the node tables (gw layout: read from the spilled image in the
+    workgroup's slab, FastEngine::sGet).  While the gw tiers handed such windows on instead, 0.044 % of the windows of config 2
+    ended in the generic engine and took it longer than all other windows together (profiles/r03e_*): none may get there,
+    and the piles must still carry the oracle's digests (tests/golden/scale_cfg2.json, first 60 piles of the bench's data set)."""
+    import json, os
+    from daccord_amd import engine
+    from scale_cases import CASES, make_case, pile_digests
+    G = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scale_cfg2.json")))
+    d, ovl, piles, sel = make_case(dict(CASES["cfg2"]), pyoracle.pile_select)
+    sel = sel[:60]
+    run = G["runs"][0]
+    E = emul_lib.Emul(default_params(**run["params"])); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    fx, bx = E.run(sel, ovl, d.trace)
+    assert pile_digests(fx, bx, sel, engine.fasta) == run["pile_sha256"][:60]
+    t1, t2, t3, generic = E.counts()
+    assert generic == 0 and t1 > 50000, E.counts()
