@@ -52,3 +52,14 @@ run(["--batch5000"], "whole file, 5000 A reads per batch")
 pp = subprocess.Popen(args + ["-J0,8", las, db], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
 _, _, ru = os.wait4(pp.pid, 0)
 print("-J0,8: peak RSS %.1f MB (las %.1f MB, read store %.1f MB; the HIP runtime itself maps several hundred MB)" % (ru.ru_maxrss / 1024.0, os.path.getsize(las) / 1e6, len(d.bps) / 1e6))
+# the same run without a given profile: the front end estimates it from the first 1024 piles on the host threads first
+# (src/daccord.cpp:1653-1878), writes <las>.eprof and corrects with it
+if os.path.exists(las + ".eprof"):
+    os.remove(las + ".eprof")
+t = time.time()
+p = subprocess.run([exe, "-k14", "-V1", las, db], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env)
+err = p.stderr.decode()
+m = re.search(r"error profile estimated on (\d+) host threads in ([\d.]+) s", err)
+m2 = re.search(r"\[V\] (\d+) corrected bases in ([\d.]+) s end to end", err)
+print("no profile given: rc=%d wall %.2f s; estimator %s s on %s host threads; correction %s s end to end"
+      % (p.returncode, time.time() - t, m.group(2) if m else "?", m.group(1) if m else "?", m2.group(2) if m2 else "?"))

@@ -8,7 +8,7 @@ tail -n 3 $O/pytest_gpu.log
 for V in libdaccord_hip_prof libvar_t1legacy_prof; do
   [ -f daccord_amd/$V.so ] && ( DACC_LIB=$R/daccord_amd/$V.so timeout 100 python scripts/prof_phases.py 64 ) > $O/phases_$V.log 2>&1
 done
-bash scripts/gpu_pmc_r3.sh r03b > $O/pmc.log 2>&1
+bash scripts/gpu_pmc.sh r03b > $O/pmc.log 2>&1
 for f in $O/bench_default.log $O/bench_t1legacy.log; do echo "== $f"; grep '^{' $f | tail -n 1 | python -c "
 import sys, json
 try:

@@ -1,7 +1,7 @@
-# Round 3, GPU call 6: full GPU suite on the fixed build, default bench (with the CPU legs), 54x and ONT bench lines, what still
+# Round 3, GPU call 7: full GPU suite on the fixed build, default bench (with the CPU legs), 54x and ONT bench lines, what still
 # reaches the generic engine in each of the three workloads, -O2 / -Oz variants, phase profile, rocprof kernel stats and the
 # PMC passes of the default workload.
-R=$GRAFT_REPO_ROOT; O=gpurun_out/r3f; mkdir -p $R/$O; cd $R
+R=$GRAFT_REPO_ROOT; O=gpurun_out/r3g; mkdir -p $R/$O; cd $R
 ( timeout 900 python -m pytest tests -x -q -m gpu -rs --durations=8 ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -n 13 $O/pytest_gpu.log
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log; tail -n 2 $O/smoke.log
@@ -11,15 +11,15 @@ tail -n 13 $O/pytest_gpu.log
 ( timeout 200 python scripts/dbg_retry.py 14 10000 ) > $O/dbg_retry_cfg2.log 2>&1
 ( timeout 200 python scripts/dbg_retry.py 14 4000 ont ) > $O/dbg_retry_ont.log 2>&1
 ( timeout 300 python scripts/dbg_retry.py 14 2000 pb 54 ) > $O/dbg_retry_54x.log 2>&1
-for V in O2 Oz; do
-  [ -f daccord_amd/libvar_$V.so ] && ( DACC_LIB=$R/daccord_amd/libvar_$V.so timeout 120 python bench.py --reads 3000 --steps 2 --warmup 1 --no-cpu ) > $O/var_$V.log 2>&1
-done
-( timeout 120 python bench.py --reads 3000 --steps 2 --warmup 1 --no-cpu ) > $O/var_default.log 2>&1
+# device code at -Os (-Xarch_device -Os: 144 KB instead of 174 KB for tier 1), whole default workload
+[ -f daccord_amd/libvar_devOs.so ] && ( DACC_LIB=$R/daccord_amd/libvar_devOs.so timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu ) > $O/var_devOs.log 2>&1
+( timeout 200 python bench.py --steps 3 --warmup 1 --no-cpu ) > $O/var_default.log 2>&1
+( timeout 300 python scripts/cli_end_to_end.py 10000 /tmp/dacc_e2e ) > $O/cli_end_to_end.log 2>&1
 ( DACC_LIB=$R/daccord_amd/libdaccord_hip_prof.so timeout 100 python scripts/prof_phases.py 64 ) > $O/phases.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 ( timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/stats -o st -- python $R/bench.py --steps 1 --warmup 0 --no-cpu ) > $R/$O/stats.log 2>&1; echo "rc=$?" >> $R/$O/stats.log
 cd $R
-bash scripts/gpu_pmc.sh r03f 10000 > $O/pmc.log 2>&1
+bash scripts/gpu_pmc.sh r03g 10000 > $O/pmc.log 2>&1
 for f in $O/bench_default.log $O/bench_54x_2000piles.log $O/bench_ont_4000piles.log $O/var_*.log; do echo "== $f"; grep '^{' $f | tail -n 1 | python -c "
 import sys, json
 try:
@@ -31,5 +31,5 @@ except Exception as e:
 "; done
 for f in $O/dbg_retry_*.log; do echo "== $f"; grep -v amdgpu $f | tail -7 | cut -c1-600; done
 head -8 $O/stats/st_kernel_stats.csv 2>/dev/null
-tail -n 15 $O/pmc.log
+tail -n 15 $O/pmc.log | cut -c1-200; grep -v amdgpu $O/cli_end_to_end.log
 true
