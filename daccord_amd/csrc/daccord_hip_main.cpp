@@ -46,7 +46,7 @@ struct Options
 	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
 	bool f = false; int V = 1; bool haveI = false, haveJ = false; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
 	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
-	bool eprofonly = false, keepeprof = false; int device = 0; uint64_t batch = 2000;
+	bool eprofonly = false, keepeprof = false, deepprofileonly = false; int device = 0; uint64_t batch = 2000;
 	std::vector<std::string> pos;
 };
 
@@ -93,7 +93,7 @@ Options parse(int argc, char ** argv)
 			else if ( val("eprof",v) ) o.eprof = v;
 			else if ( val("device",v) ) o.device = static_cast<int>(num("--device",v));
 			else if ( val("batch",v) ) { o.batch = num("--batch",v); if ( !o.batch ) die("--batch needs a positive number of A reads"); }
-			else if ( val("deepprofileonly",v) ) die("--deepprofileonly (k-mer depth profile of the estimator) is not part of this path");
+			else if ( val("deepprofileonly",v) ) o.deepprofileonly = v.empty() || v != "0";
 			else die("unknown option " + a);
 			continue;
 		}
@@ -128,7 +128,7 @@ Options parse(int argc, char ** argv)
 			"  -w<40> window  -a<10> advance  -k<8|lo,hi> k-mer size  -d<max depth>  -D<5000> max alignments per read  --vard<v>\n"
 			"  -m<3> min window coverage  -e<max window error>  -l<0> min output length  -f produce full reads\n"
 			"  -I<lo,hi> read interval (inclusive)  -J<i,j> part i of j  --minfilterfreq<0> --maxfilterfreq<2>\n"
-			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof\n"
+			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof  --deepprofileonly\n"
 			"  --device<0> HIP device  --batch<2000> A reads per GPU batch  (one process per GPU: -J<g,G> --device<g>)\n");
 		std::exit(EXIT_FAILURE);
 	}
@@ -260,6 +260,37 @@ int main(int argc, char ** argv)
 			if ( !readProfileText(eproffn,prof) ) die("cannot parse the error profile " + eproffn + " (three numbers: p_i p_d est_cor)");
 			have = true;
 		}
+	}
+	if ( o.deepprofileonly )
+	{
+		// --deepprofileonly (daccord.cpp:1442-1650): distribution of the window error rates of the estimator's windows over the
+		// first 4096 piles of the interval, "[deep] <error rate> <fraction of the windows at or below it>" per distinct value
+		int64_t const top = std::min<int64_t>(toparead,minaread+4096);
+		dacc_eprof * ep = 0;
+		if ( dacc_eprof_create(&ep,tspace,pbps,pboff,prlen,nreads,twodb ? 1 : 0) ) die("error distribution estimate: out of memory");
+		dacc_eprof_set_deep(ep,1);
+		unsigned int hw = std::thread::hardware_concurrency(); if ( !hw ) hw = 1; if ( hw > 64 ) hw = 64;
+		Batch EB;
+		for ( int64_t b0 = minaread; b0 < top; b0 += 256 )
+		{
+			loadBatch(b0,std::min<int64_t>(top,b0+256),true,EB);
+			if ( !EB.err.empty() ) die(EB.err);
+			if ( EB.spiles.empty() ) continue;
+			if ( dacc_eprof_add(ep,EB.spiles.data(),EB.spiles.size(),EB.sel.data(),EB.sel.size(),EB.trace.data(),EB.ntrace,tbytes,o.d,hw) ) die("error distribution estimate failed (out of memory)");
+		}
+		uint32_t const * dv = 0; uint64_t dn = 0;
+		dacc_eprof_deep(ep,&dv,&dn);
+		double const dcnt = static_cast<double>(dn);
+		uint64_t i = 0;
+		while ( i < dn )
+		{
+			uint64_t j = i; while ( j < dn && dv[j] == dv[i] ) ++j;
+			std::printf("[deep]\t%g\t%g\n",dv[i]/4294967295.0,static_cast<double>(j)/dcnt);
+			i = j;
+		}
+		dacc_eprof_destroy(ep);
+		dacc_las_close(las); dacc_db_close(A.h); if ( twodb ) dacc_db_close(B2.h);
+		return EXIT_SUCCESS;
 	}
 	if ( !have && !(minaread <= maxaread) )
 	{

@@ -338,7 +338,9 @@ struct TrivialGraph
 	}
 };
 
-struct Acc { uint64_t cnt[4]; uint64_t usable, unusable; std::vector<double> eloc; Acc() : usable(0), unusable(0) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; } };
+// deep: error rate of every window that got a consensus, as round(rate * (2^32-1)) (handleIndelEstimateDeep, daccord.cpp:634-995:
+// the same function as handleIndelEstimate with this one output, :963-968); collected only when asked for (--deepprofileonly)
+struct Acc { uint64_t cnt[4]; uint64_t usable, unusable; std::vector<double> eloc; bool wantdeep; std::vector<uint32_t> deep; Acc() : usable(0), unusable(0), wantdeep(false) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; } };
 
 struct Worker
 {
@@ -414,7 +416,13 @@ struct Worker
 			for ( size_t i = 0; i < M.size(); ++i ) dp.run(cons.data(),cons.size(),M[i].first,M[i].second,0,c);
 			for ( int q = 0; q < 4; ++q ) A.cnt[q] += c[q];
 			uint64_t const tot = c[0]+c[1]+c[2]+c[3];
-			esum += tot ? static_cast<double>(c[1]+c[2]+c[3])/static_cast<double>(tot) : 0.0; ++ecnt;
+			double const er = tot ? static_cast<double>(c[1]+c[2]+c[3])/static_cast<double>(tot) : 0.0;
+			esum += er; ++ecnt;
+			if ( A.wantdeep )
+			{
+				uint64_t const v = static_cast<uint64_t>(4294967295.0 * er + 0.5);
+				A.deep.push_back(static_cast<uint32_t>(v < 4294967295ull ? v : 4294967295ull));
+			}
 		}
 		return ecnt ? esum/ecnt : 0.0;
 	}
@@ -470,6 +478,7 @@ int dacc_eprof_add(dacc_eprof * e, dacc_pile const * piles, uint64_t npiles, dac
 		}
 		if ( nthreads < 1 ) nthreads = 1;
 		std::vector<Acc> part(nthreads); std::vector<double> eloc(npiles,0.0);
+		for ( int t = 0; t < nthreads; ++t ) part[t].wantdeep = e->A.wantdeep;
 		std::atomic<uint64_t> next(0);
 		std::atomic<int> failed(0);
 		auto body = [&](int const t)
@@ -490,7 +499,7 @@ int dacc_eprof_add(dacc_eprof * e, dacc_pile const * piles, uint64_t npiles, dac
 		body(0);
 		for ( size_t t = 0; t < T.size(); ++t ) T[t].join();
 		if ( failed ) return DACC_ENOMEM;
-		for ( int t = 0; t < nthreads; ++t ) { for ( int q = 0; q < 4; ++q ) e->A.cnt[q] += part[t].cnt[q]; e->A.usable += part[t].usable; e->A.unusable += part[t].unusable; }
+		for ( int t = 0; t < nthreads; ++t ) { for ( int q = 0; q < 4; ++q ) e->A.cnt[q] += part[t].cnt[q]; e->A.usable += part[t].usable; e->A.unusable += part[t].unusable; e->A.deep.insert(e->A.deep.end(),part[t].deep.begin(),part[t].deep.end()); }
 		for ( uint64_t i = 0; i < npiles; ++i ) if ( eloc[i] != 0.0 ) e->A.eloc.push_back(eloc[i]);      // in pile order
 	}
 	catch ( std::bad_alloc const & ) { return DACC_ENOMEM; }
@@ -514,6 +523,17 @@ int dacc_eprof_finish(dacc_eprof * e, uint64_t counts[4], uint64_t * usable, uin
 	uint64_t const len = matches + mism + del, numerr = mism + del + ins;
 	if ( !len ) return DACC_ENOTSUP;      // no usable window: the caller must supply a profile
 	prof[0] = static_cast<double>(ins)/len; prof[1] = static_cast<double>(del)/len; prof[2] = 1.0 - static_cast<double>(numerr)/len;
+	return DACC_OK;
+}
+
+// --deepprofileonly (daccord.cpp:1442-1650): the error rates of the windows with a consensus, ascending; `on` before the first
+// dacc_eprof_add.  The values stay valid until the next call on e.
+int dacc_eprof_set_deep(dacc_eprof * e, int on) { if ( !e ) return DACC_EINVAL; e->A.wantdeep = on != 0; return DACC_OK; }
+int dacc_eprof_deep(dacc_eprof * e, uint32_t const ** values, uint64_t * n)
+{
+	if ( !e || !values || !n ) return DACC_EINVAL;
+	std::sort(e->A.deep.begin(),e->A.deep.end());
+	*values = e->A.deep.data(); *n = e->A.deep.size();
 	return DACC_OK;
 }
 

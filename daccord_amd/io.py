@@ -32,6 +32,8 @@ def lib():
         L.dacc_eprof_add.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, vp, C.c_uint64, C.c_int, C.c_uint64, C.c_int]
         L.dacc_eprof_finish.argtypes = [vp] + [vp] * 6
         L.dacc_eprof_destroy.argtypes = [vp]
+        L.dacc_eprof_set_deep.argtypes = [vp, C.c_int]
+        L.dacc_eprof_deep.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -121,15 +123,18 @@ def select_lowest(ovl, piles, trace_bytes=1, maxinput=5000):
     return out[:o].copy(), newp
 
 
-def estimate_profile(bps, boff, rlen, tspace, piles, ovl, trace, trace_bytes=1, maxalign=2 ** 64 - 1, two_databases=False, nthreads=4):
+def estimate_profile(bps, boff, rlen, tspace, piles, ovl, trace, trace_bytes=1, maxalign=2 ** 64 - 1, two_databases=False, nthreads=4, deep=False):
     """Error profile estimation on the host (include/daccord_hip.h: dacc_eprof_*).  Returns
-    (counts[matches,mismatches,insertions,deletions], usable, unusable, (p_i, p_d, est_cor))."""
+    (counts[matches,mismatches,insertions,deletions], usable, unusable, (p_i, p_d, est_cor)); with deep=True a fifth element:
+    the sorted uint32 window error rates of --deepprofileonly (dacc_eprof_deep)."""
     L = lib(); h = C.c_void_p()
     bps = np.ascontiguousarray(bps, np.uint8); boff = np.ascontiguousarray(boff, np.uint64); rlen = np.ascontiguousarray(rlen, np.uint32)
     piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
     if L.dacc_eprof_create(C.byref(h), tspace, _ptr(bps), _ptr(boff), _ptr(rlen), len(rlen), 1 if two_databases else 0):
         raise MemoryError("dacc_eprof_create")
     try:
+        if deep:
+            L.dacc_eprof_set_deep(h, 1)
         rc = L.dacc_eprof_add(h, _ptr(piles), len(piles), _ptr(ovl), len(ovl), _ptr(trace), trace.nbytes // trace_bytes, trace_bytes, maxalign, nthreads)
         if rc:
             raise ValueError("dacc_eprof_add rc=%d" % rc)
@@ -137,6 +142,11 @@ def estimate_profile(bps, boff, rlen, tspace, piles, ovl, trace, trace_bytes=1, 
         rc = L.dacc_eprof_finish(h, _ptr(counts), C.byref(us), C.byref(un), C.byref(ea), C.byref(ed), _ptr(prof))
         if rc:
             raise ValueError("no usable window (rc=%d)" % rc)
+        if deep:
+            vp = C.POINTER(C.c_uint32)(); vn = C.c_uint64()
+            L.dacc_eprof_deep(h, C.byref(vp), C.byref(vn))
+            vals = np.ctypeslib.as_array(vp, shape=(vn.value,)).copy() if vn.value else np.zeros(0, np.uint32)
+            return counts, us.value, un.value, tuple(float(x) for x in prof), vals
         return counts, us.value, un.value, tuple(float(x) for x in prof)
     finally:
         L.dacc_eprof_destroy(h)

@@ -145,6 +145,11 @@ int  dacc_eprof_add(dacc_eprof *e, const dacc_pile *piles, uint64_t npiles, cons
 int  dacc_eprof_finish(dacc_eprof *e, uint64_t counts[4], uint64_t *usable, uint64_t *unusable,
                        double *eavg, double *edif, double prof[3]);
 void dacc_eprof_destroy(dacc_eprof *e);
+/* --deepprofileonly (daccord.cpp:1442-1650, handleIndelEstimateDeep :634-995): switch the collection on before the first
+ * dacc_eprof_add; dacc_eprof_deep returns, ascending, round(error rate * (2^32-1)) of every window that got a consensus
+ * (:963-968).  The caller prints the cumulative distribution (:1626-1648). */
+int  dacc_eprof_set_deep(dacc_eprof *e, int on);
+int  dacc_eprof_deep(dacc_eprof *e, const uint32_t **values, uint64_t *n);
 
 /* ---- measurement hooks (bench.py / profiling; not part of the data path) ---- */
 

@@ -32,7 +32,7 @@ static inline bool kmerRepeatDetect(uint8_t const * p, uint64_t const n, unsigne
 // src/daccord.cpp:271-631
 static inline double handleIndelEstimate8(uint64_t const maxalign, dacc_overlap const * ita, dacc_overlap const * ite,
 	uint64_t const windowsize, uint64_t const advancesize, ReadStore & RC, bool const twodb, void const * trace, int const trace_bytes,
-	int64_t const tspace, AlignmentStatistics & RGAS, uint64_t & usable, uint64_t & unusable)
+	int64_t const tspace, AlignmentStatistics & RGAS, uint64_t & usable, uint64_t & unusable, std::vector<uint32_t> * deep = 0)
 {
 	unsigned int const k = 8;
 	uint64_t const nintv = ite-ita;
@@ -131,6 +131,13 @@ static inline double handleIndelEstimate8(uint64_t const maxalign, dacc_overlap 
 					}
 					RGAS += GAS;
 					esum += GAS.getErrorRate(); ecnt += 1;
+					// handleIndelEstimateDeep (src/daccord.cpp:634-995) is this function with one more output (:963-968)
+					if ( deep )
+					{
+						double const e = GAS.getErrorRate();
+						uint64_t const v = static_cast<uint64_t>(static_cast<double>(std::numeric_limits<uint32_t>::max()) * e + 0.5);
+						deep->push_back(static_cast<uint32_t>(std::min(v,static_cast<uint64_t>(std::numeric_limits<uint32_t>::max()))));
+					}
 				}
 			}
 		}

@@ -349,4 +349,22 @@ int oracle_estimate_profile(void * v, dacc_pile const * piles, uint64_t npiles, 
 	return 0;
 }
 
+// src/daccord.cpp:1442-1650 (--deepprofileonly): handleIndelEstimateDeep<8> over the given (already selected) piles; the window
+// error rates as sorted 32 bit values (what the merger of :1626-1648 reads back), at most cap of them; returns their number
+uint64_t oracle_deep_profile(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, void const * trace, int trace_bytes,
+	uint64_t maxalign, int twodb, uint32_t * out, uint64_t cap)
+{
+	OracleCtx * c = static_cast<OracleCtx *>(v);
+	std::vector<uint32_t> D;
+	for ( uint64_t i = 0; i < npiles; ++i )
+	{
+		AlignmentStatistics LGAS; uint64_t lu = 0, lun = 0;
+		c->db.clear();
+		handleIndelEstimate8(maxalign,ovl+piles[i].first_ovl,ovl+piles[i].first_ovl+piles[i].novl,40,5,c->db,twodb != 0,trace,trace_bytes,c->par.tspace,LGAS,lu,lun,&D);
+	}
+	std::sort(D.begin(),D.end());
+	for ( uint64_t i = 0; i < D.size() && i < cap; ++i ) out[i] = D[i];
+	return D.size();
+}
+
 }

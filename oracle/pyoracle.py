@@ -121,6 +121,17 @@ class Oracle:
             raise ValueError("no usable window")
         return counts, us.value, un.value, tuple(float(x) for x in prof)
 
+    def deep_profile(self, piles, ovl, trace, trace_bytes=1, maxalign=2 ** 64 - 1, two_databases=False):
+        """src/daccord.cpp:1442-1650 (--deepprofileonly) over the given (already selected) piles: sorted uint32 window error rates."""
+        piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
+        self.L.oracle_deep_profile.restype = C.c_uint64
+        self.L.oracle_deep_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64]
+        n = self.L.oracle_deep_profile(self.h, _ptr(piles), len(piles), _ptr(ovl), _ptr(trace), trace_bytes, maxalign, 1 if two_databases else 0, None, 0)
+        out = np.zeros(n, np.uint32)
+        if n:
+            self.L.oracle_deep_profile(self.h, _ptr(piles), len(piles), _ptr(ovl), _ptr(trace), trace_bytes, maxalign, 1 if two_databases else 0, _ptr(out), n)
+        return out
+
     def run(self, piles, ovl, trace, trace_bytes=1, nthreads=1, want_windows=False):
         piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
         rc = self.L.oracle_run_piles(self.h, _ptr(piles), len(piles), _ptr(ovl), len(ovl), _ptr(trace), len(trace),

@@ -62,3 +62,33 @@ def test_estimator_skips_a_malformed_pile():
     c0, u0, n0, p0 = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, good_piles, ovl, d.trace, nthreads=2)
     c1, u1, n1, p1 = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:n], bad, d.trace, nthreads=2)
     assert list(c0) == list(c1) and (u0, n0) == (u1, n1) and p0 == p1
+
+
+def test_deep_profile_matches_oracle_and_cli(tmp_path):
+    """--deepprofileonly (src/daccord.cpp:1442-1650, handleIndelEstimateDeep :634-995): round(error rate * (2^32-1)) of every
+    estimator window that got a consensus -- product (dacc_eprof_deep) against the oracle's restatement, value for value, and
+    the front end's `[deep] <rate> <cumulative fraction>` lines against the same values."""
+    import os, subprocess
+    d = SynthData(60000, 120, 3000, seed=1)
+    ovl, piles = dio.select_lowest(d.ovl, d.piles)
+    n = 40
+    O = pyoracle.Oracle(default_params(k=8, tspace=100)); O.load_db(d.bps, d.boff, d.rlen)
+    want = O.deep_profile(piles[:n], ovl, d.trace)
+    got = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:n], ovl, d.trace, nthreads=3, deep=True)[4]
+    assert len(want) > 200 and (np.diff(want.astype(np.int64)) >= 0).all()
+    assert len(got) == len(want) and (got == want).all()
+    # the front end on files (host code only up to this point: it exits before a device context is created)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "daccord_amd", "daccord_hip")
+    db, las = str(tmp_path / "r.db"), str(tmp_path / "r.las")
+    dio.write_db(db, d.bps, d.boff, d.rlen); dio.write_las(las, 100, d.ovl, d.trace)
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(root, "daccord_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe, "--deepprofileonly", "-V0", "-I0,%d" % (n - 1), las, db], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr[-500:]
+    lines = [l.split("\t") for l in p.stdout.splitlines()]
+    assert lines and all(l[0] == "[deep]" for l in lines)
+    vals, cnts = np.unique(want, return_counts=True)
+    assert len(lines) == len(vals)
+    cum = np.cumsum(cnts) / float(len(want))
+    for (tag, rate, frac), v, c in zip(lines, vals, cum):
+        assert float(rate) == float("%g" % (v / 4294967295.0)) and float(frac) == float("%g" % c)
