@@ -12,8 +12,10 @@ CLI = os.path.join(_HERE, "daccord_hip")
 # device code at -Os: the window kernels are one 140-190 KB function each (every helper is inlined so that the LDS layout stays
 # a set of immediates); -Os makes tier 1 17 % smaller (174 -> 144 KB) and 1.9 % faster on config 2
 # (profiles/r03g_bench_devOs.log vs r03g_bench_default_O3.log); host code in the same translation units stays at -O3
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-Xarch_device", "-Os", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wno-unused-value"]
+# machine scheduler: the window kernels wait on dependent LDS round trips, so the GCN max-ILP strategy (independent loads
+# first) beats the default max-occupancy one by 1.9 % on tier 1 at the same register count (profiles/r03i_scheduler_variants.md)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-Xarch_device", "-Os", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-std=c++17",
+               "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
 def csrc_hash():
