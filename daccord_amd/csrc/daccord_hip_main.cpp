@@ -46,7 +46,7 @@ struct Options
 	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
 	bool f = false; int V = 1; bool haveI = false, haveJ = false; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
 	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
-	bool eprofonly = false, keepeprof = false, deepprofileonly = false; int device = 0; uint64_t batch = 2000;
+	bool eprofonly = false, keepeprof = false, deepprofileonly = false; int device = 0; int gpus = 1; uint64_t batch = 2000;
 	std::vector<std::string> pos;
 };
 
@@ -92,6 +92,7 @@ Options parse(int argc, char ** argv)
 			else if ( val("keepeprof",v) ) o.keepeprof = v.empty() || v != "0";
 			else if ( val("eprof",v) ) o.eprof = v;
 			else if ( val("device",v) ) o.device = static_cast<int>(num("--device",v));
+			else if ( val("gpus",v) ) { o.gpus = static_cast<int>(num("--gpus",v)); if ( o.gpus < 1 || o.gpus > 64 ) die("--gpus needs a number between 1 and 64"); }
 			else if ( val("batch",v) ) { o.batch = num("--batch",v); if ( !o.batch ) die("--batch needs a positive number of A reads"); }
 			else if ( val("deepprofileonly",v) ) o.deepprofileonly = v.empty() || v != "0";
 			else die("unknown option " + a);
@@ -129,7 +130,8 @@ Options parse(int argc, char ** argv)
 			"  -m<3> min window coverage  -e<max window error>  -l<0> min output length  -f produce full reads\n"
 			"  -I<lo,hi> read interval (inclusive)  -J<i,j> part i of j  --minfilterfreq<0> --maxfilterfreq<2>\n"
 			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof  --deepprofileonly\n"
-			"  --device<0> HIP device  --batch<2000> A reads per GPU batch  (one process per GPU: -J<g,G> --device<g>)\n");
+			"  --device<0> first HIP device  --gpus<1> devices used by this process (batches are dealt to them, output stays ordered)\n"
+			"  --batch<2000> A reads per GPU batch  (or one process per GPU like the reference: -J<g,G> --device<g>)\n");
 		std::exit(EXIT_FAILURE);
 	}
 	return o;
@@ -210,7 +212,7 @@ int main(int argc, char ** argv)
 	uint64_t const nB = twodb ? B2.n : A.n;
 
 	// batch of piles [b0,b1): load, top-D select per pile, shift B ids in two database mode
-	struct Batch { std::vector<dacc_overlap> sel; std::vector<dacc_pile> spiles; std::vector<uint8_t> trace; uint64_t ntrace = 0; bool end = false; std::string err; };
+	struct Batch { std::vector<dacc_overlap> sel; std::vector<dacc_pile> spiles; std::vector<uint8_t> trace; uint64_t ntrace = 0; bool end = false; std::string err; uint64_t seq = 0; };
 	std::vector<dacc_overlap> tmp;
 	auto loadBatch = [&](int64_t const b0, int64_t const b1, bool const lowest, Batch & B) -> void
 	{
@@ -338,28 +340,44 @@ int main(int argc, char ** argv)
 	dacc_params p; std::memset(&p,0,sizeof(p));
 	p.w = o.w; p.a = o.a; p.klow = o.klow; p.khigh = o.khigh; p.minfilterfreq = o.minff; p.maxfilterfreq = o.maxff; p.minwindowcov = o.m;
 	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = o.device; p.verbose = o.V;
-	dacc_ctx * ctx = 0;
-	{ int const rc = dacc_create(&ctx,&p); if ( rc ) die("dacc_create failed (" + std::to_string(rc) + "): no usable HIP device or bad parameters"); }
-	if ( dacc_load_db(ctx,pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctx));
-
-	if ( dacc_set_error_profile(ctx,prof[0],prof[1],prof[2]) ) die(std::string("error profile: ") + dacc_last_error(ctx));
+	// One context per device worker.  --gpus N uses the devices device, device+1, ...; when there are fewer devices the workers
+	// wrap around (a legal, oversubscribed configuration: two contexts on one GPU overlap one batch's host plan with the other's
+	// kernels; it is also how the mode is tested on a box with one GPU).  Piles are independent, so the batches are simply dealt to whichever worker is free; the writer
+	// restores the batch order, and with it the reference's ascending A-read order and sequential well numbers.
+	int const nwork = o.gpus;
+	std::vector<dacc_ctx *> ctxs(nwork,static_cast<dacc_ctx *>(0));
+	{
+		int ndev = 0;      // devices found so far: the first worker whose device does not exist wraps around
+		for ( int g = 0; g < nwork; ++g )
+		{
+			dacc_params pg = p; pg.device = ndev ? (o.device + g % ndev) : (o.device + g);
+			int rc = dacc_create(&ctxs[g],&pg);
+			if ( rc && g > 0 && !ndev ) { ndev = g; pg.device = o.device + g % ndev; rc = dacc_create(&ctxs[g],&pg); }
+			if ( rc ) die("dacc_create failed (" + std::to_string(rc) + ") on device " + std::to_string(pg.device) + ": no usable HIP device or bad parameters");
+			if ( dacc_load_db(ctxs[g],pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctxs[g]));
+			if ( dacc_set_error_profile(ctxs[g],prof[0],prof[1],prof[2]) ) die(std::string("error profile: ") + dacc_last_error(ctxs[g]));
+			if ( o.V && nwork > 1 ) std::fprintf(stderr,"[V] device worker %d on HIP device %d\n",g,pg.device);
+		}
+	}
 
 	// Three stages, overlapped like the reference overlaps input, handlers and output with its threads (daccord.cpp:2107-2112):
-	// a loader thread reads the byte range of the next batch of A reads from the .las and selects its piles, this thread
-	// plans the batch and runs it on the GPU, a writer thread turns the fragments of the previous batch into FASTA text.
+	// a loader thread reads the byte range of the next batch of A reads from the .las and selects its piles, the device workers
+	// plan their batches and run them on their GPUs, a writer thread turns the fragments into FASTA text in batch order.
 	int64_t const batch = static_cast<int64_t>(o.batch);
-	struct Out { std::vector<dacc_fragment> fr; std::string bases; bool end = false; };
+	struct Out { std::vector<dacc_fragment> fr; std::string bases; uint64_t seq = 0; bool end = false; };
 	std::mutex mu; std::condition_variable cv;
 	std::deque<Batch *> loaded; std::deque<Batch *> freeb; std::deque<Out *> outs; std::deque<Out *> freeo;
-	Batch bslots[2]; Out oslots[2];
-	freeb.push_back(&bslots[0]); freeb.push_back(&bslots[1]); freeo.push_back(&oslots[0]); freeo.push_back(&oslots[1]);
+	std::vector<Batch> bslots(2*nwork); std::vector<Out> oslots(2*nwork+1);
+	for ( size_t i = 0; i < bslots.size(); ++i ) freeb.push_back(&bslots[i]);
+	for ( size_t i = 0; i < oslots.size(); ++i ) freeo.push_back(&oslots[i]);
 	auto const t0 = std::chrono::steady_clock::now();
 	std::thread loader([&]() {
+		uint64_t seq = 0;
 		for ( int64_t b0 = minaread; ; b0 += batch )
 		{
 			Batch * B;
 			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeb.empty(); }); B = freeb.front(); freeb.pop_front(); }
-			B->end = !(b0 < toparead);
+			B->end = !(b0 < toparead); B->seq = seq++;
 			if ( !B->end ) loadBatch(b0,std::min(toparead,b0+batch),false,*B);
 			bool const stop = B->end || !B->err.empty();
 			{ std::lock_guard<std::mutex> lk(mu); loaded.push_back(B); }
@@ -369,11 +387,16 @@ int main(int argc, char ** argv)
 	});
 	uint64_t well = 0, totalbases = 0;
 	std::thread writer([&]() {
-		std::string rec;
+		std::string rec; uint64_t nextseq = 0;
 		while ( true )
 		{
-			Out * O;
-			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !outs.empty(); }); O = outs.front(); outs.pop_front(); }
+			Out * O = 0;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk,[&]{ for ( size_t i = 0; i < outs.size(); ++i ) if ( outs[i]->seq == nextseq ) return true; return false; });
+				for ( size_t i = 0; i < outs.size(); ++i ) if ( outs[i]->seq == nextseq ) { O = outs[i]; outs.erase(outs.begin()+i); break; }
+			}
+			++nextseq;
 			if ( O->end ) break;
 			rec.clear();
 			for ( size_t i = 0; i < O->fr.size(); ++i )
@@ -389,40 +412,65 @@ int main(int argc, char ** argv)
 			cv.notify_all();
 		}
 	});
-	std::string fatal;
-	double gpu_s = 0; uint64_t nbatches = 0;
-	while ( true )
+	std::string fatal; bool stopall = false;           // both under mu
+	double gpu_s = 0; uint64_t nbatches = 0;            // under mu
+	// every batch (also an empty one, the end marker and a failed one) hands the writer an Out with its sequence number: the
+	// writer needs an unbroken sequence.  An output slot is always available within bounded time: at most one Out per worker is
+	// in flight besides those queued for the writer, and there are 2*nwork+1 slots.
+	auto const deviceWorker = [&](int const g)
 	{
-		Batch * B;
-		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !loaded.empty(); }); B = loaded.front(); loaded.pop_front(); }
-		if ( !B->err.empty() ) { fatal = B->err; break; }
-		if ( B->end ) break;
-		if ( !B->spiles.empty() )
+		dacc_ctx * const ctx = ctxs[g];
+		while ( true )
 		{
-			auto const tb0 = std::chrono::steady_clock::now();
-			if ( dacc_submit_piles(ctx,B->spiles.data(),B->spiles.size(),B->sel.data(),B->sel.size(),B->trace.data(),B->ntrace,tbytes) )
-			{ fatal = std::string("batch failed: ") + dacc_last_error(ctx); break; }
-			gpu_s += std::chrono::duration<double>(std::chrono::steady_clock::now()-tb0).count(); ++nbatches;
-			{ char const * pe = dacc_pile_errors(ctx); if ( pe && *pe ) std::fprintf(stderr,"[E] skipped reads:\n%s",pe); }
-			dacc_fragment const * fr = 0; uint64_t nf = 0; char const * bases = 0; uint64_t nb = 0;
-			if ( dacc_collect(ctx,&fr,&nf,&bases,&nb) ) { fatal = std::string("collect: ") + dacc_last_error(ctx); break; }
+			Batch * B = 0;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				cv.wait(lk,[&]{ return stopall || !loaded.empty(); });
+				if ( stopall ) return;
+				B = loaded.front();
+				if ( B->end || !B->err.empty() ) stopall = true;      // the last batch: the other workers stop, this one reports it
+				loaded.pop_front();
+			}
+			cv.notify_all();
+			std::string err = B->err;
+			bool const end = B->end; uint64_t const seq = B->seq;
 			Out * O;
 			{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeo.empty(); }); O = freeo.front(); freeo.pop_front(); }
-			O->end = false; O->fr.assign(fr,fr+nf); O->bases.assign(bases,nb); totalbases += nb;
-			dacc_release(ctx);
-			{ std::lock_guard<std::mutex> lk(mu); outs.push_back(O); }
+			O->fr.clear(); O->bases.clear(); O->seq = seq; O->end = end || !err.empty();
+			if ( err.empty() && !end && !B->spiles.empty() )
+			{
+				auto const tb0 = std::chrono::steady_clock::now();
+				if ( dacc_submit_piles(ctx,B->spiles.data(),B->spiles.size(),B->sel.data(),B->sel.size(),B->trace.data(),B->ntrace,tbytes) )
+					err = std::string("batch failed: ") + dacc_last_error(ctx);
+				else
+				{
+					double const dt = std::chrono::duration<double>(std::chrono::steady_clock::now()-tb0).count();
+					{ char const * pe = dacc_pile_errors(ctx); if ( pe && *pe ) std::fprintf(stderr,"[E] skipped reads:\n%s",pe); }
+					dacc_fragment const * fr = 0; uint64_t nf = 0; char const * bases = 0; uint64_t nb = 0;
+					if ( dacc_collect(ctx,&fr,&nf,&bases,&nb) ) err = std::string("collect: ") + dacc_last_error(ctx);
+					else
+					{
+						O->fr.assign(fr,fr+nf); O->bases.assign(bases,nb);
+						dacc_release(ctx);
+						std::lock_guard<std::mutex> lk(mu); gpu_s += dt; ++nbatches; totalbases += nb;
+					}
+				}
+			}
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				if ( !err.empty() ) { if ( fatal.empty() ) fatal = err; stopall = true; O->end = true; O->fr.clear(); O->bases.clear(); }
+				outs.push_back(O); freeb.push_back(B);
+			}
 			cv.notify_all();
+			if ( O->end ) return;
 		}
-		{ std::lock_guard<std::mutex> lk(mu); freeb.push_back(B); }
-		cv.notify_all();
-	}
-	{
-		Out * O;
-		{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeo.empty(); }); O = freeo.front(); freeo.pop_front(); }
-		O->end = true;
-		{ std::lock_guard<std::mutex> lk(mu); outs.push_back(O); }
-		cv.notify_all();
-	}
+	};
+	std::vector<std::thread> workers;
+	for ( int g = 1; g < nwork; ++g ) workers.emplace_back(deviceWorker,g);
+	deviceWorker(0);
+	for ( size_t i = 0; i < workers.size(); ++i ) workers[i].join();
+	// every batch taken from the loader is delivered (also a failed one, as an end marker), in particular all those in front of
+	// an end marker: the writer always reaches it
 	writer.join();
 	if ( !fatal.empty() ) { std::fflush(stdout); std::fprintf(stderr,"[E] %s\n",fatal.c_str()); std::_Exit(EXIT_FAILURE); }
 	loader.join();
@@ -430,10 +478,11 @@ int main(int argc, char ** argv)
 	if ( o.V )
 	{
 		double const el = std::chrono::duration<double>(std::chrono::steady_clock::now()-t0).count();
-		std::fprintf(stderr,"[V] %llu corrected bases in %.2f s end to end (load + select + plan + GPU + FASTA) = %.3f Mbase/s; %llu batches, %.2f s in dacc_submit_piles\n",
-			static_cast<unsigned long long>(totalbases),el,el > 0 ? totalbases/el/1e6 : 0.0,static_cast<unsigned long long>(nbatches),gpu_s);
+		std::fprintf(stderr,"[V] %llu corrected bases in %.2f s end to end (load + select + plan + GPU + FASTA) = %.3f Mbase/s; %llu batches, %.2f s in dacc_submit_piles%s\n",
+			static_cast<unsigned long long>(totalbases),el,el > 0 ? totalbases/el/1e6 : 0.0,static_cast<unsigned long long>(nbatches),gpu_s,
+			nwork > 1 ? (" (summed over " + std::to_string(nwork) + " device workers)").c_str() : "");
 	}
-	dacc_destroy(ctx);
+	for ( int g = 0; g < nwork; ++g ) dacc_destroy(ctxs[g]);
 	dacc_las_close(las); dacc_db_close(A.h); if ( twodb ) dacc_db_close(B2.h);
 	return EXIT_SUCCESS;
 }

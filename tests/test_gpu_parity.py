@@ -178,6 +178,12 @@ def test_cli_from_las_and_db_files(small_data, tmp_path):
     sel = piles[piles["aread"] <= 6]
     fo, bo = O.run(sel, ovl, d.trace, nthreads=4)
     assert r.stdout.decode() == pyoracle.fasta(fo, bo)
+    # --gpus 3: three device workers (wrapping around on a box with fewer GPUs), batches of two A reads dealt to them, the
+    # writer restores the order: byte-identical output, sequential well numbers included
+    r3 = cli.run(["-k8", "-I0,6", "--gpus3", "--batch2", "--eprof%r,%r,%r" % (p_i, p_d, cor), las, db])
+    assert r3.returncode == 0, r3.stderr.decode()
+    assert r3.stdout == r.stdout
+    assert sum(1 for ln in r3.stderr.decode().splitlines() if ln.startswith("[V] device worker ")) == 3
     # -J 1,3 = second third of the read range; --vard caps the depth per read (daccord.cpp:2120-2126)
     lo, hi = int(d.ovl["aread"].min()), int(d.ovl["aread"].max()) + 1
     part = (hi - lo + 2) // 3
