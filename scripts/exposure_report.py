@@ -5,7 +5,7 @@ on a slice of BASELINE config 2 once per switch (oracle/o_align.hpp: ORACLE_TB_B
 ORACLE_KLIM_DELTA, ORACLE_CONV) and reports against the default:
   windows whose record (status, consensus, minrate, filter frequency) changes, corrected bases that change (edit distance
   between the two outputs of every read, fragment lists concatenated), and the checkconsensus error rate against the truth.
-usage: python scripts/exposure_report.py [npiles=200] [first=3000] [nthreads=6]      -> profiles/r03_exposure.json + table
+usage: python scripts/exposure_report.py [npiles=200] [first=3000] [nthreads=6] [case=cfg2]      -> profiles/r03_exposure[_case].json + table
 (one child process per variant: the switches are read when the oracle library is loaded)"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,13 +26,13 @@ VARIANTS = [("default", {}),
             ("convolution summed in descending index order", {"ORACLE_CONV": "2"})]
 
 
-def child(npiles, first, nthreads, out):
+def child(npiles, first, nthreads, out, cname="cfg2"):
     import numpy as np
     import pyoracle
     from daccord_amd._structs import default_params
     from daccord_amd import checkconsensus
     from scale_cases import CASES, make_case
-    case = dict(CASES["cfg2"]); case["first"] = first; case["npiles"] = npiles
+    case = dict(CASES[cname]); case["first"] = first; case["npiles"] = npiles
     d, ovl, piles, sel = make_case(case, pyoracle.pile_select)
     O = pyoracle.Oracle(default_params(k=14)); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
     t0 = time.time()
@@ -49,7 +49,8 @@ def main():
     npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
     nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-    tmp = os.path.join(ROOT, "gpurun_out", "exposure"); os.makedirs(tmp, exist_ok=True)
+    cname = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+    tmp = os.path.join(ROOT, "gpurun_out", "exposure" + ("" if cname == "cfg2" else "_" + cname)); os.makedirs(tmp, exist_ok=True)
     # a private build of the oracle (the switches are compiled in; other test runs may have the shared copy loaded)
     so = os.path.join(tmp, "liboracle_sw.so")
     subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-shared", "-o", so, os.path.join(ROOT, "oracle", "oracle_capi.cpp")])
@@ -59,7 +60,7 @@ def main():
         out = os.path.join(tmp, "v%02d.npz" % i)
         if not os.path.exists(out):
             e = dict(os.environ); e.update(env)
-            subprocess.check_call([sys.executable, __file__, "--child", str(npiles), str(first), str(nthreads), out], env=e)
+            subprocess.check_call([sys.executable, __file__, "--child", str(npiles), str(first), str(nthreads), out, cname], env=e)
         res.append((name, env, np.load(out, allow_pickle=False)))
         print("ran", name, "%.0f s" % float(res[-1][2]["seconds"]), flush=True)
     import pyoracle
@@ -92,8 +93,8 @@ def main():
                      "reads": len(breads), "reads_changed": rd, "corrected_bases": nb, "bases_changed_edit_distance": ed,
                      "frac_windows_changed": round(wd / max(1, len(z["status"])), 6), "frac_bases_changed": round(ed / max(1, nb), 8),
                      "truth_erate": acc.get("erate"), "truth_covered_frac": acc.get("covered_frac")})
-    out = {"workload": "BASELINE config 2, piles %d..%d, k=14" % (first, first + npiles - 1), "rows": rows}
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_exposure.json"), "w"), indent=1)
+    out = {"workload": "tests/scale_cases.py case %s, piles %d..%d, k=14" % (cname, first, first + npiles - 1), "rows": rows}
+    json.dump(out, open(os.path.join(ROOT, "profiles", "r03_exposure%s.json" % ("" if cname == "cfg2" else "_" + cname)), "w"), indent=1)
     print("%-52s %10s %10s %12s %12s %10s" % ("variant", "win chg", "cons chg", "bases chg", "frac bases", "erate"))
     for r in rows:
         print("%-52s %10d %10d %12d %12.2e %10.6f" % (r["variant"], r["windows_changed"], r["windows_consensus_changed"], r["bases_changed_edit_distance"], r["frac_bases_changed"], r["truth_erate"] or 0))
@@ -101,6 +102,6 @@ def main():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5])
+        child(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], sys.argv[6] if len(sys.argv) > 6 else "cfg2")
     else:
         main()
