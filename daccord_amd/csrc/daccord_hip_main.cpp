@@ -456,13 +456,15 @@ int main(int argc, char ** argv)
 					}
 				}
 			}
+			bool last;
 			{
 				std::lock_guard<std::mutex> lk(mu);
 				if ( !err.empty() ) { if ( fatal.empty() ) fatal = err; stopall = true; O->end = true; O->fr.clear(); O->bases.clear(); }
+				last = O->end;      // (O belongs to the writer from here on)
 				outs.push_back(O); freeb.push_back(B);
 			}
 			cv.notify_all();
-			if ( O->end ) return;
+			if ( last ) return;
 		}
 	};
 	std::vector<std::thread> workers;
