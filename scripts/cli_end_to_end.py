@@ -48,6 +48,9 @@ def run(extra, tag):
 run([], "whole file (first run scans the .las and writes the sidecar index)")
 run([], "whole file (second run loads the sidecar index)")
 run(["--batch5000"], "whole file, 5000 A reads per batch")
+# two device workers (two contexts; on a box with one GPU both on it: one batch's host plan overlaps the other's kernels)
+run(["--gpus2"], "whole file, --gpus2")
+run(["--gpus2", "--batch1000"], "whole file, --gpus2, 1000 A reads per batch")
 # peak RSS of one of eight -J parts (rusage of that child alone)
 pp = subprocess.Popen(args + ["-J0,8", las, db], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
 _, _, ru = os.wait4(pp.pid, 0)
