@@ -39,7 +39,7 @@ def check(frags, bases, genome, truth, rlen, reads=None, slack=400):
             g = g.translate(_COMP)[::-1]
         G, rl = len(g), int(rlen[r]); cov = 0; racc = np.zeros(4, np.int64)
         for f in by.get(r, []):
-            s = bases[int(f["seq_off"]):int(f["seq_off"]) + int(f["len"])]
+            s = bytes(bases[int(f["seq_off"]):int(f["seq_off"]) + int(f["len"])])      # bases: any bytes-like
             e0 = int(round(int(f["first"]) * G / rl)); e1 = int(round((int(f["last"]) + 1) * G / rl))
             w0 = max(0, e0 - slack); w1 = min(G, e1 + slack)
             st4 = np.zeros(4, np.uint64); a = C.c_uint64(); b = C.c_uint64()

@@ -189,7 +189,7 @@ def fasta(frags, bases, start_well=0):
     out = []
     well = start_well
     for f in frags:
-        s = bases[f["seq_off"]:f["seq_off"] + f["len"]].decode()
+        s = bytes(bases[f["seq_off"]:f["seq_off"] + f["len"]]).decode()      # bases: bytes, bytearray or a memoryview (shard.gather_fragments)
         out.append(">%d/%d/%d_%d A=[%d,%d]\n" % (f["aread"] + 1, well, f["first"], f["first"] + f["len"], f["first"], f["last"]))
         well += 1
         for i in range(0, len(s), 80):
