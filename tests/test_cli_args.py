@@ -25,7 +25,8 @@ def _interval(stderr):
 
 def test_usage_and_unknown_options_fail_loudly(files):
     d, las, db = files
-    for bad in (["-Q3", las, db], ["--nosuchoption", las, db], [las], ["-I5", "--eprofonly", las, db], ["-J1,0", "--eprofonly", las, db]):
+    for bad in (["-Q3", las, db], ["--nosuchoption", las, db], [las], ["-I5", "--eprofonly", las, db], ["-J1,0", "--eprofonly", las, db],
+                ["--gpus0", "--eprofonly", las, db], ["--gpus65", "--eprofonly", las, db], ["--gpusx", "--eprofonly", las, db]):
         r = cli.run(bad)
         assert r.returncode != 0 and (b"[E]" in r.stderr or b"usage" in r.stderr), bad
 
