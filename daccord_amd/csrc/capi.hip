@@ -260,6 +260,30 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t const v, uint32_t *
 	return MAXOP ? (excl > base ? excl : base) : (base + excl);
 }
 
+// Size classes (shallow batches): one thread per window decides from the window tables whether the window starts in tier 0
+// (small list) or in tier 1 (big list = the list tier 0 appends its hand-overs to); windows the pre-scan set aside are in neither.
+// Blocks reserve their range of a list with one atomic each, so a list keeps the window order inside a block.
+__global__ void __launch_bounds__(256) k_classify(WindowBatch B, uint32_t * small, uint32_t * big, uint32_t const t0inst)
+{
+	__shared__ uint32_t part4[4]; __shared__ uint32_t base2[2];
+	uint64_t const w = static_cast<uint64_t>(blockIdx.x)*256 + threadIdx.x;
+	uint32_t cls = 2;
+	if ( w < B.nwindows && !(B.pregen && ((B.pregen[w>>5] >> (w&31)) & 1)) )
+	{
+		cls = classifyWindow(B,w,t0inst);
+		B.wout[w].status = WS_INSUFFICIENT;      // never WS_RETRY from an earlier batch: the tiers resume from a hand-over record
+	}
+	uint32_t tot0, tot1;
+	uint32_t const p0 = block_scan_excl<false>(cls == 0 ? 1u : 0u,part4,tot0);
+	__syncthreads();
+	uint32_t const p1 = block_scan_excl<false>(cls == 1 ? 1u : 0u,part4,tot1);
+	if ( threadIdx.x == 0 ) { base2[0] = tot0 ? atomicAdd(small,tot0) : 0u; base2[1] = tot1 ? atomicAdd(big,tot1) : 0u; }
+	__syncthreads();
+	if ( cls == 0 ) small[1+base2[0]+p0] = static_cast<uint32_t>(w);
+	if ( cls == 1 ) big[1+base2[1]+p1] = static_cast<uint32_t>(w);
+}
+
+
 // one workgroup per pile.  The pile is walked in tiles of 256 positions (thread = position); the records of the windows
 // that cover a tile (256/a + w/a + 2 of them, 256 B each) are staged in LDS once per pass, coalesced, so that the
 // byte-wise reads of the vote hit LDS and every record leaves HBM once per pass.
@@ -423,10 +447,11 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
+	int64_t long_hint;      // windows the second stream ran in the last pass of this context (-1: unknown): grid of k_window_long
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
-	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1;     // debugging knobs, read once in dacc_create
+	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_t0inst;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<int32_t> pile_status; std::vector<std::string> pile_errors; std::string pile_errors_joined;
@@ -459,13 +484,14 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	if ( hipSetDevice(p->device) != hipSuccess ) return DACC_ENODEV;
 	dacc_ctx * c = new (std::nothrow) dacc_ctx;
 	if ( !c ) return DACC_ENOMEM;
-	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0;
+	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->long_hint = -1;
 	std::memset(&c->timing,0,sizeof(c->timing));
 	{
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
-		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 7;      // bit t enables LDS tier t+1
+		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 15;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes)
 		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
+		char const * t0 = getenv("DACC_T0INST"); c->env_t0inst = t0 ? static_cast<uint32_t>(atoi(t0)) : static_cast<uint32_t>(T0INST_DEFAULT);      // size-class threshold (k-mer instances) of tier 0
 		char const * dr = getenv("DACC_DEBUG_RETRY"); c->env_dbgretry = (dr && dr[0] == '1');
 	}
 	if ( hipStreamCreate(&c->stream) != hipSuccess ) { delete c; return DACC_EHIP; }
@@ -486,7 +512,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release();
+	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
 	delete c;
@@ -630,6 +656,15 @@ static int runDevice(dacc_ctx * c)
 					FB.gearly = early ? static_cast<uint32_t *>(0) : c->d_gearly.p;
 					uint32_t * const work = (c->sched&1) ? c->d_work.p+8*t : static_cast<uint32_t *>(0);
 					if ( t == 0 && BP.deep ) hipLaunchKernelGGL(k_window_fast<4>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( t == 0 && c->tier0_ok )
+					{
+						// size classes: the small windows run in tier 0 (8 wavefronts per CU), its hand-overs and all other windows in tier 1
+						HIPCHK(hipMemsetAsync(c->d_small.p,0,sizeof(uint32_t),s)); HIPCHK(hipMemsetAsync(c->d_big.p,0,sizeof(uint32_t),s));
+						hipLaunchKernelGGL(k_classify,dim3((BP.nwindows+255)/256),dim3(256),0,s,WB,c->d_small.p,c->d_big.p,c->env_t0inst);
+						FastBatch F0 = FB; F0.F = BP.ftier0; F0.retry = c->d_big.p; F0.gstride = c->gstride0;
+						hipLaunchKernelGGL(k_window_fast<0>,dim3(c->tier0_grid),dim3(64),F0.F.ldsbytes,s,F0,static_cast<uint32_t const *>(c->d_small.p),(c->sched&1) ? c->d_work.p+40 : static_cast<uint32_t *>(0));
+						hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,static_cast<uint32_t const *>(c->d_big.p),work);
+					}
 					else if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 && BP.deep ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<6>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
@@ -698,6 +733,13 @@ static int runDevice(dacc_ctx * c)
 	{ int const rc = voteAndFetch(); if ( rc ) return rc; }
 	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpy(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+	if ( c->usefast && BP.nwindows && (c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2]) )
+	{
+		// length of the two lists of the second stream (pre-scan, first tier's generic-only windows): grid of the next pass
+		uint32_t n1 = 0, n2 = 0;
+		HIPCHK(hipMemcpy(&n1,c->d_pregenlist.p,sizeof(uint32_t),hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&n2,c->d_gearly.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+		c->long_hint = std::max(n1,n2); c->timing.long_windows = n1 + n2;
+	}
 	// a window the generic engine could not hold (dense graph at small k): grow its scratch capacities and run those
 	// windows again, then the vote (rare; the capacities stay grown for the rest of the batch geometry)
 	for ( int attempt = 0; herr[0] && !herr[1] && !herr[2] && attempt < 3; ++attempt )
@@ -756,7 +798,7 @@ static int runDevice(dacc_ctx * c)
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
-	c->timing.first_tier = (c->usefast && BP.deep) ? 4u : 1u; c->timing.long_windows = 0;
+	c->timing.first_tier = (c->usefast && BP.deep) ? 4u : 1u;
 	c->timing.nwindows = BP.nwindows; c->timing.nblocks = BP.nblocks; c->timing.algo_bytes = BP.algo_bytes + nbases;
 	return DACC_OK;
 }
@@ -847,6 +889,19 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			// gw tiers: one global slab per workgroup (weights, spill); the tiers run one after the other and share the buffer
 			c->gstride[t] = F.gbytes;
 			if ( F.gbytes ) HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg)*F.gbytes + 256));
+		}
+		{
+			// tier 0 (size classes) in front of tier 1 of a shallow batch: DACC_TIERS bit 3 switches it off
+			FastCaps const & F0 = BP.ftier0;
+			c->tier0_ok = !BP.deep && c->tier_ok[0] && ((c->env_tiers>>3)&1) && F0.ldsbytes <= 160*1024;
+			uint64_t percu0 = (160*1024) / (F0.ldsbytes ? F0.ldsbytes : 1); if ( percu0 > 8 ) percu0 = 8; if ( percu0 < 1 ) percu0 = 1;
+			uint64_t fg0 = ((BP.nwindows+7)/8)*8; if ( fg0 > 256*percu0 ) fg0 = 256*percu0; if ( fg0 < 8 ) fg0 = 8;
+			c->tier0_grid = static_cast<uint32_t>(fg0); c->gstride0 = F0.gbytes;
+			if ( c->tier0_ok )
+			{
+				HIPCHK(c->d_small.ensure(BP.nwindows+2)); HIPCHK(c->d_big.ensure(BP.nwindows+2));
+				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg0)*F0.gbytes + 256));
+			}
 		}
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);

@@ -78,6 +78,11 @@ template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 #else
 template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96 }; };
 #endif
+// tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
+// instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
+template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 640, ncap = 416, scap = 88, lcap = 512, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96 }; };
+enum : uint32_t { T0INST_DEFAULT = 488 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
+                                               // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 #if defined(DACC_T2_LEGACY)
 template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 880, scap = 232, lcap = 1024, wcap = 992, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
@@ -332,7 +337,8 @@ struct FastLds<CT,true>
 {
 	LDSQ uint8_t * base;
 	static constexpr uint32_t keycap = fcpow2(CT::maxs < 2 ? 2 : CT::maxs);
-	static_assert((CT::precap & (CT::precap-1)) == 0,"precap must be a power of two: the bitonic sorts pad to one");
+	// (precap need not be a power of two in this layout: the sorts touch only the n keys there are; the padding of the overlap
+	// sort at the start of a window is checked against it)
 	static_assert(sizeof(typename CT::id_t) > 1 || (CT::fcap <= 256 && CT::rccap <= 256),"pool slots are recorded as id_t (pout)");
 	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
 	static_assert(CT::lstr == 64,"the gw layout holds strings of up to 64 bases");
@@ -3129,6 +3135,32 @@ struct FastEngine
 
 // returns FW_DONE, FW_NEXT (does not fit this tier's capacities) or FW_GENERIC (shape no LDS tier supports)
 enum { FW_DONE = 0, FW_NEXT = 1, FW_GENERIC = 2 };
+// Size class of a window (pre-pass of shallow batches): 0 = small (starts in tier 0), 1 = the rest (starts in tier 1).  An
+// upper bound of the number of k-mer instances at the smallest k from the window tables: every active overlap counts (the
+// window may keep fewer, `maxalign`), so a window classed small can still overflow tier 0 and is then handed on like any other.
+DEV uint32_t classifyWindow(WindowBatch const & B, uint64_t const widx, uint32_t const t0inst)
+{
+	uint32_t lo = 0, hi = B.npiles;
+	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
+	DevPile const pile = B.piles[lo];
+	uint32_t const y = static_cast<uint32_t>(widx - pile.winbase);
+	uint32_t astart, aend;
+	windowInterval(pile.l,B.P.a,B.P.w,y,astart,aend);
+	uint32_t const k = B.P.klow;
+	uint32_t nact = 0, inst = B.P.w >= k ? (B.P.w - k + 1) : 0u;
+	DevOvl const * ov = B.ovl + pile.first_ovl;
+	for ( uint32_t z = 0; z < pile.novl; ++z )
+		if ( ov[z].abpos <= static_cast<int32_t>(astart) && ov[z].aepos >= static_cast<int32_t>(aend) )
+		{
+			uint64_t const row = ov[z].wtoff + (y - ov[z].y0);
+			uint32_t const len = B.wt_e[row] - B.wt_b[row];
+			++nact; inst += len >= k ? (len - k + 1) : 0u;
+		}
+	uint64_t const nb = (B.P.maxalign > 0) ? (B.P.maxalign-1) : 0;
+	uint32_t const mao = 1 + static_cast<uint32_t>(nact < nb ? nact : nb);
+	return (mao <= FastTier<0>::maxs && inst <= t0inst && B.P.w <= 63) ? 0u : 1u;
+}
+
 template<typename CT>
 DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_t * lds, bool const resume = false)
 {
@@ -3193,7 +3225,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 		if ( act && nact+pre < CT::precap ) L.pre()[nact+pre] = (static_cast<uint64_t>(ov[z].ekey)<<32) | z;
 		nact += tot;
 	}
-	if ( nact > CT::precap ) { FFAIL(2) }
+	if ( nact > CT::precap || next_pow2(nact < 2 ? 2 : nact) > CT::precap ) { FFAIL(2) }      // (the padding below needs the next power of two to fit)
 	uint32_t const ap2 = next_pow2(nact < 2 ? 2 : nact);
 	for ( uint32_t i = nact + lane; i < ap2; i += WSZ ) L.pre()[i] = ~0ull;
 	wv_sync();

@@ -168,7 +168,7 @@ typedef struct dacc_timing {
 	float tier_ms[3];        /* LDS capacity tiers of the window kernel (3, 2, 1 wavefronts per CU); window_ms = all + generic */
 	uint32_t tier_out[3];    /* windows each tier handed on (tier_out[2] = windows run by the generic engine) */
 	uint32_t first_tier;     /* kernel of the first slot: 1 = k_window_fast<1>, 4 = k_window_fast<4> (batch of deep piles) */
-	uint32_t long_windows;   /* reserved (0) */
+	uint32_t long_windows;   /* windows the second stream ran (a string of more than 64 bases, or a shape no LDS tier takes) */
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 

@@ -1,0 +1,109 @@
+"""ORACLE SUPPORT python wrapper (test infrastructure): drives oracle/_ref/libdaccord_ref*.so = the REFERENCE'S OWN hot-path
+headers compiled against the libmaus2 stand-in (oracle/ref_shim/).  Only tests/ and scripts that validate the oracle import
+this; the product package never does.  The library is built in the build container (where /root/reference exists) and travels
+to the GPU box as a built file."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from daccord_amd._structs import (DaccParams, DaccFragment)  # noqa: E402
+
+_DIR = os.path.join(_HERE, "_ref")
+_SRCS = [os.path.join(_HERE, "ref_shim", f) for f in ("ref_capi.cpp", "build.sh", "libmaus2/shim.hpp", "k16/DebruijnGraphContainer.hpp")]
+
+
+def so_path(k16=False):
+    return os.path.join(_DIR, "libdaccord_ref_k16.so" if k16 else "libdaccord_ref.so")
+
+
+def reference_present():
+    return os.path.exists(os.path.join(os.environ.get("DACC_REFERENCE", "/root/reference"), "src", "HandleContext.hpp"))
+
+
+def build(force=False):
+    """(Re)build oracle/_ref when /root/reference is present; a no-op elsewhere (the GPU box uses the prebuilt files)."""
+    if not reference_present():
+        return None
+    so = so_path(False)
+    if force or not os.path.exists(so) or not os.path.exists(so_path(True)) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in _SRCS):
+        subprocess.check_call(["bash", os.path.join(_HERE, "ref_shim", "build.sh")], stdout=subprocess.DEVNULL)
+    return so
+
+
+def available(k16=False):
+    return os.path.exists(so_path(k16))
+
+
+_libs = {}
+
+
+def lib(k16=False):
+    if k16 not in _libs:
+        build()
+        L = C.CDLL(so_path(k16))
+        L.ref_create.restype = C.c_void_p
+        L.ref_create.argtypes = [C.POINTER(DaccParams)]
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_error.restype = C.c_char_p; L.ref_error.argtypes = [C.c_void_p]
+        L.ref_log.restype = C.c_char_p; L.ref_log.argtypes = [C.c_void_p]
+        L.ref_set_error_profile.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+        L.ref_load_db.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.ref_run_piles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
+        L.ref_collect.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ref_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        _libs[k16] = L
+    return _libs[k16]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Reference:
+    """Same call sequence as pyoracle.Oracle; k above 12 needs the k16 build (our factory, the reference's graph template)."""
+
+    def __init__(self, params):
+        self.k16 = params.khigh > 12
+        self.L = lib(self.k16)
+        self.h = self.L.ref_create(C.byref(params))
+        if not self.h:
+            raise ValueError("ref_create failed (bad parameters)")
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_destroy(self.h); self.h = None
+
+    def set_error_profile(self, p_i, p_d, est_cor):
+        if self.L.ref_set_error_profile(self.h, p_i, p_d, est_cor):
+            raise RuntimeError(self.L.ref_error(self.h).decode())
+
+    def load_db(self, bps, boff, rlen):
+        self._keep = [np.ascontiguousarray(bps), np.ascontiguousarray(boff), np.ascontiguousarray(rlen)]
+        self.L.ref_load_db(self.h, _ptr(self._keep[0]), len(bps), _ptr(self._keep[1]), _ptr(self._keep[2]), len(rlen))
+
+    def run(self, piles, ovl, trace, trace_bytes=1, nthreads=1, verbose=0):
+        piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
+        rc = self.L.ref_run_piles(self.h, _ptr(piles), len(piles), _ptr(ovl), len(ovl), _ptr(trace), len(trace), trace_bytes, nthreads, verbose)
+        if rc:
+            raise RuntimeError("ref_run_piles rc=%d %s" % (rc, self.L.ref_error(self.h).decode()))
+        fr = C.c_void_p(); nf = C.c_uint64(); ba = C.c_void_p(); nb = C.c_uint64()
+        self.L.ref_collect(self.h, C.byref(fr), C.byref(nf), C.byref(ba), C.byref(nb))
+        frags = np.frombuffer((C.c_char * (nf.value * C.sizeof(DaccFragment))).from_address(fr.value),
+                              dtype=np.dtype(DaccFragment)).copy() if nf.value else np.zeros(0, np.dtype(DaccFragment))
+        bases = C.string_at(ba.value, nb.value) if nb.value else b""
+        return frags, bases
+
+    def log(self):
+        return self.L.ref_log(self.h).decode()
+
+    def tables(self, klimit_n=128):
+        n = C.c_uint64()
+        self.L.ref_tables(self.h, None, 0, C.byref(n), klimit_n)
+        out = np.zeros(n.value, dtype=np.uint64)
+        self.L.ref_tables(self.h, _ptr(out), n.value, C.byref(n), klimit_n)
+        return out

@@ -1,0 +1,18 @@
+#!/bin/bash
+# ORACLE SUPPORT (test infrastructure): compiles the reference's own hot-path headers, where they lie under /root/reference/src
+# and unmodified, against the libmaus2 stand-in of this directory (libmaus2/shim.hpp) into oracle/_ref/ (git-ignored; the built
+# libraries travel to the GPU box with the snapshot, the reference sources do not and are never copied into the repository).
+#   oracle/_ref/libdaccord_ref.so      the reference's DebruijnGraphContainer: k in [3,12] as shipped
+#   oracle/_ref/libdaccord_ref_k16.so  the same sources with OUR factory (k16/DebruijnGraphContainer.hpp) so that DebruijnGraph<13..16> exist
+# -ffp-contract=off: the path compares FP64 weights exactly.  No-op (exit 0) where /root/reference is absent.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${DACC_REFERENCE:-/root/reference}/src"
+OUT="$HERE/../_ref"
+if [ ! -f "$REF/HandleContext.hpp" ]; then echo "ref_shim/build.sh: $REF not present, nothing built"; exit 0; fi
+mkdir -p "$OUT"
+FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w"
+g++ $FLAGS -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref.so" "$HERE/ref_capi.cpp" &
+g++ $FLAGS -DDACC_REF_K16 -I"$HERE/k16" -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref_k16.so" "$HERE/ref_capi.cpp" &
+wait
+ls -la "$OUT"

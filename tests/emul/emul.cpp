@@ -29,7 +29,7 @@ struct EmulCtx
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<dacc_window_result> windows;
 	std::string err;
-	bool usefast; uint64_t ntier[3], nretry, nlong;
+	bool usefast; uint64_t ntier[3], nretry, nlong, ntier0;
 	std::vector<uint64_t> glist;   // windows that went to the generic engine: index, flags of the last tier
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
@@ -48,15 +48,16 @@ static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 
 extern "C" {
 
-void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; return c; }
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; c->ntier0 = 0; return c; }
 void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
 void emul_reasons_tier(void * v, int t, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasonsT[t][i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbitsT[t][i]; }
 void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,1,r,fb); }
 void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,0,r,fb); }
-void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
+void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier0+c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
 uint64_t emul_generic_list(void * v, uint64_t * out, uint64_t cap) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( uint64_t i = 0; i < c->glist.size() && i < cap; ++i ) out[i] = c->glist[i]; return c->glist.size(); }
 uint64_t emul_count_long(void * v) { return static_cast<EmulCtx *>(v)->nlong; }
 void emul_counts4(void * v, uint64_t * n) { EmulCtx * c = static_cast<EmulCtx *>(v); n[0] = c->ntier[0]; n[1] = c->ntier[1]; n[2] = c->ntier[2]; n[3] = c->nretry; }
+uint64_t emul_count_tier0(void * v) { return static_cast<EmulCtx *>(v)->ntier0; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
 
@@ -148,8 +149,8 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
 		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data(); WB.prof = 0; WB.pregen = 0;
-		FastBatch FB[3];
-		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3];
+		FastBatch FB[3]; FastBatch FB0;
+		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3]; std::vector<uint8_t> lds0, gslab0;
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
 		bool tierok[3];
@@ -179,6 +180,16 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
 		c->nretry = 0; c->glist.clear();
+		// tier 0 (size classes) in front of tier 1 of a shallow batch, as in the library (DACC_TIERS bit 3 switches it off)
+		bool const tier0ok = !BP.deep && tierok[0] && !(getenv("DACC_TIERS") && !((atoi(getenv("DACC_TIERS"))>>3)&1));
+		c->ntier0 = 0;
+		if ( tier0ok )
+		{
+			FB0.W = WB; FB0.F = BP.ftier0; FB0.dpsq_vst = c->H.dpsq_vst.data(); FB0.retry = 0; FB0.gearly = 0;
+			gslab0.assign(BP.ftier0.gbytes+64,0); FB0.gslab = gslab0.data(); FB0.gstride = 0; FB0.tab32 = c->H.tab32.data();
+			lds0.resize(BP.ftier0.ldsbytes+64);
+			wave_run([&]() { FastLds< FastTier<0> > L; L.base = lds0.data(); fast_load_tables(L,BP.ftier0.nrows,BP.ftier0.nsup,T,c->H.dpsq_vst.data()); });
+		}
 		auto loadTables = [&](int const t)
 		{
 			wave_run([&]() {
@@ -221,6 +232,29 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		{
 			if ( !tierok[t] ) continue;
 			next.clear();
+			if ( t == 0 && tier0ok )
+			{
+				// k_classify + k_window_fast<0>: the small windows first; tier 1 then runs the big list followed by tier 0's hand-overs
+				std::vector<uint64_t> small, big;
+				uint32_t const t0inst = getenv("DACC_T0INST") ? static_cast<uint32_t>(atoi(getenv("DACC_T0INST"))) : static_cast<uint32_t>(T0INST_DEFAULT);
+				for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
+				{
+					if ( WB.pregen && ((WB.pregen[wdx>>5] >> (wdx&31)) & 1) ) continue;
+					uint32_t cls = 0; wave_run([&]() { uint32_t const r = classifyWindow(WB,wdx,t0inst); if ( wv_lane() == 0 ) cls = r; });
+					wout[wdx].status = WS_INSUFFICIENT;
+					(cls == 0 ? small : big).push_back(wdx);
+				}
+				for ( size_t i = 0; i < small.size(); ++i )
+				{
+					uint64_t const wdx = small[i];
+					if ( getenv("DACC_EMUL_POISON") ) { std::memset(lds0.data(),atoi(getenv("DACC_EMUL_POISON")),lds0.size()); std::memset(gslab0.data(),atoi(getenv("DACC_EMUL_POISON")),gslab0.size()); wave_run([&]() { FastLds< FastTier<0> > L; L.base = lds0.data(); fast_load_tables(L,BP.ftier0.nrows,BP.ftier0.nsup,T,c->H.dpsq_vst.data()); }); }
+					int rc = -1;
+					wave_run([&]() { int const r = processWindowFast< FastTier<0> >(FB0,wdx,lds0.data(),true); if ( wv_lane() == 0 ) rc = r; });
+					if ( rc == FW_DONE ) { ++c->ntier0; continue; }
+					if ( rc == FW_GENERIC ) gearly.push_back(wdx); else big.push_back(wdx);
+				}
+				cur.swap(big); haveList = true;
+			}
 			uint64_t const n = haveList ? cur.size() : BP.nwindows;
 			for ( uint64_t i = 0; i < n; ++i )
 			{

@@ -14,6 +14,11 @@ CASES = {
     "cfg2s": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
                   pile_ranges=[[0, 62]] + [[1250 * q - 62, 1250 * q + 63] for q in range(1, 8)] + [[9875, 10000]],
                   params=[dict(k=14)]),
+    # config 2, a second stratified sample (round 4): 125 piles from the MIDDLE of each of the eight per-XCD queue ranges
+    # (cfg2s sits on their boundaries, cfg2 on the first 1000) -- another 1000 piles of the headline batch against the oracle
+    "cfg2t": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
+                  pile_ranges=[[1250 * q + 562, 1250 * q + 687] for q in range(8)],
+                  params=[dict(k=14)]),
     # config 3 stand-in (D. melanogaster 20x is 140 Mbase; the files are not in the container): a 100-pile slice of a 20x set
     # with a larger genome and longer reads than config 2
     "cfg3": dict(genome_len=7000000, nreads=10000, read_len=14000, seed=7, synth={}, first=4000, npiles=100,
