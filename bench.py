@@ -4,7 +4,7 @@
 One "step" = one pass of the hot path (trace expansion -> per-window consensus -> pile vote ->
 fragments on the host) over one batch of synthetic piles that is already resident in HBM when the
 timed region starts.  Workload at N=1 = BASELINE.json configs[1]: synthetic 10k A-reads x 10 kb x 20x
-PacBio-like piles, k=14.
+PacBio-like piles, k=14 (the other configs are parity cases: tests/test_gpu_scale.py).
 
 Multi-GPU: ONE data set, sharded over the ranks by A-read range exactly like the reference's
 `-J g,G` option (src/daccord.cpp:1156-1183, daccord_amd/shard.py); piles are independent, so there is no
@@ -19,8 +19,11 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
                  traffic and issue-slot counters of the same kernel from the committed PMC passes (profiles/)
   cpu_baseline : the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores on a
                  bounded sample of the same piles, single thread and all cores (N=1, rank 0 only)
-  parity       : SHA-256 of the GPU FASTA of the first 1000 piles against the oracle's committed digest
-                 (tests/golden/scale_cfg2.json, default workload only) and the live oracle sample
+  parity       : SHA-256 of the GPU FASTA of every committed stratum of the batch (tests/golden/scale_cfg2*.json: the first
+                 1000 piles, the boundaries and the middles of the eight per-XCD queue ranges) against the digests the oracle
+                 produced in the build container (default workload only), the full-batch digest, and the live CPU samples
+  value_incl_plan_h2d : the same rate over the FIRST pass, which includes the host plan and the upload of piles / overlaps /
+                 trace points ("piles in host RAM" to fragments); `value` is the resident-batch rate the contract asks for
 """
 import argparse
 import hashlib
@@ -125,7 +128,7 @@ def main():
         E.rerun()
         fr, ba = E.collect()
         # the only communication of a step: corrected fragments of all ranks to rank 0 (RCCL gather; no-op at N=1)
-        gathered[0], gathered[1] = shard.gather_fragments(fr, ba, device=gdev)
+        gathered[0], gathered[1] = shard.gather_fragments(fr, ba)      # message buffers where the backend needs them (device for RCCL, host arrays for gloo)
 
     for _ in range(args.warmup):
         step()
@@ -133,25 +136,25 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    wsum = tsum = vsum = 0.0
+    wsum = tsum = vsum = t0sum = 0.0
     tsums = [0.0, 0.0, 0.0]
     touts = [0, 0, 0]
     for _ in range(args.steps):
         step()
         t = E.timing()
-        wsum += t.window_ms; tsum += t.trace_ms; vsum += t.vote_ms
+        wsum += t.window_ms; tsum += t.trace_ms; vsum += t.vote_ms; t0sum += float(getattr(t, "tier0_ms", 0.0))
         for i in range(3):
             tsums[i] += t.tier_ms[i]; touts[i] = int(t.tier_out[i])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=gdev)
+    tmax = torch.tensor([dt, tfirst], dtype=torch.float64, device=gdev)
     nb = torch.tensor([float(len(bases))], dtype=torch.float64, device=gdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nb, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
+    dt = float(tmax[0].item()); tfirst_max = float(tmax[1].item())
     total_bases = float(nb.item())
 
     if rank == 0:
@@ -160,10 +163,16 @@ def main():
         assert float(len(allba)) == total_bases, "gathered bases do not add up"
         ms_per_step = 1e3 * dt / args.steps
         value = total_bases * args.steps / dt / 1e6
-        first_kernel = "k_window_fast<4>" if int(getattr(t, "first_tier", 1)) == 4 else "k_window_fast<1>"   # deep batches start in tier 4
+        # slots of the window kernels: shallow batches run k_classify + k_window_fast<0> (size classes) and k_window_fast<1> in
+        # the first slot and k_window_fast<6> in the second; batches of deep piles k_window_fast<4> and k_window_fast<2>
+        deep = int(getattr(t, "first_tier", 1)) == 4
+        first_kernel = "k_window_fast<4>" if deep else "k_window_fast<1>"
+        second_kernel = "k_window_fast<2>" if deep else "k_window_fast<6>"
         kern = {"k_trace": tsum / args.steps, "k_vote": vsum / args.steps,
-                first_kernel: tsums[0] / args.steps, "k_window_fast<2>": tsums[1] / args.steps,
+                first_kernel: (tsums[0] - t0sum) / args.steps, second_kernel: tsums[1] / args.steps,
                 "k_window_fast<3>": tsums[2] / args.steps, "k_window": (wsum - sum(tsums)) / args.steps}
+        if t0sum > 0:
+            kern["k_classify+k_window_fast<0>"] = t0sum / args.steps
         dom = max(kern, key=kern.get)
         # algorithmic bytes (every input byte once + corrected bases) of the launch / its duration
         achieved = t.algo_bytes / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
@@ -171,7 +180,9 @@ def main():
                 "frac": round(achieved / 8000.0, 7), "traffic": None,
                 "algo_bytes_per_launch": int(t.algo_bytes), "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
                 "window_ms_all_tiers": round(wsum / args.steps, 3),
-                "windows_handed_on": {"tier1": touts[0], "tier2": touts[1], "tier3_to_generic": touts[2]}}
+                "windows_handed_on": {first_kernel: touts[0], second_kernel: touts[1], "k_window_fast<3>_to_generic": touts[2]},
+                "size_classes": {"windows_sent_to_tier0": int(getattr(t, "tier0_in", 0)), "handed_on_by_tier0": int(getattr(t, "tier0_out", 0))},
+                "windows_on_second_stream": int(getattr(t, "long_windows", 0))}
         # HBM traffic and issue counters of the dominant kernel from the PMC passes (rocprofv3 --pmc, separate runs,
         # scripts/gpu_pmc.sh -> profiles/<round>_pmc_summary.json): quoted only when they were collected on this very
         # workload AND on the very kernel sources this build was made from (csrc_hash) -- never stale counters
@@ -189,8 +200,16 @@ def main():
                 for key in ("valu_issue_frac", "salu_issue_frac", "lds_issue_frac", "wait_frac", "resident_waves_per_cu", "pmc_kernel_ms"):
                     if key in kk:
                         roof[key] = kk[key]
+                dg = kk.get("diagnostics", {})
+                for key in ("valu_lane_util", "inflight_share", "tcc_hit_rate", "tcp_tcc_read_latency_cycles", "active_scalar_frac", "lds_bank_conflict"):
+                    if key in dg:
+                        roof[key] = dg[key]
+                roof["resident_waves_per_cu_by_kernel"] = {k: v.get("resident_waves_per_cu") for k, v in pm["kernels"].items() if v.get("resident_waves_per_cu")}
                 roof["traffic_all_kernels"] = {k: int(v["traffic_bytes_per_launch"]) for k, v in pm["kernels"].items()}
-                roof["pmc_source"] = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this workload, csrc %s)" % (os.path.basename(fn), cur)
+                roof["pmc_source"] = ("NOT measured in this run: constants read from profiles/%s, collected by scripts/gpu_pmc.sh (separate rocprofv3 --pmc "
+                                      "passes, traffic = 2*FETCH_SIZE + WRITE_SIZE) on this workload and on the very device sources of this build (csrc %s); "
+                                      "lane utilisation / in-flight shares / L2 hit rate from a %s-read slice of the same workload"
+                                      % (os.path.basename(fn), cur, pm.get("diagnostics_workload_reads", "?")))
                 break
             else:
                 roof["pmc_source"] = "none for this build (csrc %s): traffic is null until scripts/gpu_pmc.sh has run on it" % cur
@@ -201,15 +220,19 @@ def main():
             "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "value_incl_plan_h2d": round(total_bases / max(tfirst_max, 1e-9) / 1e6, 3),
+            "gather": (shard.last_transport if world > 1 else None),
             "dtype": "u64+f64", "data": "synthetic",
-            "config": {"workload": "synthetic %d A-reads x %d b x %.0fx%s, 15%% error (%s), k=%d, w=40, a=10, tspace=100"
-                       % (total_reads, args.readlen, args.coverage, " (%d per GPU)" % args.reads if args.scaling == "weak" and world > 1 else "",
+            "config": {"workload": "%ssynthetic %d A-reads x %d b x %.0fx%s, 15%% error (%s), k=%d, w=40, a=10, tspace=100"
+                       % (("BASELINE.json configs[1] (10k A-reads x 10 kb x 20x, k=14, one MI355X%s): " % (" per rank, weak scaling" if world > 1 else ""))
+                          if (args.reads, args.readlen, args.coverage, args.k, args.ont) == (10000, 10000, 20.0, 14, False) and (world == 1 or args.scaling == "weak") else "",
+                          total_reads, args.readlen, args.coverage, " (%d per GPU)" % args.reads if args.scaling == "weak" and world > 1 else "",
                           "ins/del/sub 1/3 each" if args.ont else "ins 80/del 13.3/sub 6.7", args.k),
                        "piles_total": int(npiles_total), "piles_rank0": int(len(piles)), "overlaps_rank0": int(len(ovl)), "windows_rank0": int(t.nwindows),
                        "trace_blocks_rank0": int(t.nblocks), "corrected_bases_total": int(total_bases),
                        "sharding": "one data set, A-read ranges as -J g,G (daccord.cpp:1156-1183), no data-path collective; RCCL gather of corrected fragments per step"},
             "roofline": roof,
-            "setup_s": {"generate": round(tgen, 2), "first_pass_incl_h2d": round(tfirst, 2), "h2d_ms": round(tm0.h2d_ms, 2)},
+            "setup_s": {"generate": round(tgen, 2), "first_pass_incl_plan_h2d": round(tfirst_max, 2), "h2d_ms": round(tm0.h2d_ms, 2)},
         }
         # ---- parity: full-batch digest, the oracle's committed digest of the first 1000 piles, live oracle sample ----
         def fasta_sha256(fr, ba):
@@ -245,10 +268,11 @@ def main():
                 out["piles_that_differ"] = bad[:50]
             return out
         if default_set:
-            cmp_ = [c for c in (compare_golden("cfg2s"), compare_golden("cfg2")) if c]
+            cmp_ = [c for c in (compare_golden("cfg2s"), compare_golden("cfg2t"), compare_golden("cfg2")) if c]
             if cmp_:
                 par.update({"piles_compared": int(sum(c["piles_compared"] for c in cmp_)), "identical": all(c["identical"] for c in cmp_), "fixtures": cmp_,
-                            "oracle_source": "oracle run in the build container (tests/golden/make_golden_scale.py); stratified over all eight queue ranges of the batch"})
+                            "oracle_source": "oracle run in the build container (tests/golden/make_golden_scale.py): the first 1000 piles, the boundaries and the middles of all eight queue ranges of the batch; "
+                                             "the oracle itself is pinned to the reference's own sources (oracle/_ref, tests/test_oracle_vs_ref.py)"})
         res["parity"] = par
         # ---- accuracy against the known truth of the synthetic reads (checkconsensus measurement, README.md:406-472):
         # the only quality figure that does not depend on the oracle ----
@@ -265,6 +289,7 @@ def main():
         if world == 1 and not args.no_cpu:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import pyoracle
+            pyref_fasta = pyoracle.fasta
             O = pyoracle.Oracle(p)
             O.set_error_profile(*d.error_profile())
             O.load_db(d.bps, d.boff, d.rlen)
@@ -353,6 +378,33 @@ def main():
                     "identical_to_gpu_on_sample": bool(same), "gpu_over_this": round(value / max(lb / tl / 1e6, 1e-12), 1)}
             except Exception as ex:
                 res["cpu_baseline"]["like_for_like"] = {"error": repr(ex)[:200]}
+            # the reference's OWN sources (oracle/_ref: /root/reference/src headers compiled in the build container against the
+            # libmaus2 stand-in, oracle/ref_shim/; the built library travels, the sources do not) on the same host cores, bounded
+            # sample: the CPU figure closest to "reference daccord on this box" that exists without libmaus2.  Its primitives
+            # (aligner, heaps, rank / RMQ structures) are plain stand-ins, slower than libmaus2's SIMD code, so the ratio flatters
+            # the GPU even more than the oracle's does; what it adds is that the GPU output equals the REFERENCE SOURCE's here.
+            try:
+                import pyref
+                if pyref.available(k16=(args.k > 12)):
+                    R = pyref.Reference(p)
+                    R.set_error_profile(*d.error_profile()); R.load_db(d.bps, d.boff, d.rlen)
+                    rthr = max(1, min(nthr, 16 if args.k <= 14 else 2))      # a DebruijnGraph<k> of the reference holds 4^k int32 per thread
+                    nrp = min(len(piles) - first, rthr)
+                    tc = time.perf_counter()
+                    fr_, br_ = R.run(piles[first:first + nrp], ovl, d.trace, nthreads=rthr)
+                    tr_ = time.perf_counter() - tc
+                    lo_, hi_ = int(piles[first]["aread"]), int(piles[first + nrp - 1]["aread"])
+                    gs_ = frags[(frags["aread"] >= lo_) & (frags["aread"] <= hi_)]
+                    res["cpu_baseline"]["reference_build"] = {
+                        "value": round(len(br_) / tr_ / 1e6, 5), "unit": "Mbase/s", "cores": rthr, "kind": "reference",
+                        "what": "src/HandleContext.hpp + DebruijnGraph.hpp + OffsetLikely.hpp ... of the reference, unmodified, on the libmaus2 stand-in (oracle/_ref%s)"
+                                % (", k <= 16 factory" if args.k > 12 else ""),
+                        "sample": "piles %d..%d of the same batch, %.1f s" % (first, first + nrp - 1, tr_),
+                        "identical_to_gpu_on_sample": bool(engine.fasta(gs_, bases) == pyref_fasta(fr_, br_))}
+                else:
+                    res["cpu_baseline"]["reference_build"] = {"error": "oracle/_ref not built (needs /root/reference at build time)"}
+            except Exception as ex:
+                res["cpu_baseline"]["reference_build"] = {"error": repr(ex)[:200]}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

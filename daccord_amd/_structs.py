@@ -34,7 +34,8 @@ class DaccTiming(C.Structure):
     _fields_ = [("h2d_ms", C.c_float), ("trace_ms", C.c_float), ("window_ms", C.c_float), ("vote_ms", C.c_float),
                 ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("nwindows", C.c_uint64), ("nblocks", C.c_uint64),
                 ("algo_bytes", C.c_uint64), ("tier_ms", C.c_float * 3), ("tier_out", C.c_uint32 * 3),
-                ("first_tier", C.c_uint32), ("long_windows", C.c_uint32)]
+                ("first_tier", C.c_uint32), ("long_windows", C.c_uint32), ("tier0_ms", C.c_float), ("tier0_in", C.c_uint32),
+                ("tier0_out", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class DaccWindowResult(C.Structure):

@@ -412,17 +412,23 @@ struct DevBuf
 template<typename T>
 struct HostBuf
 {
-	T * p; size_t cap;
-	HostBuf() : p(0), cap(0) {}
+	T * p; size_t cap; bool pinned;
+	HostBuf() : p(0), cap(0), pinned(false) {}
+	// pinned memory (the device-to-host copy of the symbol stream runs at link speed into it); where the process may not lock
+	// that much memory (memlock limit) a pageable buffer does the same job through the runtime's staging copy
 	hipError_t ensure(size_t n)
 	{
 		if ( n <= cap ) return hipSuccess;
-		if ( p ) { hipHostFree(p); p = 0; cap = 0; }
-		hipError_t const e = hipHostMalloc(reinterpret_cast<void **>(&p),n*sizeof(T),hipHostMallocDefault);
-		if ( e == hipSuccess ) cap = n;
-		return e;
+		release();
+		hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&p),n*sizeof(T),hipHostMallocDefault);
+		if ( e == hipSuccess ) { cap = n; pinned = true; return e; }
+		(void)hipGetLastError();
+		p = static_cast<T *>(std::malloc(n*sizeof(T)));
+		if ( !p ) return hipErrorOutOfMemory;
+		cap = n; pinned = false;
+		return hipSuccess;
 	}
-	void release() { if ( p ) hipHostFree(p); p = 0; cap = 0; }
+	void release() { if ( p ) { if ( pinned ) hipHostFree(p); else std::free(p); } p = 0; cap = 0; pinned = false; }
 };
 
 }
@@ -432,7 +438,7 @@ struct dacc_ctx
 	dacc_params par;
 	int device;
 	hipStream_t stream; hipStream_t stream2; hipEvent_t evFirstTier, evEarlyGeneric, evPrescan;   // stream2: generic engine for the windows no LDS tier can run, concurrent with tiers 2 and 3
-	hipEvent_t ev[6]; hipEvent_t evtier[3];
+	hipEvent_t ev[6]; hipEvent_t evtier[3]; hipEvent_t evT0; bool tier0_ran;
 	std::string err;
 	bool haveprofile, havedb, havebatch;
 	double est_cor;
@@ -471,6 +477,15 @@ static int upload(dacc_ctx * c, DevBuf<T> & b, T const * src, size_t n)
 
 extern "C" {
 
+// number of HIP devices this process sees (0 if there is none or the runtime fails): lets a caller that spreads workers over
+// devices tell "no such device" from any other dacc_create failure
+int dacc_device_count(void)
+{
+	int ndev = 0;
+	if ( hipGetDeviceCount(&ndev) != hipSuccess || ndev < 0 ) return 0;
+	return ndev;
+}
+
 int dacc_create(dacc_ctx ** out, dacc_params const * p)
 {
 	if ( !out || !p ) return DACC_EINVAL;
@@ -499,6 +514,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming); hipEventCreateWithFlags(&c->evPrescan,hipEventDisableTiming);
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
 	for ( int i = 0; i < 3; ++i ) hipEventCreate(&c->evtier[i]);
+	hipEventCreate(&c->evT0); c->tier0_ran = false;
 	*out = c;
 	return DACC_OK;
 }
@@ -515,6 +531,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
+	hipEventDestroy(c->evT0);
 	delete c;
 }
 
@@ -613,6 +630,7 @@ static int runDevice(dacc_ctx * c)
 		// no LDS tier usable (DACC_TIERS=0 or a model table no tier's overlay holds): everything runs in the generic engine on
 		// the main stream; the pre-scan / second stream would hand the same windows to two kernels
 		bool const anytier = c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2];
+		c->tier0_ran = false;
 		if ( c->usefast && anytier )
 		{
 			// windows only the generic engine can run (a string longer than 64 bases): found by a scan of the window tables and
@@ -663,6 +681,7 @@ static int runDevice(dacc_ctx * c)
 						hipLaunchKernelGGL(k_classify,dim3((BP.nwindows+255)/256),dim3(256),0,s,WB,c->d_small.p,c->d_big.p,c->env_t0inst);
 						FastBatch F0 = FB; F0.F = BP.ftier0; F0.retry = c->d_big.p; F0.gstride = c->gstride0;
 						hipLaunchKernelGGL(k_window_fast<0>,dim3(c->tier0_grid),dim3(64),F0.F.ldsbytes,s,F0,static_cast<uint32_t const *>(c->d_small.p),(c->sched&1) ? c->d_work.p+40 : static_cast<uint32_t *>(0));
+						HIPCHK(hipEventRecord(c->evT0,s)); c->tier0_ran = true;
 						hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,static_cast<uint32_t const *>(c->d_big.p),work);
 					}
 					else if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
@@ -733,12 +752,22 @@ static int runDevice(dacc_ctx * c)
 	{ int const rc = voteAndFetch(); if ( rc ) return rc; }
 	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpy(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+	c->timing.tier0_in = 0; c->timing.tier0_out = 0;
 	if ( c->usefast && BP.nwindows && (c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2]) )
 	{
 		// length of the two lists of the second stream (pre-scan, first tier's generic-only windows): grid of the next pass
 		uint32_t n1 = 0, n2 = 0;
 		HIPCHK(hipMemcpy(&n1,c->d_pregenlist.p,sizeof(uint32_t),hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&n2,c->d_gearly.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
 		c->long_hint = std::max(n1,n2); c->timing.long_windows = n1 + n2;
+		if ( c->tier0_ran )
+		{
+			// size classes: the pre-pass sent nsmall windows to tier 0 and nwindows - nsmall - n1 to the big list, which tier 0's
+			// hand-overs have joined since
+			uint32_t nsmall = 0, nbig = 0;
+			HIPCHK(hipMemcpy(&nsmall,c->d_small.p,sizeof(uint32_t),hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&nbig,c->d_big.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+			uint64_t const big0 = BP.nwindows - std::min<uint64_t>(BP.nwindows,static_cast<uint64_t>(nsmall) + n1);
+			c->timing.tier0_in = nsmall; c->timing.tier0_out = nbig > big0 ? static_cast<uint32_t>(nbig - big0) : 0u;
+		}
 	}
 	// a window the generic engine could not hold (dense graph at small k): grow its scratch capacities and run those
 	// windows again, then the vote (rare; the capacities stay grown for the rest of the batch geometry)
@@ -795,6 +824,8 @@ static int runDevice(dacc_ctx * c)
 	hipEventElapsedTime(&ms,c->ev[1],c->ev[2]); c->timing.window_ms = ms;
 	for ( int i = 0; i < 3; ++i ) { c->timing.tier_ms[i] = 0; c->timing.tier_out[i] = c->tier_out[i]; }
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) { hipEventElapsedTime(&ms,i ? c->evtier[i-1] : c->ev[1],c->evtier[i]); c->timing.tier_ms[i] = ms; }
+	c->timing.tier0_ms = 0; c->timing.reserved_ = 0;
+	if ( c->tier0_ran ) { hipEventElapsedTime(&ms,c->ev[1],c->evT0); c->timing.tier0_ms = ms; }
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
@@ -855,7 +886,16 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		if ( g > gmax ) g = gmax;
 		if ( g < 1 ) g = 1;
 		c->tr_grid = g;
-		if ( c->tr_words == 2 ) HIPCHK(c->d_trslab.ensure(static_cast<size_t>(g)*traceSlabWords(BP.maxcols)));
+		if ( c->tr_words == 2 )
+		{
+			// the checkpoint slabs of the resident workgroups are meant to stay in the Infinity Cache (256 MB): one block with a
+			// long B span makes every workgroup's slab large (300 KB at the 928 columns this kernel takes), so the grid gives way
+			// before the slabs outgrow 192 MB, down to one workgroup per CU
+			uint64_t const slabbytes = static_cast<uint64_t>(traceSlabWords(BP.maxcols))*sizeof(uint64_t);
+			while ( g > 256 && g*slabbytes > (192ull<<20) ) g -= 256;
+			c->tr_grid = g;
+			HIPCHK(c->d_trslab.ensure(static_cast<size_t>(g)*traceSlabWords(BP.maxcols)));
+		}
 	}
 	// window kernel geometry + arenas
 	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);

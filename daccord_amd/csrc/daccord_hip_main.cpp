@@ -318,6 +318,14 @@ int main(int argc, char ** argv)
 			if ( EB.spiles.empty() ) continue;
 			if ( dacc_eprof_add(ep,EB.spiles.data(),EB.spiles.size(),EB.sel.data(),EB.sel.size(),EB.trace.data(),EB.ntrace,tbytes,o.d,hw) ) die("error profile estimation failed (out of memory)");
 		}
+		{
+			// malformed piles are left out of the estimate (one read is logged and skipped, daccord.cpp:2464-2478); say so, and refuse
+			// a profile made from a minority of the sample (a .las that does not belong to this database)
+			uint64_t nskip = 0, nseen = 0;
+			dacc_eprof_skipped(ep,&nskip,&nseen);
+			if ( nskip ) std::fprintf(stderr,"[E] error profile estimation: %llu of %llu piles left out (malformed overlap or trace records)\n",static_cast<unsigned long long>(nskip),static_cast<unsigned long long>(nseen));
+			if ( nseen && 2*nskip > nseen ) die("error profile estimation: most piles of the sample have malformed overlap records -- does the .las belong to this database?");
+		}
 		if ( dacc_eprof_finish(ep,counts,&usable,&unusable,&eavg,&edif,prof) ) die("error profile estimation found no usable window; give --eprof<p_i,p_d,est_cor>");
 		dacc_eprof_destroy(ep);
 		std::fprintf(stderr,"usable=%llu unusable=%llu eavg=%g edif=%g\n",static_cast<unsigned long long>(usable),static_cast<unsigned long long>(unusable),eavg,edif);
@@ -347,13 +355,16 @@ int main(int argc, char ** argv)
 	int const nwork = o.gpus;
 	std::vector<dacc_ctx *> ctxs(nwork,static_cast<dacc_ctx *>(0));
 	{
-		int ndev = 0;      // devices found so far: the first worker whose device does not exist wraps around
+		// workers beyond the last device wrap around onto the devices from --device on; any OTHER failure of a worker's context
+		// (out of memory, bad parameters) ends the run with its return code instead of silently oversubscribing a device
+		int const ndev = dacc_device_count();
+		if ( ndev <= 0 || o.device >= ndev ) die("no usable HIP device " + std::to_string(o.device) + " (" + std::to_string(ndev) + " visible)");
+		int const span = ndev - o.device;
 		for ( int g = 0; g < nwork; ++g )
 		{
-			dacc_params pg = p; pg.device = ndev ? (o.device + g % ndev) : (o.device + g);
-			int rc = dacc_create(&ctxs[g],&pg);
-			if ( rc && g > 0 && !ndev ) { ndev = g; pg.device = o.device + g % ndev; rc = dacc_create(&ctxs[g],&pg); }
-			if ( rc ) die("dacc_create failed (" + std::to_string(rc) + ") on device " + std::to_string(pg.device) + ": no usable HIP device or bad parameters");
+			dacc_params pg = p; pg.device = o.device + g % span;
+			int const rc = dacc_create(&ctxs[g],&pg);
+			if ( rc ) die("dacc_create failed (" + std::to_string(rc) + ") for worker " + std::to_string(g) + " on device " + std::to_string(pg.device) + " of " + std::to_string(ndev));
 			if ( dacc_load_db(ctxs[g],pbps,nbps,pboff,prlen,nreads) ) die(std::string("load db: ") + dacc_last_error(ctxs[g]));
 			if ( dacc_set_error_profile(ctxs[g],prof[0],prof[1],prof[2]) ) die(std::string("error profile: ") + dacc_last_error(ctxs[g]));
 			if ( o.V && nwork > 1 ) std::fprintf(stderr,"[V] device worker %d on HIP device %d\n",g,pg.device);

@@ -491,7 +491,11 @@ struct FastLds<CT,true>
 	HDEV static uint32_t bytes(uint32_t const, uint32_t const) { return (uend + 15u) & ~15u; }
 	// the global slab of a workgroup: forward weights, reverse weights (16 bytes per entry), spill of S; the walk slots of
 	// the stretch construction borrow the weight part
-	static constexpr uint32_t g_wF = 0, g_wR = 16u*CT::wcapg, g_spill = 32u*CT::wcapg, g_bytes = ((32u*CT::wcapg + sbytes + 255u) & ~255u);
+	// (round 4) behind the spill image: the sorted k-mer instances and last k-mers of the current k, saved before the first
+	// traversal of a pass overwrites overlay A, so that the next filter frequency pass reloads them instead of sorting again
+	static constexpr uint32_t g_wF = 0, g_wR = 16u*CT::wcapg, g_spill = 32u*CT::wcapg, g_inst = ((32u*CT::wcapg + sbytes + 255u) & ~255u),
+		g_bytes = g_inst + (((CT::precap + keycap)*8u + 255u) & ~255u);
+	static_assert((o_pre & 15u) == 0 && (CT::precap & 1u) == 0 && (keycap & 1u) == 0,"instance arrays are saved 16 bytes at a time");
 	static constexpr uint32_t xnslot = (32u*CT::wcapg) / 128u;
 };
 #undef FLD
@@ -2528,6 +2532,34 @@ struct FastEngine
 			wv_sync();
 		}
 	}
+	// sorted k-mer instances + last k-mer list of the current k <-> the workgroup's slab (gw tiers).  A pass that ran a
+	// traversal has overwritten overlay A; the next filter frequency pass of the same k needs the very same arrays.
+	DEV void saveInstances()
+	{
+		if constexpr ( GW )
+		{
+			typedef FastLds<CT> LL;
+			G4 * const dst = reinterpret_cast<G4 *>(gslab + LL::g_inst);
+			LDSQ G4 const * const sp = reinterpret_cast<LDSQ G4 const *>(L.pre());
+			LDSQ G4 const * const sl = reinterpret_cast<LDSQ G4 const *>(L.lastk());
+			for ( uint32_t i = lane; i < (npre+1)/2; i += WSZ ) dst[i] = sp[i];
+			for ( uint32_t i = lane; i < (nlast+1)/2; i += WSZ ) dst[CT::precap/2 + i] = sl[i];
+		}
+	}
+	DEV void restoreInstances()
+	{
+		if constexpr ( GW )
+		{
+			typedef FastLds<CT> LL;
+			G4 const * const src = reinterpret_cast<G4 const *>(gslab + LL::g_inst);
+			LDSQ G4 * const dp = reinterpret_cast<LDSQ G4 *>(L.pre());
+			LDSQ G4 * const dl = reinterpret_cast<LDSQ G4 *>(L.lastk());
+			wv_sync();
+			for ( uint32_t i = lane; i < (npre+1)/2; i += WSZ ) dp[i] = src[i];
+			for ( uint32_t i = lane; i < (nlast+1)/2; i += WSZ ) dl[i] = src[CT::precap/2 + i];
+			wv_sync();
+		}
+	}
 	DEV void restoreS()
 	{
 		if constexpr ( GW )
@@ -3304,13 +3336,14 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh; ++k )
 		{
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
-			bool instvalid = false;
+			bool instvalid = false, instsaved = false;
 			for ( int32_t ff = startff; ff >= B.P.minff; --ff )
 			{
 				curff = ff;
 				PROF_T0
-				// the sorted instances of this k are still in place when the pass before ended without a traversal
-				if ( !instvalid ) E.buildInstances();
+				// the sorted instances of this k are still in place when the pass before ended without a traversal; a pass that
+				// traversed has saved them to the slab first (gw tiers)
+				if ( !instvalid ) { if ( instsaved ) E.restoreInstances(); else E.buildInstances(); }
 				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only
 				PROF(E,2)
 				E.buildNodes(ff > 1 ? ff : 1);
@@ -3322,6 +3355,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				// traversal structures then never overwrite the instance array, which the next pass takes over.
 				instvalid = false;
 				if ( ff != 0 && E.passIsDead() ) { instvalid = true; continue; }
+				if ( CT::gw != 0 && ff > B.P.minff && !instsaved ) { E.saveInstances(); instsaved = true; }
 				E.buildSuccessors(mao);
 				PROF(E,4)
 				if ( ff == 0 )

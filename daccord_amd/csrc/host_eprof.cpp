@@ -432,7 +432,7 @@ struct Worker
 
 struct dacc_eprof
 {
-	Store R; int32_t tspace; bool twodb; Acc A; std::string err; uint64_t skipped = 0;
+	Store R; int32_t tspace; bool twodb; Acc A; std::string err; uint64_t skipped = 0, seen = 0;
 };
 
 extern "C" {
@@ -446,6 +446,14 @@ int dacc_eprof_create(dacc_eprof ** out, int32_t tspace, uint8_t const * bps, ui
 	*out = e; return DACC_OK;
 }
 void dacc_eprof_destroy(dacc_eprof * e) { delete e; }
+// piles given to dacc_eprof_add so far and how many of them were left out for malformed overlap / trace records (the
+// skip must be visible to the caller -- a .las that does not belong to the .db yields a profile from a small subset otherwise)
+int dacc_eprof_skipped(dacc_eprof * e, uint64_t * skipped, uint64_t * seen)
+{
+	if ( !e || !skipped || !seen ) return DACC_EINVAL;
+	*skipped = e->skipped; *seen = e->seen;
+	return DACC_OK;
+}
 
 // A malformed pile (record outside the database, trace values that do not add up, overlaps of different A reads or not
 // sorted by abpos) is skipped, as the correction path drops only that pile (batch_plan.hpp) and the reference logs one read
@@ -475,6 +483,7 @@ int dacc_eprof_add(dacc_eprof * e, dacc_pile const * piles, uint64_t npiles, dac
 				if ( !ok ) good[i] = 0;
 			}
 			if ( !good[i] ) e->skipped += 1;
+			e->seen += 1;
 		}
 		if ( nthreads < 1 ) nthreads = 1;
 		std::vector<Acc> part(nthreads); std::vector<double> eloc(npiles,0.0);

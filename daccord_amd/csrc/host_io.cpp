@@ -89,43 +89,87 @@ struct dacc_las
 
 namespace {
 
-// sidecar index "<las>.daidx" (our own format, little endian): magic, file size, novl, tspace, minaread, maxaread, n, aoff[n].
-// Written once (temp file + rename) by whichever process scans the .las first; -J g,G processes that start later load it
-// instead of scanning the whole file again.  DACC_LAS_INDEX=0 disables reading and writing it.
-static char const IDXMAGIC[8] = {'D','A','C','C','I','D','X','1'};
+// sidecar index "<las>.daidx" (our own format, little endian): magic, file size, novl, tspace, minaread, maxaread, n, mtime of the
+// .las (ns), FNV-1a of the .las header + its first and last 40-byte record header, aoff[n].  Written once (temp file + rename) by
+// whichever process scans the .las first; -J g,G processes that start later load it instead of scanning the whole file again.
+// A sidecar is accepted only for the very file it was made from: same size, record count and trace spacing, same modification
+// time AND the same header / first record / last record bytes (a regenerated .las of the same size and count would otherwise
+// reuse stale byte offsets).  Anything wrong with it -- including an absurd n -- means "scan again", never an error.
+// DACC_LAS_INDEX=0 disables reading and writing it.
+static char const IDXMAGIC[8] = {'D','A','C','C','I','D','X','2'};
+enum { IDXHDR = 72 };
 static bool sidecarEnabled() { char const * e = std::getenv("DACC_LAS_INDEX"); return !(e && e[0] == '0'); }
+static bool preadAll(int fd, uint8_t * dst, uint64_t n, uint64_t off);
+static uint64_t lasMtimeNs(dacc_las const & L)
+{
+	struct stat st;
+	if ( ::fstat(L.fd,&st) != 0 ) return 0;
+	return static_cast<uint64_t>(st.st_mtim.tv_sec)*1000000000ull + static_cast<uint64_t>(st.st_mtim.tv_nsec);
+}
+// FNV-1a over the 12 header bytes, the first record header and the 40 bytes at `lastoff` (the last record header)
+static uint64_t lasFingerprint(dacc_las const & L, uint64_t const lastoff)
+{
+	uint8_t b[12+40+40]; std::memset(b,0,sizeof(b));
+	if ( !preadAll(L.fd,b,12,0) ) return 0;
+	if ( L.fsize >= 52 && !preadAll(L.fd,b+12,40,12) ) return 0;
+	if ( lastoff >= 12 && lastoff + 40 <= L.fsize && !preadAll(L.fd,b+52,40,lastoff) ) return 0;
+	uint64_t h = 1469598103934665603ull;
+	for ( size_t i = 0; i < sizeof(b); ++i ) { h ^= b[i]; h *= 1099511628211ull; }
+	return h ? h : 1;
+}
 static bool loadSidecar(dacc_las & L)
 {
-	std::vector<uint8_t> D; std::string err;
 	FILE * f = std::fopen((L.path + ".daidx").c_str(),"rb");
 	if ( !f ) return false;
-	uint8_t h[56];
-	bool ok = std::fread(h,1,sizeof(h),f) == sizeof(h) && std::memcmp(h,IDXMAGIC,8) == 0;
-	if ( ok )
+	bool ok = false;
+	try
 	{
-		uint64_t const fs = get64(h+8); int64_t const novl = get64(h+16); int32_t const tsp = get32(h+24);
-		int64_t const mina = get64(h+32), maxa = get64(h+40); uint64_t const n = get64(h+48);
-		ok = fs == L.fsize && novl == L.novl && tsp == L.tspace && maxa >= -1 && n == static_cast<uint64_t>(maxa+2) && n < (1ull<<40);
+		uint8_t h[IDXHDR];
+		ok = std::fread(h,1,sizeof(h),f) == sizeof(h) && std::memcmp(h,IDXMAGIC,8) == 0;
 		if ( ok )
 		{
-			L.aoff.resize(n);
-			ok = n == 0 || std::fread(L.aoff.data(),8,n,f) == n;
-			for ( uint64_t i = 0; ok && i+1 < n; ++i ) ok = L.aoff[i] <= L.aoff[i+1];
-			ok = ok && (n == 0 || (L.aoff[0] >= 12 && L.aoff[n-1] <= L.fsize));     // bytes behind the last record are ignored
-			if ( ok ) { L.minaread = mina; L.maxaread = maxa; }
+			uint64_t const fs = get64(h+8); int64_t const novl = get64(h+16); int32_t const tsp = get32(h+24);
+			int64_t const mina = get64(h+32), maxa = get64(h+40); uint64_t const n = get64(h+48);
+			uint64_t const mt = get64(h+56), fp = get64(h+64);
+			// (an index has one entry per A read id up to the last one that has a record, plus one: never more than records + 2)
+			ok = fs == L.fsize && novl == L.novl && tsp == L.tspace && maxa >= -1 && n == static_cast<uint64_t>(maxa+2) && mt == lasMtimeNs(L) &&
+			     (novl == 0 || n >= 2) && n <= (1ull<<32);
+			if ( ok )
+			{
+				L.aoff.resize(n);
+				ok = n == 0 || std::fread(L.aoff.data(),8,n,f) == n;
+				for ( uint64_t i = 0; ok && i+1 < n; ++i ) ok = L.aoff[i] <= L.aoff[i+1];
+				ok = ok && (n == 0 || (L.aoff[0] >= 12 && L.aoff[n-1] <= L.fsize));     // bytes behind the last record are ignored
+				// the last record starts where the last A read's byte range holds its final record: found by walking that range
+				if ( ok && n >= 2 )
+				{
+					uint64_t pos = L.aoff[n-2], last = pos; uint8_t r[4];
+					while ( ok && pos + 40 <= L.aoff[n-1] )
+					{
+						ok = preadAll(L.fd,r,4,pos);
+						int32_t const tlen = get32(r);
+						if ( !ok || tlen < 0 ) { ok = false; break; }
+						last = pos; pos += 40 + static_cast<uint64_t>(tlen)*L.tbytes;
+					}
+					ok = ok && pos == L.aoff[n-1] && fp == lasFingerprint(L,last);
+				}
+				if ( ok ) { L.minaread = mina; L.maxaread = maxa; }
+			}
 		}
 	}
+	catch ( std::exception const & ) { ok = false; }      // (a failed allocation for a corrupt n: scan instead)
 	std::fclose(f);
-	if ( !ok ) L.aoff.clear();
+	if ( !ok ) { L.aoff.clear(); L.aoff.shrink_to_fit(); }
 	return ok;
 }
-static void writeSidecar(dacc_las const & L)
+static void writeSidecar(dacc_las const & L, uint64_t const lastrec)
 {
 	std::string const fn = L.path + ".daidx", tmp = fn + ".tmp." + std::to_string(static_cast<long long>(::getpid()));
 	FILE * f = std::fopen(tmp.c_str(),"wb");
 	if ( !f ) return;                      // read-only directory: every process scans for itself
-	uint8_t h[56]; std::memset(h,0,sizeof(h));
+	uint8_t h[IDXHDR]; std::memset(h,0,sizeof(h));
 	std::memcpy(h,IDXMAGIC,8); put64(h+8,L.fsize); put64(h+16,L.novl); put32(h+24,L.tspace); put64(h+32,L.minaread); put64(h+40,L.maxaread); put64(h+48,L.aoff.size());
+	put64(h+56,lasMtimeNs(L)); put64(h+64,lasFingerprint(L,lastrec));
 	bool ok = std::fwrite(h,1,sizeof(h),f) == sizeof(h) && (L.aoff.empty() || std::fwrite(L.aoff.data(),8,L.aoff.size(),f) == L.aoff.size());
 	ok = (std::fclose(f) == 0) && ok;
 	if ( !ok || std::rename(tmp.c_str(),fn.c_str()) != 0 ) std::remove(tmp.c_str());
@@ -233,7 +277,7 @@ int dacc_las_open(const char * path, dacc_las ** out)
 		uint64_t const W = 1ull<<24;
 		std::vector<uint8_t> win(W);
 		uint64_t wlo = 0, whi = 0;           // file range held in win
-		uint64_t pos = 12; int64_t prev = -1;
+		uint64_t pos = 12, lastrec = 0; int64_t prev = -1;
 		std::vector<uint64_t> & aoff = las->aoff;
 		for ( int64_t i = 0; i < las->novl; ++i )
 		{
@@ -256,14 +300,14 @@ int dacc_las_open(const char * path, dacc_las ** out)
 				aoff.resize(static_cast<size_t>(aread)+1,pos);     // reads without records (prev+1..aread-1) share this offset
 				prev = aread;
 			}
-			pos += 40 + tb;
+			lastrec = pos; pos += 40 + tb;
 		}
 		if ( las->novl )
 		{
 			las->maxaread = prev;
 			aoff.push_back(pos);
 		}
-		if ( sidecarEnabled() && las->novl ) writeSidecar(*las);
+		if ( sidecarEnabled() && las->novl ) writeSidecar(*las,lastrec);
 	}
 	catch ( std::bad_alloc const & ) { las->err = "out of memory"; return DACC_ENOMEM; }
 	catch ( std::exception const & ex ) { las->err = ex.what(); return DACC_EINVAL; }

@@ -37,6 +37,7 @@ def lib():
         vp = C.c_void_p
         L.dacc_create.argtypes = [C.POINTER(vp), C.POINTER(DaccParams)]
         L.dacc_destroy.argtypes = [vp]
+        L.dacc_device_count.argtypes = []
         L.dacc_destroy.restype = None
         L.dacc_set_error_profile.argtypes = [vp, C.c_double, C.c_double, C.c_double]
         L.dacc_load_db.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64]
@@ -60,7 +61,7 @@ def lib():
     return _lib
 
 
-EXPORTS = ["dacc_create", "dacc_destroy", "dacc_set_error_profile", "dacc_load_db", "dacc_submit_piles", "dacc_collect",
+EXPORTS = ["dacc_device_count", "dacc_create", "dacc_destroy", "dacc_set_error_profile", "dacc_load_db", "dacc_submit_piles", "dacc_collect",
            "dacc_release", "dacc_last_error", "dacc_pile_select", "dacc_last_timing", "dacc_rerun_resident",
            "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile", "dacc_debug_retry", "dacc_pile_status", "dacc_pile_errors"]
 

@@ -34,6 +34,7 @@ def lib():
         L.dacc_eprof_destroy.argtypes = [vp]
         L.dacc_eprof_set_deep.argtypes = [vp, C.c_int]
         L.dacc_eprof_deep.argtypes = [vp, vp, vp]
+        L.dacc_eprof_skipped.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 
@@ -138,6 +139,9 @@ def estimate_profile(bps, boff, rlen, tspace, piles, ovl, trace, trace_bytes=1, 
         rc = L.dacc_eprof_add(h, _ptr(piles), len(piles), _ptr(ovl), len(ovl), _ptr(trace), trace.nbytes // trace_bytes, trace_bytes, maxalign, nthreads)
         if rc:
             raise ValueError("dacc_eprof_add rc=%d" % rc)
+        sk = C.c_uint64(); sn = C.c_uint64()
+        L.dacc_eprof_skipped(h, C.byref(sk), C.byref(sn))
+        estimate_profile.last_skipped = (sk.value, sn.value)      # (piles left out for malformed records, piles seen)
         counts = np.zeros(4, np.uint64); us = C.c_uint64(); un = C.c_uint64(); ea = C.c_double(); ed = C.c_double(); prof = np.zeros(3, np.float64)
         rc = L.dacc_eprof_finish(h, _ptr(counts), C.byref(us), C.byref(un), C.byref(ea), C.byref(ed), _ptr(prof))
         if rc:

@@ -42,20 +42,44 @@ def _host_buffer(n, device):
     return t
 
 
-def gather_fragments(frags, bases, device="cpu", dst=0):
+# which gather ran last ("p2p" | "padded" | "local"); bench.py echoes it in its JSON line
+last_transport = "local"
+
+
+def _transport():
+    """The gather's transport, decided ONCE and by configuration alone -- never by catching an exception on one rank (a rank that
+    fell back to a collective while its peers had finished their sends would wait for them for ever): point-to-point sends of
+    exactly the bytes each rank has ("p2p": RCCL / NCCL and gloo both implement batch_isend_irecv) unless DACC_GATHER=padded asks
+    for the padded collective (debugging, or a backend without point-to-point operations).  Every rank reads the same
+    environment, so the choice is collective."""
+    import os
+    t = os.environ.get("DACC_GATHER", "p2p")
+    if t not in ("p2p", "padded"):
+        raise ValueError("DACC_GATHER must be p2p or padded")
+    return t
+
+
+def gather_fragments(frags, bases, device=None, dst=0, copy=False):
     """All ranks call.  Returns (frags, bases) of the whole job on rank `dst` (fragments in rank order, seq_off rebased
     onto the concatenated base buffer) and (None, None) elsewhere.  Without an initialised process group: identity.
 
     Every rank sends exactly its bytes (no padding to the largest rank) and rank `dst` receives them at their final offsets
-    of ONE fragment buffer and ONE base buffer, so nothing is re-sliced or concatenated afterwards; the gathered `bases` is a
-    bytes-like view of a reused host buffer and stays valid until the next call.  (The first version padded every rank to the
-    largest, gathered world tensors, copied each to the host, sliced and joined them: about half a second of host work per step
-    on rank 0 at eight ranks of BASELINE config 2 -- inside the timed step.)"""
+    of ONE fragment buffer and ONE base buffer, so nothing is re-sliced or concatenated afterwards.  `device`: where the
+    message buffers live; default = what the backend needs ("cuda" for nccl = RCCL, whose operands must be device tensors;
+    "cpu" for gloo, whose operands are the host arrays themselves -- no host -> device -> host round trip).
+
+    ALIASING: the gathered `bases` is a memoryview of a module-level host buffer that the NEXT call overwrites; pass
+    copy=True to get an owned bytes object when a result must outlive the next call.  Errors of the transport are raised, not
+    swallowed."""
+    global last_transport
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        last_transport = "local"
         return frags, bases
     world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
     fb = np.ascontiguousarray(frags).view(np.uint8).reshape(-1)
     bb = np.frombuffer(bases, dtype=np.uint8)
     cnt = torch.tensor([fb.size, bb.size], dtype=torch.int64, device=device)
@@ -64,49 +88,63 @@ def gather_fragments(frags, bases, device="cpu", dst=0):
     allc = torch.stack(allc).cpu().numpy()
     nf, nb = allc[:, 0].astype(np.int64), allc[:, 1].astype(np.int64)
     foff = np.concatenate([np.zeros(1, np.int64), np.cumsum(nf)]); boff = np.concatenate([np.zeros(1, np.int64), np.cumsum(nb)])
-    try:
-        if rank != dst:
-            ops = []
-            if fb.size:
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(fb.copy()).to(device), dst))
-            if bb.size:
-                ops.append(dist.P2POp(dist.isend, torch.from_numpy(bb.copy()).to(device), dst))
-            if ops:
-                for q in dist.batch_isend_irecv(ops):
-                    q.wait()
-            return None, None
-        F = torch.empty(max(int(foff[-1]), 1), dtype=torch.uint8, device=device)
-        B = torch.empty(max(int(boff[-1]), 1), dtype=torch.uint8, device=device)
+    last_transport = _transport()
+    if last_transport == "padded":
+        F2, B2 = _gather_padded(frags, fb, bb, allc, device, dst)
+        return (F2, bytes(B2)) if (copy and B2 is not None) else (F2, B2)
+
+    def msg(a):
+        # the host array itself on a CPU backend (torch.from_numpy shares its memory; it is only read), a device copy for RCCL
+        t = torch.from_numpy(a if a.flags.writeable else a.copy())
+        return t if str(device) == "cpu" else t.to(device)
+
+    if rank != dst:
         ops = []
-        for r in range(world):
-            if r == dst:
-                if fb.size:
-                    F[foff[r]:foff[r + 1]] = torch.from_numpy(fb.copy()).to(device)
-                if bb.size:
-                    B[boff[r]:boff[r + 1]] = torch.from_numpy(bb.copy()).to(device)
-                continue
-            if nf[r]:
-                ops.append(dist.P2POp(dist.irecv, F[foff[r]:foff[r + 1]], r))
-            if nb[r]:
-                ops.append(dist.P2POp(dist.irecv, B[boff[r]:boff[r + 1]], r))
+        if fb.size:
+            ops.append(dist.P2POp(dist.isend, msg(fb), dst))
+        if bb.size:
+            ops.append(dist.P2POp(dist.isend, msg(bb), dst))
         if ops:
             for q in dist.batch_isend_irecv(ops):
                 q.wait()
-    except (RuntimeError, NotImplementedError, AttributeError):
-        return _gather_padded(frags, fb, bb, allc, device, dst)
+        return None, None
+    F = torch.empty(max(int(foff[-1]), 1), dtype=torch.uint8, device=device)
+    if str(device) == "cpu":
+        B = _host_buffer(int(boff[-1]), device)      # received straight into the reused host buffer
+    else:
+        B = torch.empty(max(int(boff[-1]), 1), dtype=torch.uint8, device=device)
+    ops = []
+    for r in range(world):
+        if r == dst:
+            if fb.size:
+                F[foff[r]:foff[r + 1]] = msg(fb)
+            if bb.size:
+                B[boff[r]:boff[r + 1]] = msg(bb)
+            continue
+        if nf[r]:
+            ops.append(dist.P2POp(dist.irecv, F[foff[r]:foff[r + 1]], r))
+        if nb[r]:
+            ops.append(dist.P2POp(dist.irecv, B[boff[r]:boff[r + 1]], r))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     allf = F[:int(foff[-1])].cpu().numpy().view(frags.dtype).copy() if foff[-1] else frags[:0].copy()
     # rebase seq_off: the fragments of rank r start at fragment index foff[r] / itemsize and their bases at boff[r]
     isz = frags.dtype.itemsize
     for r in range(world):
         if nf[r]:
             allf["seq_off"][int(foff[r]) // isz:int(foff[r + 1]) // isz] += allf["seq_off"].dtype.type(int(boff[r]))
-    host = _host_buffer(int(boff[-1]), device)
-    host[:int(boff[-1])].copy_(B[:int(boff[-1])])
-    return allf, memoryview(host.numpy())[:int(boff[-1])]
+    if str(device) == "cpu":
+        host = B
+    else:
+        host = _host_buffer(int(boff[-1]), device)
+        host[:int(boff[-1])].copy_(B[:int(boff[-1])])
+    view = memoryview(host.numpy())[:int(boff[-1])]
+    return allf, (bytes(view) if copy else view)
 
 
 def _gather_padded(frags, fb, bb, allc, device, dst):
-    """Fallback for a backend without point-to-point operations: every rank padded to the largest, one gather."""
+    """DACC_GATHER=padded: every rank padded to the largest, one all_gather (for a backend without point-to-point operations)."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -116,13 +154,9 @@ def _gather_padded(frags, fb, bb, allc, device, dst):
         buf[:fb.size] = torch.from_numpy(fb.copy()).to(device)
     if bb.size:
         buf[fb.size:fb.size + bb.size] = torch.from_numpy(bb.copy()).to(device)
-    out = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)] if rank == dst else None
-    try:
-        dist.gather(buf, out, dst=dst)
-    except (RuntimeError, NotImplementedError):
-        # backend without gather: every rank collects (same result on dst, a little more traffic)
-        out = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
-        dist.all_gather(out, buf)
+    # all_gather: implemented by every backend (one code path on all ranks; the padded transport is a debugging aid)
+    out = [torch.zeros(max(mx, 1), dtype=torch.uint8, device=device) for _ in range(world)]
+    dist.all_gather(out, buf)
     if rank != dst:
         return None, None
     allf, allb, off = [], [], 0

@@ -91,6 +91,9 @@ typedef struct dacc_fragment {
 
 typedef struct dacc_ctx dacc_ctx;
 
+/* Number of HIP devices visible to this process (0: none).  The reference has no device notion; a front end that runs one
+ * context per device (`--gpus N`) uses it to tell a missing device from any other dacc_create failure. */
+int  dacc_device_count(void);
 int  dacc_create(dacc_ctx **ctx, const dacc_params *params);
 void dacc_destroy(dacc_ctx *ctx);
 
@@ -145,6 +148,10 @@ int  dacc_eprof_add(dacc_eprof *e, const dacc_pile *piles, uint64_t npiles, cons
 int  dacc_eprof_finish(dacc_eprof *e, uint64_t counts[4], uint64_t *usable, uint64_t *unusable,
                        double *eavg, double *edif, double prof[3]);
 void dacc_eprof_destroy(dacc_eprof *e);
+/* piles passed to dacc_eprof_add so far (*seen) and how many were left out because of malformed overlap / trace records (*skipped):
+ * the reference logs such a read (src/daccord.cpp:2464-2478); a caller should report the count and refuse a profile made from a
+ * minority of the piles */
+int  dacc_eprof_skipped(dacc_eprof *e, uint64_t *skipped, uint64_t *seen);
 /* --deepprofileonly (daccord.cpp:1442-1650, handleIndelEstimateDeep :634-995): switch the collection on before the first
  * dacc_eprof_add; dacc_eprof_deep returns, ascending, round(error rate * (2^32-1)) of every window that got a consensus
  * (:963-968).  The caller prints the cumulative distribution (:1626-1648). */
@@ -169,6 +176,10 @@ typedef struct dacc_timing {
 	uint32_t tier_out[3];    /* windows each tier handed on (tier_out[2] = windows run by the generic engine) */
 	uint32_t first_tier;     /* kernel of the first slot: 1 = k_window_fast<1>, 4 = k_window_fast<4> (batch of deep piles) */
 	uint32_t long_windows;   /* windows the second stream ran (a string of more than 64 bases, or a shape no LDS tier takes) */
+	float tier0_ms;          /* size classes (shallow batches): pre-pass + k_window_fast<0>, the part of tier_ms[0] in front of k_window_fast<1>; 0 if tier 0 did not run */
+	uint32_t tier0_in;       /* windows the pre-pass sent to tier 0 */
+	uint32_t tier0_out;      /* windows tier 0 handed on to tier 1 */
+	uint32_t reserved_;
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 

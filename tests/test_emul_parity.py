@@ -257,9 +257,9 @@ def test_long_strings_make_long_stretches():
 
 
 def test_twice_split_stretch_stays_in_the_lds_tiers():
-    """A (first, last) k-mer pair that splits one stretch at two different nodes needs the MIDDLE piece of that stretch, whose
-    feasibility is computed while the enumeration pools lie over the node tables (gw layout: read from the spilled image in the
-    workgroup's slab, FastEngine::sGet).  While the gw tiers handed such windows on instead, 0.044 % of the windows of config 2
+    """A (first, last) k-mer pair that splits one stretch at two different nodes needs the MIDDLE piece of that stretch, which
+    the gw layout creates together with the candidates' pieces (FastEngine::findCandidatesAndPieces, makePiece) so that it gets its
+    feasibility with all other stretches, before the enumeration pools are laid over the node tables.  While the gw tiers handed such windows on instead, 0.044 % of the windows of config 2
     ended in the generic engine and took it longer than all other windows together (profiles/r03e_*): none may get there,
     and the piles must still carry the oracle's digests (tests/golden/scale_cfg2.json, first 60 piles of the bench's data set)."""
     import json, os

@@ -62,6 +62,9 @@ def test_estimator_skips_a_malformed_pile():
     c0, u0, n0, p0 = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, good_piles, ovl, d.trace, nthreads=2)
     c1, u1, n1, p1 = dio.estimate_profile(d.bps, d.boff, d.rlen, 100, piles[:n], bad, d.trace, nthreads=2)
     assert list(c0) == list(c1) and (u0, n0) == (u1, n1) and p0 == p1
+    assert dio.estimate_profile.last_skipped == (1, n)      # the skip is reported (dacc_eprof_skipped), not silent
+    dio.estimate_profile(d.bps, d.boff, d.rlen, 100, good_piles, ovl, d.trace, nthreads=2)
+    assert dio.estimate_profile.last_skipped == (0, n - 1)
 
 
 def test_deep_profile_matches_oracle_and_cli(tmp_path):

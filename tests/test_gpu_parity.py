@@ -70,6 +70,27 @@ def test_high_error_gap_filling_and_failures():
     assert frags_equal(fo, bo, fx, bx)
 
 
+@pytest.mark.parametrize("t0inst", ["0", "300", "488", "100000"])
+def test_size_class_threshold_does_not_change_results(small_data, t0inst, monkeypatch):
+    """tier 0 (size classes, round 4): whatever share of the windows the pre-pass sends to the small tier -- none, some, all
+    that its string capacity admits -- the per-window records and the FASTA are the oracle's; what tier 0 cannot hold is handed on"""
+    d, ovl, piles = small_data
+    monkeypatch.setenv("DACC_T0INST", t0inst)
+    O, E = _pair(d, k=14)
+    fo, bo = O.run(piles[:30], ovl, d.trace, nthreads=8, want_windows=True); wo = O.windows()
+    fx, bx = E(piles[:30], ovl, d.trace); wx = E.debug_windows(); t = E.timing()
+    assert windows_equal(wo, wx) == [] and frags_equal(fo, bo, fx, bx)
+    if t0inst == "0":
+        assert t.tier0_in == 0
+    else:
+        assert t.tier0_in > 0 and t.tier0_ms > 0
+    if t0inst == "100000":
+        assert t.tier0_in > 0.9 * len(wx) and t.tier0_out > 0      # everything starts small, the big windows are handed on
+    E.rerun(); f2, b2 = E.collect()
+    assert frags_equal(fo, bo, f2, b2)
+    E.close()
+
+
 @pytest.mark.parametrize("tspace", [126, 200, 300])
 def test_wide_trace_spacing(tspace):
     """tspace > 125: two byte trace values; > 128: k_trace_wide<4> (up to 256) / <8> (up to 512)."""

@@ -141,6 +141,21 @@ def test_las_index_ranges_and_sidecar(tmp_path, monkeypatch):
     assert len(o3) == len(ovl) // 2
     las4 = dio.LasFile(p)
     assert len(las4.piles()[1]) == len(ovl) // 2
+    # ... and so is the sidecar of a file of the SAME size and record count whose records differ (a regenerated .las):
+    # renumber the A reads of the last pile, so that the byte offsets of the old index no longer name the right reads
+    half = ovl[:len(ovl) // 2].copy()
+    last = int(half["aread"].max())
+    half["aread"][half["aread"] == last] = last + 3
+    st0 = os.stat(p + ".daidx").st_mtime_ns
+    dio.write_las(p, 100, half, d.trace)
+    las5 = dio.LasFile(p)
+    p5, o5, _ = las5.piles()
+    assert len(o5) == len(half) and int(p5["aread"].max()) == last + 3 and las5.max_aread == last + 3
+    assert os.stat(p + ".daidx").st_mtime_ns != st0                      # rescanned and rewritten
+    # a corrupt sidecar (absurd entry count) means "scan", never an error
+    raw = bytearray(open(p + ".daidx", "rb").read()); raw[48:56] = (2 ** 62).to_bytes(8, "little"); open(p + ".daidx", "wb").write(bytes(raw))
+    las6 = dio.LasFile(p)
+    assert len(las6.piles()[1]) == len(half)
 
 
 def test_las_reader_streams(tmp_path):

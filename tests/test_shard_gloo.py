@@ -4,6 +4,7 @@ import os
 import sys
 import socket
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,18 +76,25 @@ def _worker_edge(rank, world, port, q):
         s = bytes([65 + rank]) * (10 + i)
         f[i]["aread"] = 100 * rank + i; f[i]["first"] = i; f[i]["last"] = i + len(s); f[i]["len"] = len(s); f[i]["seq_off"] = len(bases)
         bases += s
-    F, B = shard.gather_fragments(f, bases, device="cpu")
+    F, B = shard.gather_fragments(f, bases)            # device from the backend: host arrays for gloo
+    assert shard.last_transport == os.environ.get("DACC_GATHER", "p2p")
     if rank == 0:
+        # a second gather overwrites the buffer the first result aliases unless a copy was asked for (documented)
+        F2, B2 = shard.gather_fragments(f, bases, copy=True)
+        assert isinstance(B2, bytes) and bytes(B) == B2 and [int(x) for x in F2["aread"]] == [int(x) for x in F["aread"]]
         ok = len(F) == 1 + 0 + 3 and [int(x) for x in F["aread"]] == [0, 200, 201, 202]
         ok = ok and all(B[int(x["seq_off"]):int(x["seq_off"]) + int(x["len"])] == bytes([65 + int(x["aread"]) // 100]) * int(x["len"]) for x in F)
         q.put(ok)
     else:
         assert F is None and B is None
+        assert shard.gather_fragments(f, bases, copy=True) == (None, None)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_with_an_empty_rank_and_uneven_sizes():
+@pytest.mark.parametrize("transport", ["p2p", "padded"])
+def test_gather_with_an_empty_rank_and_uneven_sizes(transport, monkeypatch):
+    monkeypatch.setenv("DACC_GATHER", transport)      # read by every rank: the transport is chosen by configuration, collectively
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -125,8 +133,6 @@ def _worker_hip(rank, world, port, q):
     dist.barrier()
     dist.destroy_process_group()
 
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
