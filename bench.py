@@ -389,7 +389,7 @@ def main():
                     R = pyref.Reference(p)
                     R.set_error_profile(*d.error_profile()); R.load_db(d.bps, d.boff, d.rlen)
                     rthr = max(1, min(nthr, 16 if args.k <= 14 else 2))      # a DebruijnGraph<k> of the reference holds 4^k int32 per thread
-                    nrp = min(len(piles) - first, rthr)
+                    nrp = min(len(piles) - first, 2 * rthr)      # about 20-25 s at 20x / k = 14
                     tc = time.perf_counter()
                     fr_, br_ = R.run(piles[first:first + nrp], ovl, d.trace, nthreads=rthr)
                     tr_ = time.perf_counter() - tc

@@ -42,8 +42,8 @@ def test_scale_case_matches_oracle_digests(name):
         assert len(w) == run["nwindows"]
         if name in ("cfg2", "cfg2s", "cfg2t", "cfg3"):
             # shallow batches: the size classes ran -- the pre-pass sent a good part of the windows to tier 0 (8 wavefronts per CU),
-            # which finished most of them (round 4)
-            assert t.tier0_in > 0.25 * len(w) and t.tier0_out < 0.2 * t.tier0_in and t.tier0_ms > 0, (t.tier0_in, t.tier0_out, t.tier0_ms)
+            # which finished most of them (a fifth is handed on at the default threshold: node overflows; round 4)
+            assert t.tier0_in > 0.25 * len(w) and t.tier0_out < 0.35 * t.tier0_in and t.tier0_ms > 0, (t.tier0_in, t.tier0_out, t.tier0_ms)
         if name in ("cfg4", "cfg4b"):
             assert t.tier0_in == 0 and t.tier0_ms == 0      # deep batches start in the deep tier, no size classes
 
