@@ -155,6 +155,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(nb, op=dist.ReduceOp.SUM)
     dt = float(tmax[0].item()); tfirst_max = float(tmax[1].item())
+    t_post = time.perf_counter()      # rank 0's work behind the timed loop (digests, accuracy, CPU legs) is reported as post_loop_s
     total_bases = float(nb.item())
 
     if rank == 0:
@@ -405,6 +406,7 @@ def main():
                     res["cpu_baseline"]["reference_build"] = {"error": "oracle/_ref not built (needs /root/reference at build time)"}
             except Exception as ex:
                 res["cpu_baseline"]["reference_build"] = {"error": repr(ex)[:200]}
+        res["post_loop_s"] = round(time.perf_counter() - t_post, 2)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

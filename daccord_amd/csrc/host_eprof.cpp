@@ -401,7 +401,9 @@ struct Worker
 			{
 				Active & a = it->second; uint32_t const z = it->first & 0xFFFFFFFFu;
 				size_t p = a.pos; uint64_t ua, ub; advanceOps(ops[z],p,EW,ua,ub);
-				if ( M.empty() && twodb ) M.push_back(std::make_pair(static_cast<uint8_t const *>(ra.data()+astart),static_cast<uint32_t>(EW)));
+				// the reference's test `&RC != &RC2` (daccord.cpp:522) compares two local containers (daccord.cpp:1775-1776): always
+				// true, so the A window always joins the window's strings, with one database as with two (found with oracle/_ref in round 4)
+				if ( M.empty() ) M.push_back(std::make_pair(static_cast<uint8_t const *>(ra.data()+astart),static_cast<uint32_t>(EW)));
 				if ( M.size() < maxalign ) M.push_back(std::make_pair(static_cast<uint8_t const *>(rb[z].data()+a.ub),static_cast<uint32_t>(ub)));
 				uint64_t va, vb; advanceOps(ops[z],a.pos,EA,va,vb); a.ub += vb;
 			}

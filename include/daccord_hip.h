@@ -137,7 +137,8 @@ int  dacc_pile_select_lowest(const dacc_overlap *in, uint64_t n, int trace_bytes
 /* handleIndelEstimate<8> (daccord.cpp:271-631) over batches of piles: windows of 40 bases every 5, k = 8, k-mers seen
  * at least twice, trivial traversal (DebruijnGraph.hpp:3794-3824), every window string aligned to the window consensus,
  * alignment operations counted.  The read store (same layout as dacc_load_db) is borrowed until dacc_eprof_destroy;
- * two_databases != 0: A and B reads come from different databases (the A window then joins the strings, :562-566).
+ * two_databases: kept for ABI stability, without effect since round 4 -- the A window ALWAYS joins a window's strings: the reference's
+ * test `&RC != &RC2` (:522) compares two distinct local containers (:1775-1776) and is always true, with one database as with two.
  * dacc_eprof_finish: counts = {matches, mismatches, insertions, deletions}, prof = {p_i, p_d, est_cor}
  * (daccord.cpp:1867-1878); DACC_ENOTSUP if no window was usable. */
 typedef struct dacc_eprof dacc_eprof;

@@ -97,7 +97,11 @@ static inline double handleIndelEstimate8(uint64_t const maxalign, dacc_overlap 
 			AE_t & AE = s_ita->second;
 			std::pair<uint64_t,uint64_t> const adv = advanceA(AE.ta,AE.te,windowsize);
 			std::pair<uint64_t,uint64_t> const sl = getStringLengthUsed(AE.ta,AE.ta+adv.second);
-			if ( MA.empty() && twodb ) MA.push_back(StringRef(AE.ua,windowsize));
+			// `(! MAo) && (&RC != &RC2)` (daccord.cpp:522): RC and RC2 are two local containers of the caller (daccord.cpp:1775-1776),
+			// so the test is ALWAYS true in v0.0.14 and the A window always joins the strings -- also with one database.  (Rounds 1-3
+			// read it as "two databases only"; oracle/_ref, the reference's own estimator, showed the difference in round 4.)
+			(void)twodb;
+			if ( MA.empty() ) MA.push_back(StringRef(AE.ua,windowsize));
 			if ( MA.size() < maxalign ) MA.push_back(StringRef(AE.ub,sl.second));
 			std::pair<uint64_t,uint64_t> const advadv = advanceA(AE.ta,AE.te,advancesize);
 			std::pair<uint64_t,uint64_t> const sladv = getStringLengthUsed(AE.ta,AE.ta+advadv.second);

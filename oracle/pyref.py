@@ -55,6 +55,7 @@ def lib(k16=False):
         L.ref_run_piles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
         L.ref_collect.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ref_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.ref_estimate_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _libs[k16] = L
     return _libs[k16]
 
@@ -97,6 +98,24 @@ class Reference:
                               dtype=np.dtype(DaccFragment)).copy() if nf.value else np.zeros(0, np.dtype(DaccFragment))
         bases = C.string_at(ba.value, nb.value) if nb.value else b""
         return frags, bases
+
+    def estimate_profile(self, piles, ovl, trace, trace_bytes=1, maxalign=2 ** 64 - 1, deep=False):
+        """src/daccord.cpp:1653-1878 with the reference's handleIndelEstimate<8> (:271-631) over the given (already selected) piles:
+        (counts, usable, unusable, (p_i, p_d, est_cor)); deep=True: handleIndelEstimateDeep<8> (:633-995), plus the sorted uint32
+        window error rates"""
+        piles = np.ascontiguousarray(piles); ovl = np.ascontiguousarray(ovl); trace = np.ascontiguousarray(trace)
+        counts = np.zeros(4, np.uint64); us = C.c_uint64(); un = C.c_uint64(); prof = np.zeros(3, np.float64)
+        cap = 1 << 22; out = np.zeros(cap if deep else 1, np.uint32); nd = C.c_uint64()
+        rc = self.L.ref_estimate_profile(self.h, _ptr(piles), len(piles), _ptr(ovl), _ptr(trace), trace_bytes, maxalign, _ptr(counts), C.byref(us),
+                                         C.byref(un), _ptr(prof), 1 if deep else 0, _ptr(out), cap, C.byref(nd))
+        if rc == -9:
+            raise RuntimeError("oracle/_ref was built without the estimator")
+        if rc == -2:
+            raise RuntimeError(self.L.ref_error(self.h).decode())
+        if rc:
+            raise ValueError("no usable window")
+        res = (counts, us.value, un.value, tuple(float(x) for x in prof))
+        return res + (out[:nd.value].copy(),) if deep else res
 
     def log(self):
         return self.L.ref_log(self.h).decode()

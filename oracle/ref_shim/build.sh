@@ -11,7 +11,13 @@ REF="${DACC_REFERENCE:-/root/reference}/src"
 OUT="$HERE/../_ref"
 if [ ! -f "$REF/HandleContext.hpp" ]; then echo "ref_shim/build.sh: $REF not present, nothing built"; exit 0; fi
 mkdir -p "$OUT"
-FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w"
+# the estimator functions (handleIndelEstimate<k>, handleIndelEstimateDeep<k>) are lines 271-995 of the driver's translation unit:
+# cut out for the duration of the compile only
+EXC="$OUT/.estimate_excerpt.$$.hpp"
+sed -n '271,995p' "$REF/daccord.cpp" > "$EXC"
+grep -q "^double handleIndelEstimate(" "$EXC" || { echo "ref_shim/build.sh: estimator not at the expected lines of daccord.cpp"; rm -f "$EXC"; exit 1; }
+trap 'rm -f "$EXC"' EXIT
+FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\""
 g++ $FLAGS -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref.so" "$HERE/ref_capi.cpp" &
 g++ $FLAGS -DDACC_REF_K16 -I"$HERE/k16" -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref_k16.so" "$HERE/ref_capi.cpp" &
 wait

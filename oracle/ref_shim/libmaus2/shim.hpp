@@ -502,6 +502,21 @@ inline char invertUnmapped(char const c)
 {
 	switch ( c ) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; default: return c; }
 }
+// libmaus2/fastx/KmerRepeatDetector.hpp (the estimator, daccord.cpp:384, :545): detect = some q-mer occurs twice in the string
+// (the definition of oracle/o_eprof.hpp::kmerRepeatDetect)
+struct KmerRepeatDetector
+{
+	unsigned int q;
+	KmerRepeatDetector(unsigned int const rq) : q(rq) {}
+	template<typename it> bool detect(it p, uint64_t const n)
+	{
+		std::set<std::string> S;
+		for ( uint64_t i = 0; i+q <= n; ++i )
+			if ( !S.insert(std::string(p+i,p+i+q)).second ) return true;
+		return false;
+	}
+	void printRepeats() const {}
+};
 inline std::string reverseComplementUnmapped(std::string const & s)
 {
 	std::string r(s.rbegin(),s.rend());
@@ -770,8 +785,16 @@ struct CigarStringParser
 };
 }
 
-// ---------------------------------------------------------------- libmaus2/sorting/ParallelStableSort.hpp (window-parallel variant only)
+// ---------------------------------------------------------------- libmaus2/util/U: number wrapper of the serialising sorters
+namespace util { template<typename N> struct U { N u; U(N const ru = N()) : u(ru) {} bool operator<(U const & o) const { return u < o.u; } }; }
+// ---------------------------------------------------------------- libmaus2/sorting/ParallelStableSort.hpp (window-parallel variant only),
+// SerialisingSortingBufferedOutputFileArray (--deepprofileonly collects its window error rates in one: here a vector)
 namespace sorting {
+template<typename T>
+struct SerialisingSortingBufferedOutputFileArray
+{
+	struct sorter_type { std::vector<T> V; void put(T const & v) { V.push_back(v); } };
+};
 struct ParallelStableSort
 {
 	template<typename iterator, typename order_type>

@@ -19,6 +19,12 @@
  */
 #include <libmaus2/shim.hpp>
 #include <HandleContext.hpp>
+// The estimator functions of the reference, handleIndelEstimate<k> and handleIndelEstimateDeep<k> (src/daccord.cpp:271-995), live in
+// the driver's translation unit next to main(); build.sh cuts exactly those lines out of /root/reference/src/daccord.cpp into a
+// temporary file of the (git-ignored) output directory at build time and deletes it after the compile -- the repository never holds them.
+#if defined(DACC_REF_ESTIMATE_EXCERPT)
+#include DACC_REF_ESTIMATE_EXCERPT
+#endif
 #include "../../include/daccord_hip.h"
 #ifdef _OPENMP
 #include <omp.h>
@@ -234,6 +240,87 @@ int ref_max_k()
 	#else
 	return 12;
 	#endif
+}
+
+}
+
+#if defined(DACC_REF_ESTIMATE_EXCERPT)
+namespace {
+typedef libmaus2::dazzler::align::Overlap RefOverlap;
+static void fillOverlaps(std::vector<RefOverlap> & V, dacc_pile const & pile, dacc_overlap const * ovl, void const * trace, int const trace_bytes)
+{
+	V.assign(pile.novl+1,RefOverlap());
+	for ( uint64_t z = 0; z < pile.novl; ++z )
+	{
+		dacc_overlap const & o = ovl[pile.first_ovl+z];
+		RefOverlap & d = V[z];
+		d.aread = o.aread; d.bread = o.bread; d.flags = o.flags; d.path.abpos = o.abpos; d.path.aepos = o.aepos; d.path.bbpos = o.bbpos; d.path.bepos = o.bepos;
+		d.path.diffs = o.diffs; d.path.tlen = o.tlen; d.path.path.resize(o.tlen/2);
+		for ( int32_t i = 0; i < o.tlen/2; ++i )
+		{
+			uint64_t const a = trace_bytes == 2 ? reinterpret_cast<uint16_t const *>(trace)[o.trace_off+2*i] : reinterpret_cast<uint8_t const *>(trace)[o.trace_off+2*i];
+			uint64_t const b = trace_bytes == 2 ? reinterpret_cast<uint16_t const *>(trace)[o.trace_off+2*i+1] : reinterpret_cast<uint8_t const *>(trace)[o.trace_off+2*i+1];
+			d.path.path[i] = std::pair<uint16_t,uint16_t>(a,b);
+		}
+	}
+}
+}
+#endif
+
+extern "C" {
+
+// src/daccord.cpp:1653-1878 around handleIndelEstimate<8> (:271-631): the sampling loop over the given (already selected, :1705-1755)
+// piles with the estimator's window 40 / advance 5 (:1665-1666), and the rates of :1867-1878.  deep != 0: handleIndelEstimateDeep<8>
+// (:633-995, --deepprofileonly), the window error rates sorted ascending into out (at most cap; returns their number in *ndeep).
+int ref_estimate_profile(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, void const * trace, int trace_bytes,
+	uint64_t maxalign, uint64_t * counts, uint64_t * usable, uint64_t * unusable, double * prof, int deep, uint32_t * out, uint64_t cap, uint64_t * ndeep)
+{
+#if defined(DACC_REF_ESTIMATE_EXCERPT)
+	RefCtx * c = static_cast<RefCtx *>(v);
+	try
+	{
+		libmaus2::parallel::LockedGrowingFreeList<trace_type,TraceAllocator,TraceTypeInfo> traceFreeList;
+		libmaus2::parallel::LockedGrowingFreeList<ReadData,ReadDataAllocator,ReadDataTypeInfo> readDataFreeList;
+		ReadDecoderAllocator RDA(&c->DB);
+		libmaus2::parallel::LockedGrowingFreeList<ReadDecoder,ReadDecoderAllocator,ReadDecoderTypeInfo> readDecoderFreeList(RDA);
+		libmaus2::parallel::LockedGrowingFreeList<ReadDecoder,ReadDecoderAllocator,ReadDecoderTypeInfo> readDecoderFreeList2(RDA);
+		libmaus2::lcs::Aligner::unique_ptr_type Pal(DebruijnGraphBase::getAligner());       // daccord.cpp:1690
+		libmaus2::lcs::AlignmentStatistics GAS; uint64_t us = 0, un = 0;
+		libmaus2::sorting::SerialisingSortingBufferedOutputFileArray< libmaus2::util::U<uint32_t> >::sorter_type usorter;
+		std::ostringstream sink;
+		for ( uint64_t i = 0; i < npiles; ++i )
+		{
+			std::vector<RefOverlap> RO; fillOverlaps(RO,piles[i],ovl,trace,trace_bytes);
+			libmaus2::lcs::AlignmentStatistics LGAS; uint64_t lu = 0, lun = 0;
+			DecodedReadContainer RDC(readDataFreeList,readDecoderFreeList);        // daccord.cpp:1775-1776: two containers, always
+			DecodedReadContainer RDC2(readDataFreeList,readDecoderFreeList2);
+			if ( deep )
+				handleIndelEstimateDeep<8>(usorter,sink,maxalign,RO.data(),RO.data()+piles[i].novl,40,5,RDC,RDC2,traceFreeList,*Pal,c->par.tspace,LGAS,lu,lun);
+			else
+				handleIndelEstimate<8>(sink,maxalign,RO.data(),RO.data()+piles[i].novl,40,5,RDC,RDC2,traceFreeList,*Pal,c->par.tspace,LGAS,lu,lun);
+			GAS += LGAS; us += lu; un += lun;
+		}
+		counts[0] = GAS.matches; counts[1] = GAS.mismatches; counts[2] = GAS.insertions; counts[3] = GAS.deletions;
+		*usable = us; *unusable = un;
+		if ( deep )
+		{
+			std::vector<uint32_t> D; for ( uint64_t i = 0; i < usorter.V.size(); ++i ) D.push_back(usorter.V[i].u);
+			std::sort(D.begin(),D.end());
+			for ( uint64_t i = 0; i < D.size() && i < cap; ++i ) out[i] = D[i];
+			*ndeep = D.size();
+		}
+		uint64_t const len = GAS.matches + GAS.mismatches + GAS.deletions;                   // daccord.cpp:1867-1878
+		uint64_t const numerr = GAS.mismatches + GAS.deletions + GAS.insertions;
+		if ( !len ) return -1;
+		double const est_erate = static_cast<double>(numerr) / len;
+		prof[0] = static_cast<double>(GAS.insertions) / len; prof[1] = static_cast<double>(GAS.deletions) / len; prof[2] = 1.0 - est_erate;
+		return 0;
+	}
+	catch ( std::exception const & ex ) { c->err = ex.what(); return -2; }
+#else
+	(void)v; (void)piles; (void)npiles; (void)ovl; (void)trace; (void)trace_bytes; (void)maxalign; (void)counts; (void)usable; (void)unusable; (void)prof; (void)deep; (void)out; (void)cap; (void)ndeep;
+	return -9;
+#endif
 }
 
 }

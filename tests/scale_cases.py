@@ -23,6 +23,11 @@ CASES = {
     # with a larger genome and longer reads than config 2
     "cfg3": dict(genome_len=7000000, nreads=10000, read_len=14000, seed=7, synth={}, first=4000, npiles=100,
                  params=[dict(k=14)]),
+    # config 3 at its TRUE scale (round 4): a 140 Mbase genome at 20x = 280 000 reads of 10 kb (a 700 MB 2-bit read store on the
+    # device, B reads from all over it); overlaps and piles only for 100 A reads in the middle (SynthData aread_range: the records
+    # are those of the full set), all of them selected
+    "cfg3b": dict(genome_len=140000000, nreads=280000, read_len=10000, seed=9, synth={}, first=0, npiles=100, aread_range=[140000, 140100],
+                  params=[dict(k=14)]),
     # config 4 shape again, 200 piles of a 54x set (cfg4 above is a 50-pile slice)
     "cfg4b": dict(genome_len=222222, nreads=1200, read_len=10000, seed=14, synth={}, first=500, npiles=200,
                   params=[dict(k=14)]),
@@ -40,7 +45,8 @@ CASES = {
 
 def make_case(case, pile_select):
     from daccord_amd.synth import SynthData
-    d = SynthData(case["genome_len"], case["nreads"], case["read_len"], seed=case["seed"], **case["synth"])
+    extra = dict(aread_range=tuple(case["aread_range"])) if case.get("aread_range") else {}
+    d = SynthData(case["genome_len"], case["nreads"], case["read_len"], seed=case["seed"], **extra, **case["synth"])
     ovl, piles = pile_select(d.ovl, d.piles)
     if "pile_ranges" in case:
         sel = np.concatenate([piles[a:b] for a, b in case["pile_ranges"]])

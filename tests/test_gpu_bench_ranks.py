@@ -39,3 +39,15 @@ def test_two_ranks_weak_and_strong_equal_one_rank():
     assert weak["parity"]["gpu_fasta_sha256_all"] == d1 and strong["parity"]["gpu_fasta_sha256_all"] == d1
     assert weak["config"]["corrected_bases_total"] == one["config"]["corrected_bases_total"] == strong["config"]["corrected_bases_total"]
     assert weak["config"]["piles_rank0"] == 120 and strong["config"]["piles_rank0"] == 120 and one["config"]["piles_rank0"] == 240
+
+
+def test_eight_ranks_on_one_device_weak():
+    """the shape of the driver's 8-GPU run (--gpus 8, weak scaling: --reads per rank) end to end on the one device of the test box:
+    eight ranks, -J g,8 sharding of one data set, gather in rank order, rank 0's digests and accuracy block; equals the N = 1 run over
+    the same 8 x 40 reads and reports which gather ran and how long rank 0 worked behind the timed loop"""
+    one = _run(1, 320, "weak")
+    eight = _run(8, 40, "weak")
+    assert eight["n_gpus"] == 8 and eight["ranks"] == 8 and eight["gather"] == "p2p" and one["gather"] is None
+    assert eight["parity"]["gpu_fasta_sha256_all"] == one["parity"]["gpu_fasta_sha256_all"]
+    assert eight["config"]["corrected_bases_total"] == one["config"]["corrected_bases_total"] and eight["config"]["piles_rank0"] == 40
+    assert eight["post_loop_s"] < 60 and "accuracy" in eight

@@ -42,11 +42,11 @@ def test_model_tables_are_bit_identical(prof):
 
 @pytest.mark.parametrize("k", [8, 12])
 def test_small_data_fasta_identical(small_data, k):
-    """the reference's own container (k in [3,12]): every pile of the small data set"""
+    """the reference's own container (k in [3,12]) on the small data set (all of it and more in profiles/r04_oracle_vs_ref_*.log)"""
     d, ovl, piles = small_data
     p = default_params(k=k)
     O, R = _pair(p, d)
-    n = len(piles) if k == 8 else 60
+    n = 80 if k == 8 else 24
     fo, bo = O.run(piles[:n], ovl, d.trace, nthreads=4)
     fr, br = R.run(piles[:n], ovl, d.trace, nthreads=4)
     assert len(fo) and pyoracle.fasta(fo, bo) == pyoracle.fasta(fr, br)
@@ -72,7 +72,7 @@ def test_config2_piles_at_k14():
     if not pyref.available(k16=True):
         pytest.skip("k16 build of oracle/_ref missing")
     from scale_cases import CASES, make_case
-    case = dict(CASES["cfg2"]); case["first"] = 5000; case["npiles"] = 6
+    case = dict(CASES["cfg2"]); case["first"] = 5000; case["npiles"] = 4
     d, ovl, piles, sel = make_case(case, pyoracle.pile_select)
     p = default_params(k=14)
     O, R = _pair(p, d)
@@ -81,9 +81,30 @@ def test_config2_piles_at_k14():
     assert len(bo) > 50000 and pyoracle.fasta(fo, bo) == pyoracle.fasta(fr, br)
 
 
+@pytest.mark.parametrize("kw,tspace,maxalign", [(dict(seed=1), 100, 2 ** 64 - 1), (dict(seed=7, ins_frac=1 / 3., del_frac=1 / 3., sub_frac=1 / 3.), 100, 6),
+                                                (dict(seed=3, erate=0.08), 200, 2 ** 64 - 1)])
+def test_error_profile_estimator_against_the_reference_functions(kw, tspace, maxalign):
+    """handleIndelEstimate<8> / handleIndelEstimateDeep<8> of the reference (src/daccord.cpp:271-995, cut out of the driver's
+    translation unit at build time) against oracle/o_eprof.hpp: counts, usable / unusable windows, rates, and the window error
+    rates of --deepprofileonly.  (This comparison found that the A window always joins the estimator's strings, round 4.)"""
+    from daccord_amd.synth import SynthData
+    d = SynthData(60000, 120, 3000, tspace=tspace, **kw)
+    ovl, piles = pyoracle.select_lowest(d.ovl, d.piles)
+    n = 30
+    p = default_params(k=8, tspace=tspace)
+    O = pyoracle.Oracle(p); O.load_db(d.bps, d.boff, d.rlen)
+    R = pyref.Reference(p); R.load_db(d.bps, d.boff, d.rlen)
+    co, uo, no, po = O.estimate_profile(piles[:n], ovl, d.trace, trace_bytes=d.trace_bytes, maxalign=maxalign)
+    cr, ur, nr, pr = R.estimate_profile(piles[:n], ovl, d.trace, trace_bytes=d.trace_bytes, maxalign=maxalign)
+    assert list(co) == list(cr) and (uo, no) == (ur, nr) and po == pr and uo > 50
+    do = O.deep_profile(piles[:n], ovl, d.trace, trace_bytes=d.trace_bytes, maxalign=maxalign)
+    dr = R.estimate_profile(piles[:n], ovl, d.trace, trace_bytes=d.trace_bytes, maxalign=maxalign, deep=True)[4]
+    assert len(do) == len(dr) and np.array_equal(do, dr)
+
+
 def test_random_parameter_sets():
     """a few rounds of scripts/fuzz_oracle_vs_ref.py (narrow and wide) inside the CPU suite"""
-    for args in (["20260922", "8"], ["4242", "4", "--wide"]):
+    for args in (["20260922", "5"], ["4242", "2", "--wide"]):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_oracle_vs_ref.py")] + args, capture_output=True, text=True, timeout=1500)
         assert out.returncode == 0 and "DONE bad=0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
