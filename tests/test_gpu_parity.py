@@ -70,6 +70,26 @@ def test_high_error_gap_filling_and_failures():
     assert frags_equal(fo, bo, fx, bx)
 
 
+@pytest.mark.parametrize("kw", [dict(k=8), dict(klow=8, khigh=10), dict(k=12, producefull=1), dict(k=14), dict(k=16, w=48, a=12)])
+def test_hip_equals_the_reference_build(small_data, kw):
+    """The HIP path against oracle/_ref directly: the reference's OWN HandleContext.hpp / DebruijnGraph.hpp / OffsetLikely.hpp ...
+    compiled (in the build container, unmodified) against the libmaus2 stand-in; the built library travels with the snapshot, the
+    sources do not.  k <= 12 runs the reference's own graph container, larger k our factory around its DebruijnGraph<k>."""
+    import pyref
+    p = default_params(**kw)
+    if not pyref.available(k16=(p.khigh > 12)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    d, ovl, piles = small_data
+    n = 24 if p.khigh <= 14 else 6          # (a DebruijnGraph<16> of the reference holds 16 GiB of node cache per context)
+    R = pyref.Reference(p); R.set_error_profile(*d.error_profile()); R.load_db(d.bps, d.boff, d.rlen)
+    E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    assert (R.tables(200) == E.tables(200)).all()
+    fr, br = R.run(piles[:n], ovl, d.trace, nthreads=(8 if p.khigh <= 12 else (4 if p.khigh <= 14 else 1)))
+    fx, bx = E(piles[:n], ovl, d.trace)
+    assert len(bx) > 1000 and frags_equal(fr, br, fx, bx) and engine.fasta(fx, bx) == pyoracle.fasta(fr, br)
+    E.close()
+
+
 @pytest.mark.parametrize("t0inst", ["0", "300", "488", "100000"])
 def test_size_class_threshold_does_not_change_results(small_data, t0inst, monkeypatch):
     """tier 0 (size classes, round 4): whatever share of the windows the pre-pass sends to the small tier -- none, some, all
