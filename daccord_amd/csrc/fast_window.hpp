@@ -256,7 +256,7 @@ struct FastLds<CT,false>
 	FLD(fmx,uint64_t,CT::fnc+1,e_ftm)
 	// recorded (path, entry) sequences of the pairs of a round
 	FLD(pout,typename CT::id_t,32*32,e_fmx)
-	FLD(poutn,uint8_t,32,e_pout)
+	FLD(poutn,uint8_t,64,e_pout)
 	FLD(ctr,uint32_t,4,e_poutn)
 	FLD(rchx,uint8_t,32,e_ctr)              // chunk ids of a reverse enumeration on lane 0 alone
 	static constexpr uint32_t upool = e_rchx;
@@ -397,7 +397,7 @@ struct FastLds<CT,true>
 	FLD(ftm,uint64_t,CT::fnc+1,e_ffm)
 	FLD(fmx,uint64_t,CT::fnc+1,e_ftm)
 	FLD(pout,typename CT::id_t,32*32,e_fmx)
-	FLD(poutn,uint8_t,32,e_pout)
+	FLD(poutn,uint8_t,64,e_pout)
 	FLD(ctr,uint32_t,4,e_poutn)
 	FLD(rchx,uint8_t,32,e_ctr)
 	static constexpr uint32_t upool = e_rchx;
@@ -2228,7 +2228,9 @@ struct FastEngine
 		FSTAT_ADD(18,1);
 		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
 		uint32_t conslen = 0;
+		uint64_t const tbs_ = pclock();
 		uint32_t const n = buildSeq(path,rp,cur,conslen);
+		pcount(24,pclock()-tbs_);      // profiling builds: cycles of the sequence walks (lane 0)
 		if ( n == ~0u ) return false;
 		// sequences are compared and copied as 64 bit words (a slot is FSEQCAP ids, 8 byte aligned; ids behind a sequence's
 		// length are never looked at): one round of loads instead of one per stretch
@@ -2305,7 +2307,10 @@ struct FastEngine
 	// as (path, current, left, right); weights are recomputed from the tables.  Returns the count or 0xFF if the heap
 	// is too small (the pair is then combined serially).
 	struct PSI { id_t path, current, left, right; };
-	enum { PSIQ = 20 };
+	// (round 4: 10 intervals per lane and 8 recorded pops per pair instead of 20 / 16, so that the same lane scratch and the same
+	// record area serve 64 pairs per round instead of 32: a window has 96 pairs on average, its lanes are the pairs; 0.24 % of the
+	// pairs have more than 10 matching intervals and are combined serially, a pair with more than 8 pops continues serially)
+	enum { PSIQ = 10, POUTE = 8 };
 	DEV uint64_t psiW(PSI const & e, ChunkList<FNW> const & FC, uint32_t const sbase) const { return L.fp_adj()[clSlot<FCH>(FC,e.path)] + L.rc_w()[L.rc_ord()[sbase+e.current]]; }
 	DEV uint32_t combineLane(ChunkList<FNW> const & FC, uint32_t const nfpop, uint32_t const sbase, uint32_t const nacc2, uint64_t const rfm, int64_t const lmin, int64_t const lmax,
 		uint32_t const maxfullpath, LDSQ PSI * H, LDSQ id_t * out, bool const prune, uint64_t const T0)
@@ -2333,6 +2338,7 @@ struct FastEngine
 				}
 			}
 		}
+		FSTAT_ADD(25,1); FSTAT_ADD(26,n > 8 ? 1u : 0u); FSTAT_ADD(27,n > 10 ? 1u : 0u); FSTAT_ADD(28,n > 12 ? 1u : 0u); FSTAT_ADD(29,n > 16 ? 1u : 0u); FSTAT_MX(30,n);
 		uint32_t cnt = 0;
 		for ( uint32_t numfullpath = 0; n && numfullpath < maxfullpath; ++numfullpath )
 		{
@@ -2340,6 +2346,8 @@ struct FastEngine
 			// the candidate heap was full with lightest weight T0 when the round began: as long as that still holds when
 			// the pair is offered, nothing from here on can enter (replayRound checks it and continues serially otherwise)
 			if ( prune && psiW(top,FC,sbase) <= T0 ) return cnt | 0x20;
+			// the record of a pair holds POUTE pops: the rest of this pair's sequence is produced serially at its place in the pair order
+			if ( cnt == POUTE ) return cnt | 0x10;
 			// pop
 			{
 				--n; PSI const last = H[n]; H[0] = last;
@@ -2568,7 +2576,8 @@ struct FastEngine
 	// pair into recorded (path, entry) sequences, and lane 0 offers those to the candidate heap in the reference's pair
 	// order.  A pair whose cached enumerations may be touched by the other k-mer's split (rare) is enumerated on its
 	// exact stretch set by lane 0 at its place in that order.
-	enum { NPL = 32, RPSTL = 32, PM_SKIP = 0xF0, PM_SERIAL = 0xF1, PM_EXACT = 0xE0 };
+	enum { NPL = 64, RPSTL = 32, PM_SKIP = 0xF0, PM_SERIAL = 0xF1, PM_EXACT = 0xE0 };
+	static_assert(sizeof(PSI)*PSIQ*NPL <= FastLds<CT>::lscrbytes && 2u*POUTE*NPL <= 32u*32u,"score interval heaps and pop records of a round of pairs");
 	enum : uint32_t { MIDCAP = 8 };
 	uint32_t nmid, midbase;              // middle pieces of this activation state: pool ids midbase .. midbase+nmid-1
 	uint32_t rstop;                      // sorted reverse entries used by the cached blocks
@@ -2638,14 +2647,16 @@ struct FastEngine
 				ChunkList<FNW> FC; forwardTreeLoad(FC,fi);
 				if ( mode < 0x40 )
 				{
-					uint32_t const cnt = mode & 0x1F; uint32_t pn;
-					bool const used = replayPair(FC,L.rbase()[li],L.pout() + 32*q,cnt,pn);
+					uint32_t const cnt = mode & 0x0F; uint32_t pn;
+					bool const used = replayPair(FC,L.rbase()[li],L.pout() + 2*POUTE*q,cnt,pn);
 					if ( flags ) return 0;
-					// a sequence cut at weight T0 is complete only while the candidate heap is full with a top of at least T0
-					if ( used && (mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0) )
+					// a sequence cut at weight T0 (0x20) is complete only while the candidate heap is full with a top of at least T0; one
+					// cut because the record was full (0x10) always goes on
+					if ( used && ( (mode & 0x10) || ((mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0)) ) )
+					{
 						pcount(21,1);
-					if ( used && (mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0) )
 						combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16,cnt,pn);
+					}
 				}
 				else { pcount(23,1); combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16); }
 				if ( flags ) return 0;
@@ -2856,7 +2867,7 @@ struct FastEngine
 					{
 						ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
 						uint32_t const cnt = combineLane(FC,L.fnp()[pfi],L.rbase()[pli],L.rn()[pli],L.rfmask()[pli],lmin,lmax,16,
-							reinterpret_cast<LDSQ PSI *>(L.lscr()) + PSIQ*t,L.pout() + 32*t,cfull,roundT0);
+							reinterpret_cast<LDSQ PSI *>(L.lscr()) + PSIQ*t,L.pout() + 2*POUTE*t,cfull,roundT0);
 						mode = cnt == 0xFF ? static_cast<uint32_t>(PM_SERIAL) : (cnt ? cnt : static_cast<uint32_t>(PM_SKIP));
 					}
 					L.poutn()[t] = mode;

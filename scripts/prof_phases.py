@@ -9,7 +9,7 @@ from daccord_amd.synth import SynthData
 NAMES = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors", "pair-gen (lanes)", "gapfill", "pair-replay (lane 0)",
          "stretches", "cand+tab+stretchfeas", "F trees (lanes)", "R blocks (lanes)", "tail", "cand-errors", "align+emit", "-",
          " candidates+pieces", " loadTab", " feas:ranges", " F:bucket scan+heap fill (lane 0)", " F:drain, pops+extensions (lane 0)"]
-EXTRA = {21: "cut sequences continued", 22: "exact pairs", 23: "serial combines", 25: "pairs", 26: "F batches", 27: "pair rounds", 28: "batch restarts"}
+EXTRA = {24: "buildSeq cycles (lane 0)", 21: "cut sequences continued", 22: "exact pairs", 23: "serial combines", 25: "pairs", 26: "F batches", 27: "pair rounds", 28: "batch restarts"}
 npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 d = SynthData(250000, 1000, 5000, seed=3)
 ovl, piles = engine.pile_select(d.ovl, d.piles)
