@@ -453,7 +453,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
 	int64_t long_hint;      // windows the second stream ran in the last pass of this context (-1: unknown): grid of k_window_long
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
@@ -528,7 +528,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release();
+	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release(); c->d_hand.release(); c->d_handctr.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
 	hipEventDestroy(c->evT0);
@@ -641,7 +641,7 @@ static int runDevice(dacc_ctx * c)
 				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
 			HIPCHK(hipEventRecord(c->evPrescan,s));
 			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
-			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0; FL.gslab = 0; FL.gstride = 0; FL.tab32 = c->d_tab32.p;
+			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0; FL.gslab = 0; FL.gstride = 0; FL.tab32 = c->d_tab32.p; FL.hand = 0; FL.handctr = 0; FL.handcap = 0; FL.handwords = 0;
 			if ( !c->tierL_ok ) FL.F.ldsbytes = 0;
 			// a launch the device refuses (the LDS of a whole CU) falls back to the generic engine alone, for good
 			auto const launchLong = [&](uint32_t const * const lst)
@@ -658,6 +658,7 @@ static int runDevice(dacc_ctx * c)
 			WB.pregen = c->d_pregen.p;
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_handctr.p,0,sizeof(uint32_t),s));
 			bool early = false;
 			HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s));
 			// capacity tiers: every tier takes the windows the previous one handed over (list = 0: all windows)
@@ -668,6 +669,7 @@ static int runDevice(dacc_ctx * c)
 				{
 					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p;
 					FB.gslab = c->d_gslab.p; FB.gstride = c->gstride[t]; FB.tab32 = c->d_tab32.p;
+					FB.hand = c->handcap ? c->d_hand.p : static_cast<uint64_t *>(0); FB.handctr = c->d_handctr.p; FB.handcap = c->handcap; FB.handwords = c->handwords;
 					// only the first tier feeds the early generic list (its kernel reads the list once, right after that tier): a
 					// window that reaches a later tier first (mao beyond the earlier tier) and turns out to be generic-only takes
 					// the ordinary hand-over chain to the generic kernel at the end
@@ -942,6 +944,20 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 				HIPCHK(c->d_small.ensure(BP.nwindows+2)); HIPCHK(c->d_big.ensure(BP.nwindows+2));
 				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg0)*F0.gbytes + 256));
 			}
+		}
+		{
+			// hand-over slots (sorted instances of a window that overflowed a tier's node table, picked up by the next tier): header +
+			// the instance capacity of the tiers that hand on + their last k-mer lists; as many slots as a third of the windows, within
+			// 16 GB (config 2: 1.6 M hand-overs of 10 M windows).  DACC_HAND=0 switches the mechanism off (every hand-over restarts).
+			char const * he = getenv("DACC_HAND");
+			c->handwords = (BP.deep ? 2048u + 128u : 1024u + 64u) + 4u;
+			uint64_t cap = BP.nwindows/3 + 4096; uint64_t const maxcap = (16ull<<30) / (static_cast<uint64_t>(c->handwords)*8ull);
+			if ( cap > maxcap ) cap = maxcap;
+			if ( he && he[0] == '0' ) cap = 0;
+			if ( c->par.klow != c->par.khigh ) cap = 0;
+			c->handcap = static_cast<uint32_t>(cap);
+			HIPCHK(c->d_handctr.ensure(4));
+			if ( cap ) HIPCHK(c->d_hand.ensure(static_cast<size_t>(cap)*c->handwords));
 		}
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);

@@ -511,6 +511,10 @@ struct FastBatch
 	uint8_t * gslab;            // gw tiers: global scratch, gstride bytes per workgroup (weights, spill of the build-phase arrays)
 	uint64_t gstride;
 	uint32_t const * tab32;     // gw tiers: [nsup+1][nrows+1] 32 bit copy of the fixed-point table, zero row / column at the end
+	// round 4: hand-over without restart.  A window that overflows a tier's node table leaves its sorted k-mer instances and last k-mer
+	// list in a slot of this buffer (handwords 64 bit words per slot: header {npre, nlast}, instances, last k-mers); the tier that picks
+	// the window up loads them instead of generating and sorting them again.  hand == 0: every hand-over restarts from the strings.
+	uint64_t * hand; uint32_t * handctr; uint32_t handcap, handwords;
 };
 
 // once per workgroup: the support bounds of the model table
@@ -2542,6 +2546,38 @@ struct FastEngine
 			for ( uint32_t i = lane; i < (nlast+1)/2; i += WSZ ) dst[CT::precap/2 + i] = sl[i];
 		}
 	}
+	// hand-over slots (FastBatch::hand): slot = number + 1, 0 = none.  A window keeps its slot from tier to tier (the instances of a k
+	// do not change), so only the first hand-over writes.
+	DEV uint32_t saveHand(FastBatch const & FB, uint32_t hslot)
+	{
+		if ( hslot ) return hslot;
+		if ( npre + 2u*((nlast+1)/2) + 4u > FB.handwords || npre > FB.handwords ) return 0;
+		uint32_t sl = 0;
+		if ( lane == 0 ) { uint32_t const q = wv_atomic_add_global(FB.handctr,1u); sl = q < FB.handcap ? q+1 : 0u; }
+		sl = wv_bcast(sl,0);
+		if ( !sl ) return 0;
+		uint64_t * const dst = FB.hand + static_cast<uint64_t>(sl-1)*FB.handwords;
+		if ( lane == 0 ) { dst[0] = npre | (static_cast<uint64_t>(nlast)<<32); dst[1] = k; }
+		uint32_t const po = 2, lo = 2 + ((npre+1)&~1u);
+		for ( uint32_t i = lane; i < npre; i += WSZ ) dst[po+i] = L.pre()[i];
+		for ( uint32_t i = lane; i < nlast; i += WSZ ) dst[lo+i] = L.lastk()[i];
+		return sl;
+	}
+	DEV bool loadHand(FastBatch const & FB, uint32_t const hslot)
+	{
+		uint64_t const * const src = FB.hand + static_cast<uint64_t>(hslot-1)*FB.handwords;
+		uint64_t const h0 = src[0];
+		uint32_t const n = static_cast<uint32_t>(h0), nl = static_cast<uint32_t>(h0>>32);
+		if ( n > CT::precap || nl > FastLds<CT>::keycap || src[1] != k ) return false;      // (cannot happen between the tiers of one batch)
+		npre = n; nlast = nl;
+		FSTAT_ADD(31,1);
+		uint32_t const po = 2, lo = 2 + ((n+1)&~1u);
+		wv_sync();
+		for ( uint32_t i = lane; i < n; i += WSZ ) L.pre()[i] = src[po+i];
+		for ( uint32_t i = lane; i < nl; i += WSZ ) L.lastk()[i] = src[lo+i];
+		wv_sync();
+		return true;
+	}
 	DEV void restoreInstances()
 	{
 		if constexpr ( GW )
@@ -3225,13 +3261,19 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	// that overflowed: with a single k the passes before it ended without a consensus and left no state behind
 	// (minrate, best), so the next tier starts at that pass instead of repeating them.
 	int32_t curff = B.P.maxff;
+	uint32_t hslot = 0;      // hand-over slot + 1 with the sorted instances of this window (FastBatch::hand), 0: none
+	bool const handable = FB.hand != 0 && B.P.klow == B.P.khigh && CT::gw != 0;
 	if ( resume && B.P.klow == B.P.khigh )
 	{
 		WindowOut const prev = B.wout[widx];
-		if ( prev.status == WS_RETRY && prev.filterfreq <= B.P.maxff && prev.filterfreq >= B.P.minff ) curff = prev.filterfreq;
+		if ( prev.status == WS_RETRY && prev.filterfreq <= B.P.maxff && prev.filterfreq >= B.P.minff )
+		{
+			curff = prev.filterfreq;
+			if ( handable && prev.minrate <= FB.handcap ) hslot = static_cast<uint32_t>(prev.minrate);
+		}
 	}
 	int32_t const startff = curff;
-	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); B.wout[widx].filterfreq = curff; } return ((code) == 1 || (code) == 4) ? FW_GENERIC : FW_NEXT; }
+	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); B.wout[widx].filterfreq = curff; B.wout[widx].minrate = hslot; } return ((code) == 1 || (code) == 4) ? FW_GENERIC : FW_NEXT; }
 
 	uint32_t lo = 0, hi = B.npiles;
 	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
@@ -3335,19 +3377,25 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh; ++k )
 		{
 			E.k = k; E.kmask = (1ull<<(2*k))-1;
-			bool instvalid = false, instsaved = false;
+			bool instvalid = false, instsaved = false, handloaded = false;
 			for ( int32_t ff = startff; ff >= B.P.minff; --ff )
 			{
 				curff = ff;
 				PROF_T0
 				// the sorted instances of this k are still in place when the pass before ended without a traversal; a pass that
 				// traversed has saved them to the slab first (gw tiers)
-				if ( !instvalid ) { if ( instsaved ) E.restoreInstances(); else E.buildInstances(); }
+				if ( !instvalid )
+				{
+					if ( instsaved ) E.restoreInstances();
+					else if ( !(hslot && !handloaded && E.loadHand(FB,hslot)) ) E.buildInstances();      // handed over by the tier before: no second sort
+					handloaded = true;
+				}
 				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only
 				PROF(E,2)
 				E.buildNodes(ff > 1 ? ff : 1);
 				E.flags = wv_or(E.flags);
-				if ( E.flags ) { FFAIL(7) }
+				// the node table does not fit this tier (82 % of tier 1's hand-overs): the instances are sorted and valid, the next tier takes them
+				if ( E.flags ) { if ( handable ) hslot = E.saveHand(FB,hslot); FFAIL(7) }
 				PROF(E,3)
 				// A pass cannot produce a candidate if no node holds position 0 of a string (no first k-mer) or no last k-mer
 				// candidate is a node (every reverse enumeration is empty): its three traversals (:2270-2322) are skipped.  The

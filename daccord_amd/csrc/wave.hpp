@@ -46,6 +46,7 @@
   static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
   static inline void atomicOrFlag(uint32_t * f) { *f |= 1u; }
   template<typename T> static inline T wv_atomic_add(T * p, T const v) { T const o = *p; *p = o + v; return o; }
+  static inline uint32_t wv_atomic_add_global(uint32_t * p, uint32_t const v) { uint32_t const o = *p; *p = o + v; return o; }
   template<typename F> static inline void wave_run(F const & f) { f(); }
   }
 #else
@@ -152,6 +153,8 @@
   DEV void atomicOrFlag(uint32_t * f) { atomicOr(f,1u); }
   // workgroup scope atomic add on an LDS (or global) word, returns the old value
   template<typename PT> DEV uint32_t wv_atomic_add(PT p, uint32_t const v) { return __hip_atomic_fetch_add(p,v,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_WORKGROUP); }
+  // device scope atomic add on a word in global memory (counters shared by all workgroups of a kernel)
+  DEV uint32_t wv_atomic_add_global(uint32_t * p, uint32_t const v) { return __hip_atomic_fetch_add(p,v,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT); }
   }
 #endif
 

@@ -155,6 +155,7 @@ static inline int dacc_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline void atomicOrFlag(uint32_t * f) { *f |= 1u; }
 // LDS / global atomics of the device code (lanes never run concurrently here)
 template<typename T> static inline T wv_atomic_add(T * p, T const v) { T const o = *p; *p = o + v; return o; }
+static inline uint32_t wv_atomic_add_global(uint32_t * p, uint32_t const v) { uint32_t const o = *p; *p = o + v; return o; }
 
 }
 #endif

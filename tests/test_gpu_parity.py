@@ -90,11 +90,14 @@ def test_hip_equals_the_reference_build(small_data, kw):
     E.close()
 
 
-@pytest.mark.parametrize("t0inst", ["0", "300", "488", "100000"])
+@pytest.mark.parametrize("t0inst", ["0", "300", "488", "100000", "100000/nohand"])
 def test_size_class_threshold_does_not_change_results(small_data, t0inst, monkeypatch):
     """tier 0 (size classes, round 4): whatever share of the windows the pre-pass sends to the small tier -- none, some, all
     that its string capacity admits -- the per-window records and the FASTA are the oracle's; what tier 0 cannot hold is handed on"""
     d, ovl, piles = small_data
+    if t0inst.endswith("/nohand"):
+        # hand-over without restart switched off (DACC_HAND=0): every window a tier hands on is sorted again by the next one
+        t0inst = t0inst.split("/")[0]; monkeypatch.setenv("DACC_HAND", "0")
     monkeypatch.setenv("DACC_T0INST", t0inst)
     O, E = _pair(d, k=14)
     fo, bo = O.run(piles[:30], ovl, d.trace, nthreads=8, want_windows=True); wo = O.windows()
