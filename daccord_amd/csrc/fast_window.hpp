@@ -80,7 +80,10 @@ template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 enum : uint32_t { T0INST_DEFAULT = 488 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
-template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 64, precap = 2048, ncap = 1024, scap = 232, lcap = 1280, wcap = 1536, rccap = 192, fcap = 128, siqcap = 96, blcap = 96 }; };
+// (round 4: 76 KB = 2 wavefronts per CU instead of 46.5 KB = 3, with tier 3's node capacity: at 54x more than half of what the deep tier
+// hands on has more than 1024 nodes at filter frequency 1 and used to go through this tier only to be handed on again to tier 3, which
+// runs one wavefront per CU)
+template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 2048, scap = 232, lcap = 2304, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96 }; };
 // tier 6 (second slot of SHALLOW batches since round 3, gw layout, 36 KB = 4 wavefronts per CU): what tier 1 hands on at 20x
 // are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
 // tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep
