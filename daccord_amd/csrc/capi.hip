@@ -957,7 +957,9 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			if ( c->par.klow != c->par.khigh ) cap = 0;
 			c->handcap = static_cast<uint32_t>(cap);
 			HIPCHK(c->d_handctr.ensure(4));
-			if ( cap ) HIPCHK(c->d_hand.ensure(static_cast<size_t>(cap)*c->handwords));
+			// (an optimisation only: if the device cannot spare the buffer, halve it, and in the end do without)
+			while ( cap && c->d_hand.ensure(static_cast<size_t>(cap)*c->handwords) != hipSuccess ) { (void)hipGetLastError(); cap = cap > 65536 ? cap/2 : 0; }
+			c->handcap = static_cast<uint32_t>(cap);
 		}
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);
