@@ -453,7 +453,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
 	int64_t long_hint;      // windows the second stream ran in the last pass of this context (-1: unknown): grid of k_window_long
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
@@ -499,7 +499,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	if ( hipSetDevice(p->device) != hipSuccess ) return DACC_ENODEV;
 	dacc_ctx * c = new (std::nothrow) dacc_ctx;
 	if ( !c ) return DACC_ENOMEM;
-	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->long_hint = -1;
+	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->long_hint = -1; c->handcap = 0; c->handwords = 0; c->handwant = 0; c->nruns = 0;
 	std::memset(&c->timing,0,sizeof(c->timing));
 	{
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
@@ -601,6 +601,15 @@ static int runDevice(dacc_ctx * c)
 {
 	BatchPlan & BP = c->BP;
 	hipStream_t const s = c->stream;
+	if ( c->nruns && c->handwant > c->handcap )
+	{
+		// second use of this context: now the hand-over buffer pays (dacc_submit_piles); an optimisation only -- if the device
+		// cannot spare it, halve it, and in the end do without
+		uint64_t cap = c->handwant;
+		while ( cap && c->d_hand.ensure(static_cast<size_t>(cap)*c->handwords) != hipSuccess ) { (void)hipGetLastError(); cap = cap > 65536 ? cap/2 : 0; }
+		c->handcap = static_cast<uint32_t>(cap); c->handwant = cap;
+	}
+	++c->nruns;
 	HIPCHK(hipMemsetAsync(c->d_err.p,0,4*sizeof(uint32_t),s));
 	HIPCHK(hipEventRecord(c->ev[0],s));
 	if ( BP.ovl.size() )
@@ -949,17 +958,19 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 			// hand-over slots (sorted instances of a window that overflowed a tier's node table, picked up by the next tier): header +
 			// the instance capacity of the tiers that hand on + their last k-mer lists; as many slots as a third of the windows, within
 			// 16 GB (config 2: 1.6 M hand-overs of 10 M windows).  DACC_HAND=0 switches the mechanism off (every hand-over restarts).
+			// The buffer is an optimisation for contexts that live: the driver clears device memory it hands out (16 GB = half a
+			// second on some boxes), which a single pass does not earn back, so the FIRST pass of a context runs without it and the
+			// buffer is allocated when the context is used again (runDevice).
 			char const * he = getenv("DACC_HAND");
 			c->handwords = (BP.deep ? 2048u + 128u : 1024u + 64u) + 4u;
 			uint64_t cap = BP.nwindows/3 + 4096; uint64_t const maxcap = (16ull<<30) / (static_cast<uint64_t>(c->handwords)*8ull);
 			if ( cap > maxcap ) cap = maxcap;
 			if ( he && he[0] == '0' ) cap = 0;
 			if ( c->par.klow != c->par.khigh ) cap = 0;
-			c->handcap = static_cast<uint32_t>(cap);
+			c->handwant = cap;
 			HIPCHK(c->d_handctr.ensure(4));
-			// (an optimisation only: if the device cannot spare the buffer, halve it, and in the end do without)
-			while ( cap && c->d_hand.ensure(static_cast<size_t>(cap)*c->handwords) != hipSuccess ) { (void)hipGetLastError(); cap = cap > 65536 ? cap/2 : 0; }
-			c->handcap = static_cast<uint32_t>(cap);
+			if ( c->d_hand.cap < static_cast<size_t>(cap)*c->handwords ) c->handcap = static_cast<uint32_t>(c->d_hand.cap / c->handwords);     // what an earlier batch left
+			else c->handcap = static_cast<uint32_t>(cap);
 		}
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);
