@@ -1,9 +1,12 @@
 /*
  * ORACLE (test infrastructure, not product code): CPU restatement of the error profile estimation,
- * src/daccord.cpp:271-631 (handleIndelEstimate<8>) and :1653-1878 (driver, rates).  PARITY UNPINNED like the rest of
- * oracle/: libmaus2's aligner, AlignmentStatistics and KmerRepeatDetector are not in the reference tree; their
- * semantics are recalled (KmerRepeatDetector(q).detect: true iff some q-mer occurs twice in the string;
- * AlignmentStatistics: counts of MATCH / MISMATCH / INS (second string only) / DEL (first string only) steps).
+ * src/daccord.cpp:271-631 (handleIndelEstimate<8>) and :1653-1878 (driver, rates).  PARITY: handleIndelEstimate<8> and
+ * handleIndelEstimateDeep<8> are pinned to the reference's own functions since round 4 (compiled into oracle/_ref from the lines
+ * of daccord.cpp where they lie; tests/test_oracle_vs_ref.py) -- that comparison corrected this file: the A window ALWAYS joins
+ * a window's strings.  The sampling loop around them (:1653-1755) and the libmaus2 primitives stay unpinned: libmaus2's aligner,
+ * AlignmentStatistics and KmerRepeatDetector are not in the reference tree; their semantics are recalled
+ * (KmerRepeatDetector(q).detect: true iff some q-mer occurs twice in the string; AlignmentStatistics: counts of MATCH /
+ * MISMATCH / INS (second string only) / DEL (first string only) steps).
  */
 #ifndef ORACLE_EPROF_HPP
 #define ORACLE_EPROF_HPP
