@@ -49,5 +49,8 @@ def test_wide_random_parameter_sets_match_oracle_digests(part):
         assert window_digest(w) == e["windows_sha256"], (e["i"], kw, data)
         assert hashlib.sha256(engine.fasta(fx, bx).encode()).hexdigest() == e["fasta_sha256"], (e["i"], kw, data)
         assert len(bx) == e["nbases"] and len(fx) == e["nfragments"]
+        # second pass over the resident batch (hand-over buffer active from the second use of a context on): same digests
+        E.rerun(); f2, b2 = E.collect(); w2 = E.debug_windows()
+        assert window_digest(w2) == e["windows_sha256"] and hashlib.sha256(engine.fasta(f2, b2).encode()).hexdigest() == e["fasta_sha256"], ("second pass", e["i"], kw, data)
         E.close()
     print("wide fuzz part %d: %d sets, %d windows, handed on per tier %s" % (part, len(sets), nwin, tiers.tolist()))

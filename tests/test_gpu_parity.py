@@ -288,6 +288,10 @@ def _random_configs(first, last, seed=20260921):
         print("fuzz seed %d config %d: %s %s windows %d handed on %s" % (seed, i, kw, data, t.nwindows, list(t.tier_out)))
         assert windows_equal(O.windows(), E.debug_windows()) == [], (seed, i, kw, data)
         assert frags_equal(fo, bo, fx, bx), (seed, i, kw, data)
+        # second pass over the resident batch: the hand-over buffer exists from the second use of a context on (round 4), so this
+        # is the pass in which the tiers load the sorted instances of the windows handed to them
+        E.rerun(); f2, b2 = E.collect()
+        assert frags_equal(fo, bo, f2, b2), ("second pass", seed, i, kw, data)
         E.close()
     print("fuzz total: %d windows, handed on per tier %s" % (nwin, tiers.tolist()))
 

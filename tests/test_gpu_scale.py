@@ -55,4 +55,8 @@ def test_scale_case_matches_oracle_digests(name):
         assert window_digest(w) == run["windows_sha256"], run["params"]
         assert len(bx) == run["nbases"] and len(fx) == run["nfragments"]
         assert hashlib.sha256(txt.encode()).hexdigest() == run["fasta_sha256"], run["params"]
+        # second pass over the resident batch: the tiers now load the sorted instances of the windows handed to them (the hand-over
+        # buffer exists from the second use of a context on)
+        E.rerun(); f2, b2 = E.collect()
+        assert hashlib.sha256(engine.fasta(f2, b2).encode()).hexdigest() == run["fasta_sha256"], ("second pass", run["params"])
         E.close()
