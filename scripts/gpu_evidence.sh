@@ -1,4 +1,4 @@
-# Round 4, GPU call 4 (evidence on the current build): full GPU suite, smoke, default bench with the CPU legs, PMC passes + diagnostics,
+# Evidence on the current build (rounds 4+; `gpurun --timeout 2400 -- 'bash scripts/gpu_evidence.sh <tag>'` -> gpurun_out/<tag>/, ~10 GPU minutes): full GPU suite, smoke, default bench with the CPU legs, PMC passes + diagnostics,
 # the bench line again quoting them, rocprof kernel stats of the same command, 54x / ONT / config-3-shape bench lines
 R=$GRAFT_REPO_ROOT; TAG=${1:-r04d}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 ( timeout 900 python -m pytest tests -x -q -m gpu -rs --durations=6 ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log

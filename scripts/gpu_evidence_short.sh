@@ -1,4 +1,4 @@
-# Round 4, last GPU call: evidence on the final sources (lazy hand-over buffer): a parity subset, the default bench line with the CPU legs,
+# Short form of scripts/gpu_evidence.sh (~6 GPU minutes): a parity subset, the default bench line with the CPU legs,
 # PMC passes + diagnostics, the bench line again quoting them, rocprof kernel stats of the same command
 R=$GRAFT_REPO_ROOT; TAG=${1:-r04q}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 ( timeout 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "size_class or windows_and_fragments or rerun or reference_build or golden" ) > $O/pytest_subset.log 2>&1; echo "pytest rc=$?" >> $O/pytest_subset.log; tail -n 3 $O/pytest_subset.log
