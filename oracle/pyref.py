@@ -55,6 +55,7 @@ def lib(k16=False):
         L.ref_run_piles.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int]
         L.ref_collect.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ref_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        L.ref_pile_select_lowest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.ref_estimate_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _libs[k16] = L
     return _libs[k16]
@@ -62,6 +63,20 @@ def lib(k16=False):
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def select_lowest(ovl, piles, maxinput=5000):
+    """The estimator's pile selection through the reference's own loop (src/daccord.cpp:1712-1742, :1758) for every pile."""
+    L = lib(False)
+    out = np.zeros(len(ovl), dtype=ovl.dtype); newp = piles.copy(); o = 0
+    for i, p in enumerate(piles):
+        n = C.c_uint64(0)
+        seg = np.ascontiguousarray(ovl[p["first_ovl"]:p["first_ovl"] + p["novl"]])
+        dst = np.zeros(max(len(seg), 1), dtype=ovl.dtype)
+        if L.ref_pile_select_lowest(_ptr(seg), len(seg), maxinput, _ptr(dst), C.byref(n)):
+            raise RuntimeError("oracle/_ref was built without the selection loop")
+        out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value
+    return out[:o].copy(), newp
 
 
 class Reference:

@@ -16,8 +16,13 @@ mkdir -p "$OUT"
 EXC="$OUT/.estimate_excerpt.$$.hpp"
 sed -n '271,995p' "$REF/daccord.cpp" > "$EXC"
 grep -q "^double handleIndelEstimate(" "$EXC" || { echo "ref_shim/build.sh: estimator not at the expected lines of daccord.cpp"; rm -f "$EXC"; exit 1; }
-trap 'rm -f "$EXC"' EXIT
-FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\""
+# ... and three more pieces of the same file: the two comparators of :997-1011, the heap order of the estimator's pile selection
+# (:1406-1412, a local struct of daccord()) and the selection loop itself (:1712-1742, the body that feeds on pdec->getNextOverlap)
+EXC2="$OUT/.cmp_excerpt.$$.hpp"; EXC3="$OUT/.pfg_excerpt.$$.hpp"; EXC4="$OUT/.sel_excerpt.$$.hpp"
+sed -n '997,1011p' "$REF/daccord.cpp" > "$EXC2"; sed -n '1406,1412p' "$REF/daccord.cpp" > "$EXC3"; sed -n '1712,1742p' "$REF/daccord.cpp" > "$EXC4"
+grep -q "^struct OverlapPosComparator" "$EXC2" && grep -q "struct PairFirstGreaterComp" "$EXC3" && head -1 "$EXC4" | grep -q "while ( pdec->getNextOverlap(OVL) )" || { echo "ref_shim/build.sh: selection code not at the expected lines of daccord.cpp"; rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4"; exit 1; }
+trap 'rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4"' EXIT
+FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\" -DDACC_REF_CMP_EXCERPT=\"$EXC2\" -DDACC_REF_PFG_EXCERPT=\"$EXC3\" -DDACC_REF_SEL_EXCERPT=\"$EXC4\""
 g++ $FLAGS -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref.so" "$HERE/ref_capi.cpp" &
 g++ $FLAGS -DDACC_REF_K16 -I"$HERE/k16" -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref_k16.so" "$HERE/ref_capi.cpp" &
 wait

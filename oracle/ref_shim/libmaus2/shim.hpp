@@ -843,7 +843,8 @@ struct Overlap
 	Path path;
 	uint32_t flags;
 	int32_t aread, bread;
-	Overlap() : flags(0), aread(0), bread(0) {}
+	uint64_t tag;      // (harness only: index of the record in the caller's array)
+	Overlap() : flags(0), aread(0), bread(0), tag(0) {}
 	bool isInverse() const { return flags & 1; }
 	double getErrorRate() const { return (path.aepos > path.abpos) ? static_cast<double>(path.diffs) / (path.aepos-path.abpos) : 0.0; }
 	uint64_t getNumErrors() const { return path.diffs; }

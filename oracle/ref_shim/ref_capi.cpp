@@ -25,6 +25,10 @@
 #if defined(DACC_REF_ESTIMATE_EXCERPT)
 #include DACC_REF_ESTIMATE_EXCERPT
 #endif
+#if defined(DACC_REF_CMP_EXCERPT) && defined(DACC_REF_PFG_EXCERPT)
+#include DACC_REF_CMP_EXCERPT      // struct OverlapPosComparator, OverlapErrorDescComparator (daccord.cpp:997-1011)
+#include DACC_REF_PFG_EXCERPT      // struct PairFirstGreaterComp (daccord.cpp:1406-1412)
+#endif
 #include "../../include/daccord_hip.h"
 #ifdef _OPENMP
 #include <omp.h>
@@ -319,6 +323,45 @@ int ref_estimate_profile(void * v, dacc_pile const * piles, uint64_t npiles, dac
 	catch ( std::exception const & ex ) { c->err = ex.what(); return -2; }
 #else
 	(void)v; (void)piles; (void)npiles; (void)ovl; (void)trace; (void)trace_bytes; (void)maxalign; (void)counts; (void)usable; (void)unusable; (void)prof; (void)deep; (void)out; (void)cap; (void)ndeep;
+	return -9;
+#endif
+}
+
+}
+extern "C" {
+
+// The estimator's pile selection, src/daccord.cpp:1696-1758: the records of one pile in file order through the reference's own
+// selection loop (:1712-1742, compiled from its lines: keep the lmaxinput lowest scores, a record that replaces another takes its
+// slot) and its sort by abpos (:1758).  out receives the selected records in the resulting order.
+int ref_pile_select_lowest(dacc_overlap const * in, uint64_t n, uint64_t lmaxinput, dacc_overlap * out, uint64_t * nout)
+{
+#if defined(DACC_REF_SEL_EXCERPT)
+	typedef libmaus2::dazzler::align::Overlap Overlap_t;
+	struct Feed
+	{
+		dacc_overlap const * in; uint64_t n, i;
+		bool getNextOverlap(Overlap_t & O)
+		{
+			if ( i == n ) return false;
+			dacc_overlap const & o = in[i];
+			O.aread = o.aread; O.bread = o.bread; O.flags = o.flags; O.path.abpos = o.abpos; O.path.aepos = o.aepos; O.path.bbpos = o.bbpos; O.path.bepos = o.bepos;
+			O.path.diffs = o.diffs; O.path.tlen = o.tlen; O.tag = i++;
+			return true;
+		}
+	} feed; feed.in = in; feed.n = n; feed.i = 0;
+	Feed * pdec = &feed;
+	if ( !lmaxinput ) { *nout = 0; return 0; }
+	libmaus2::util::FiniteSizeHeap< std::pair<uint64_t,uint64_t>, PairFirstGreaterComp > RH(lmaxinput);      // :1414-1418, :1696-1701
+	libmaus2::autoarray::AutoArray < Overlap_t > RO(lmaxinput);                                              // :1404, :1698-1703
+	Overlap_t OVL;
+	uint64_t f = 0;
+	#include DACC_REF_SEL_EXCERPT
+	std::sort(RO.begin(),RO.begin()+f,OverlapPosComparator());                                               // :1758
+	for ( uint64_t i = 0; i < f; ++i ) out[i] = in[RO[i].tag];
+	*nout = f;
+	return 0;
+#else
+	(void)in; (void)n; (void)lmaxinput; (void)out; (void)nout;
 	return -9;
 #endif
 }

@@ -101,6 +101,21 @@ def test_error_profile_estimator_against_the_reference_functions(kw, tspace, max
     assert len(do) == len(dr) and np.array_equal(do, dr)
 
 
+@pytest.mark.parametrize("maxinput", [5000, 40, 7, 1])
+def test_estimator_pile_selection_against_the_reference_loop(maxinput):
+    """src/daccord.cpp:1712-1742 + :1758 (keep the maxinput lowest error scores, a replacing record takes the slot of the one it
+    replaces, sort by abpos), compiled from its lines, against the oracle's and the product's restatements, record for record"""
+    from daccord_amd.synth import SynthData
+    from daccord_amd import io as dio
+    d = SynthData(60000, 200, 3000, seed=4)
+    oo, po = pyoracle.select_lowest(d.ovl, d.piles, maxinput=maxinput)
+    orf, pr = pyref.select_lowest(d.ovl, d.piles, maxinput=maxinput)
+    ox, px = dio.select_lowest(d.ovl, d.piles, maxinput=maxinput)
+    assert len(oo) == len(orf) == len(ox) and np.array_equal(po, pr) and np.array_equal(po, px)
+    assert oo.tobytes() == orf.tobytes() == ox.tobytes()
+    assert len(oo) < len(d.ovl) if maxinput < 20 else True
+
+
 def test_random_parameter_sets():
     """a few rounds of scripts/fuzz_oracle_vs_ref.py (narrow and wide) inside the CPU suite"""
     for args in (["20260922", "3"], ["22", "1", "--wide"]):      # (k = 14, 9, 8; a two-byte trace set; the k = 14...16 sets are in the profiles/ log)
