@@ -240,7 +240,8 @@ int oracle_window_consensus(void * v, uint8_t const * strings, uint32_t const * 
 // ascending (block,entry) order (:2216-2262), and std::sorts the pointers by abpos (:2284-2288).
 // Which block a record split across a 64 KiB boundary is attributed to is libmaus2
 // OverlapParser behaviour (not in /root/reference): we attribute it to the block in which its
-// last byte arrives -- unpinned for piles larger than 64 KiB.
+// last byte arrives.  PINNED: tests/test_oracle_vs_ref.py runs this function against :2026-2105 + :2120-2288 compiled from the
+// reference's lines (oracle/ref_shim/ref_select.cpp) over piles of up to 9 input blocks; only the parser's attribution stays assumed.
 namespace {
 struct OverlapEntry
 {

@@ -56,6 +56,7 @@ def lib(k16=False):
         L.ref_collect.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.ref_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.ref_pile_select_lowest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.ref_pile_select.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_estimate_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _libs[k16] = L
     return _libs[k16]
@@ -77,6 +78,23 @@ def select_lowest(ovl, piles, maxinput=5000):
             raise RuntimeError("oracle/_ref was built without the selection loop")
         out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value
     return out[:o].copy(), newp
+
+
+def pile_select(ovl, piles, trace_bytes=1, maxinput=5000, vard=0, rl=None, avgreadlength=1.0):
+    """The MAIN path's pile selection through the reference's own lines (src/daccord.cpp:2026-2105, :2120-2288: score heap with
+    keep-the-worst eviction, 64 KiB input blocks, copy order, sort by abpos) for every pile.  With vard the reference's own
+    lmaxinput formula (:2121-2126) is used with the A read lengths rl[i]; the lmaxinput values come back as third result."""
+    L = lib(False)
+    out = np.zeros(len(ovl), dtype=ovl.dtype); newp = piles.copy(); o = 0; lm = []
+    for i, p in enumerate(piles):
+        n = C.c_uint64(0); l = C.c_uint64(0)
+        seg = np.ascontiguousarray(ovl[p["first_ovl"]:p["first_ovl"] + p["novl"]])
+        dst = np.zeros(max(len(seg), 1), dtype=ovl.dtype)
+        rc = L.ref_pile_select(_ptr(seg), len(seg), trace_bytes, maxinput, vard, int(rl[i]) if rl is not None else 0, avgreadlength, _ptr(dst), C.byref(n), C.byref(l))
+        if rc:
+            raise RuntimeError("ref_pile_select: %d (-9: oracle/_ref built without the selection lines, -2: a copied record differs)" % rc)
+        out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value; lm.append(l.value)
+    return out[:o].copy(), newp, lm
 
 
 class Reference:

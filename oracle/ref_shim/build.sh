@@ -21,9 +21,14 @@ grep -q "^double handleIndelEstimate(" "$EXC" || { echo "ref_shim/build.sh: esti
 EXC2="$OUT/.cmp_excerpt.$$.hpp"; EXC3="$OUT/.pfg_excerpt.$$.hpp"; EXC4="$OUT/.sel_excerpt.$$.hpp"
 sed -n '997,1011p' "$REF/daccord.cpp" > "$EXC2"; sed -n '1406,1412p' "$REF/daccord.cpp" > "$EXC3"; sed -n '1712,1742p' "$REF/daccord.cpp" > "$EXC4"
 grep -q "^struct OverlapPosComparator" "$EXC2" && grep -q "struct PairFirstGreaterComp" "$EXC3" && head -1 "$EXC4" | grep -q "while ( pdec->getNextOverlap(OVL) )" || { echo "ref_shim/build.sh: selection code not at the expected lines of daccord.cpp"; rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4"; exit 1; }
-trap 'rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4"' EXIT
-FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\" -DDACC_REF_CMP_EXCERPT=\"$EXC2\" -DDACC_REF_PFG_EXCERPT=\"$EXC3\" -DDACC_REF_SEL_EXCERPT=\"$EXC4\""
-g++ $FLAGS -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref.so" "$HERE/ref_capi.cpp" &
-g++ $FLAGS -DDACC_REF_K16 -I"$HERE/k16" -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref_k16.so" "$HERE/ref_capi.cpp" &
+# ... and the MAIN path's pile selection (ref_select.cpp): :2026-2105 = the heap entry, its block order and the per-thread buffers (with the
+# 64 KiB input block size), :2120-2288 = the body of the loop over A reads from lmaxinput to the sort by abpos
+EXC5="$OUT/.mainsel_a_excerpt.$$.hpp"; EXC6="$OUT/.mainsel_b_excerpt.$$.hpp"
+sed -n '2026,2105p' "$REF/daccord.cpp" > "$EXC5"; sed -n '2120,2288p' "$REF/daccord.cpp" > "$EXC6"
+head -1 "$EXC5" | grep -q "struct OverlapEntry" && grep -q "inputbuffersize = 64\*1024" "$EXC5" && head -1 "$EXC6" | grep -q "uint64_t const rl = RL\[z-minaread\]" && tail -3 "$EXC6" | grep -q "OverlapDataInterfacePosComparator()" || { echo "ref_shim/build.sh: main pile selection not at the expected lines of daccord.cpp"; rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4" "$EXC5" "$EXC6"; exit 1; }
+trap 'rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4" "$EXC5" "$EXC6"' EXIT
+FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\" -DDACC_REF_CMP_EXCERPT=\"$EXC2\" -DDACC_REF_PFG_EXCERPT=\"$EXC3\" -DDACC_REF_SEL_EXCERPT=\"$EXC4\" -DDACC_REF_MAINSEL_A_EXCERPT=\"$EXC5\" -DDACC_REF_MAINSEL_B_EXCERPT=\"$EXC6\""
+g++ $FLAGS -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref.so" "$HERE/ref_capi.cpp" "$HERE/ref_select.cpp" &
+g++ $FLAGS -DDACC_REF_K16 -I"$HERE/k16" -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref_k16.so" "$HERE/ref_capi.cpp" "$HERE/ref_select.cpp" &
 wait
 ls -la "$OUT"

@@ -116,6 +116,61 @@ def test_estimator_pile_selection_against_the_reference_loop(maxinput):
     assert len(oo) < len(d.ovl) if maxinput < 20 else True
 
 
+def _selection_piles(seed, npiles, tbytes):
+    """piles in file order with many ties in score and abpos, trace lengths that make records of 60...400 bytes, sizes from 0 to a few
+    64 KiB input blocks (with records straddling the block ends)"""
+    from daccord_amd._structs import DaccOverlap, DaccPile
+    OVL_DTYPE, PILE_DTYPE = np.dtype(DaccOverlap), np.dtype(DaccPile)
+    rng = np.random.default_rng(seed)
+    sizes = [0, 1, 2, 3] + [int(x) for x in rng.integers(4, 2500, npiles - 4)]
+    ovl = np.zeros(sum(sizes), dtype=OVL_DTYPE); piles = np.zeros(len(sizes), dtype=PILE_DTYPE); o = 0; toff = 0
+    for i, n in enumerate(sizes):
+        piles[i]["aread"] = i; piles[i]["first_ovl"] = o; piles[i]["novl"] = n
+        seg = ovl[o:o + n]
+        ab = rng.integers(0, 40, n) * 100                                  # few distinct start positions: ties for the unstable sort
+        ln = rng.integers(1, 30, n) * 100
+        seg["aread"] = i; seg["bread"] = rng.integers(0, 1000, n); seg["flags"] = rng.integers(0, 2, n)
+        seg["abpos"] = ab; seg["aepos"] = ab + ln; seg["bbpos"] = rng.integers(0, 100, n); seg["bepos"] = seg["bbpos"] + ln
+        seg["diffs"] = (ln * rng.integers(0, 6, n)) // 20                  # six distinct error rates: ties in the heap
+        seg["tlen"] = 2 * rng.integers(10, 181, n) // tbytes
+        seg["trace_off"] = toff + np.concatenate([[0], np.cumsum(seg["tlen"][:-1])]) if n else 0
+        toff += int(seg["tlen"].sum()); o += n
+    return ovl, piles
+
+
+@pytest.mark.parametrize("maxinput,tbytes", [(5000, 1), (400, 1), (150, 2), (37, 1), (2, 2), (1, 1)])
+def test_main_pile_selection_against_the_reference_lines(maxinput, tbytes):
+    """src/daccord.cpp:2026-2105 + :2120-2288 (the MAIN path's selection: heap on the error score that evicts the LOWEST score when full,
+    survivors copied last-input-block-backwards then earlier blocks forwards, unstable sort by abpos), compiled from its lines, against
+    the oracle's restatement (oracle_pile_select) and the product's (dacc_pile_select), record for record.  The block parser under the
+    reference's lines is ours (ref_select.cpp: a straddling record belongs to the block its last byte arrives in)."""
+    from daccord_amd import engine
+    ovl, piles = _selection_piles(11 + maxinput, 40, tbytes)
+    oo, po = pyoracle.pile_select(ovl, piles, trace_bytes=tbytes, maxinput=maxinput)
+    orf, pr, _ = pyref.pile_select(ovl, piles, trace_bytes=tbytes, maxinput=maxinput)
+    ox, px = engine.pile_select(ovl, piles, trace_bytes=tbytes, maxinput=maxinput)
+    assert np.array_equal(po, pr) and np.array_equal(po, px)
+    assert oo.tobytes() == orf.tobytes() == ox.tobytes()
+    assert (len(oo) < len(ovl)) == (maxinput < 2400)
+    # piles larger than one input block were among them
+    sz = 40 * piles["novl"] + np.array([int(ovl["tlen"][p["first_ovl"]:p["first_ovl"] + p["novl"]].sum()) * tbytes for p in piles])
+    assert (sz > 3 * 65536).any() and (sz < 65536).any()
+
+
+def test_main_pile_selection_vard_formula():
+    """--vard: the reference's per-read cap lmaxinput (src/daccord.cpp:2121-2126, computed by its own lines) equals the product's
+    (daccord_hip_main.cpp: the same expression), and the selection under it equals the oracle's"""
+    ovl, piles = _selection_piles(5, 12, 1)
+    rl = [0, 1, 10, 999, 5000, 10000, 12345, 20000, 40000, 7, 9999, 100001]
+    for vard, avg in ((10, 10000.0), (3, 7777.5), (1, 1.0)):
+        orf, pr, lm = pyref.pile_select(ovl, piles, maxinput=5000, vard=vard, rl=rl, avgreadlength=avg)
+        mine = [max(max(2 * vard, 1), int((2.0 * float(vard) * float(r) / float(avg)) + 0.5)) for r in rl]
+        assert lm[:len(mine)] == mine[:len(lm)]
+        for i, p in enumerate(piles):
+            oo, po = pyoracle.pile_select(ovl, piles[i:i + 1], maxinput=mine[i])
+            assert oo.tobytes() == orf[pr[i]["first_ovl"]:pr[i]["first_ovl"] + pr[i]["novl"]].tobytes()
+
+
 def test_random_parameter_sets():
     """a few rounds of scripts/fuzz_oracle_vs_ref.py (narrow and wide) inside the CPU suite"""
     for args in (["20260922", "3"], ["22", "1", "--wide"]):      # (k = 14, 9, 8; a two-byte trace set; the k = 14...16 sets are in the profiles/ log)
