@@ -64,6 +64,57 @@ def respawn(args):
     return subprocess.call(cmd, env=env)
 
 
+def pmc_lookup(dom, reads, readlen, coverage, k):
+    """What the committed PMC summaries (profiles/*_pmc_summary.json, scripts/gpu_pmc.sh) say about kernel `dom` on this workload and
+    THIS build: roofline keys (traffic, issue fractions, diagnostics) or only a pmc_source that says why there are none.  A summary
+    counts when its device sources are this build's (csrc_hash) or, failing that, for the kernels whose gfx950 instruction stream is
+    identical in this build (kernel_isa); kernels that changed since are left out of the per-kernel numbers."""
+    roof = {}
+    try:
+        import glob
+        from daccord_amd import build as _build
+        cur = _build.csrc_hash(); isa = None
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+            pm = json.load(open(fn))
+            wl = pm["workload"]
+            if (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) != (reads, readlen, coverage, k) or dom not in pm["kernels"]:
+                continue
+            same_src = pm.get("csrc_hash") == cur
+            if same_src:
+                valid = set(pm["kernels"])
+            else:
+                if isa is None:
+                    isa = _build.kernel_isa_hashes()
+                valid = set(kn for kn, h in pm.get("kernel_isa", {}).items() if isa.get(kn) == h)
+            if dom not in valid:
+                continue
+            kern = {kn: v for kn, v in pm["kernels"].items() if kn in valid}
+            kk = kern[dom]
+            roof["traffic"] = int(kk["traffic_bytes_per_launch"])
+            for key in ("valu_issue_frac", "salu_issue_frac", "lds_issue_frac", "wait_frac", "resident_waves_per_cu", "pmc_kernel_ms"):
+                if key in kk:
+                    roof[key] = kk[key]
+            dg = kk.get("diagnostics", {})
+            for key in ("valu_lane_util", "inflight_share", "tcc_hit_rate", "tcp_tcc_read_latency_cycles", "active_scalar_frac", "lds_bank_conflict"):
+                if key in dg:
+                    roof[key] = dg[key]
+            roof["resident_waves_per_cu_by_kernel"] = {kn: v.get("resident_waves_per_cu") for kn, v in kern.items() if v.get("resident_waves_per_cu")}
+            roof["traffic_all_kernels"] = {kn: int(v["traffic_bytes_per_launch"]) for kn, v in kern.items()}
+            roof["pmc_source"] = ("NOT measured in this run: constants read from profiles/%s, collected by scripts/gpu_pmc.sh (separate rocprofv3 --pmc "
+                                  "passes, traffic = 2*FETCH_SIZE + WRITE_SIZE) on this workload and on %s; "
+                                  "lane utilisation / in-flight shares / L2 hit rate from a %s-read slice of the same workload"
+                                  % (os.path.basename(fn), ("the very device sources of this build (csrc %s)" % cur) if same_src else
+                                     ("kernels whose gfx950 instruction stream is identical in this build (kernel_isa of %s; sources then csrc %s, now %s: "
+                                      "kernels that changed since are left out of the per-kernel numbers)" % (", ".join(sorted(valid)), pm.get("csrc_hash"), cur)),
+                                     pm.get("diagnostics_workload_reads", "?")))
+            break
+        else:
+            roof["pmc_source"] = "none for this build (csrc %s): traffic is null until scripts/gpu_pmc.sh has run on it" % cur
+    except Exception as ex:
+        roof["pmc_source"] = "error while reading the PMC summaries: %r" % (ex,)
+    return roof
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -186,36 +237,10 @@ def main():
                 "windows_on_second_stream": int(getattr(t, "long_windows", 0))}
         # HBM traffic and issue counters of the dominant kernel from the PMC passes (rocprofv3 --pmc, separate runs,
         # scripts/gpu_pmc.sh -> profiles/<round>_pmc_summary.json): quoted only when they were collected on this very
-        # workload AND on the very kernel sources this build was made from (csrc_hash) -- never stale counters
-        try:
-            import glob
-            from daccord_amd import build as _build
-            cur = _build.csrc_hash()
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
-                pm = json.load(open(fn))
-                wl = pm["workload"]
-                if pm.get("csrc_hash") != cur or (wl["reads"], wl["readlen"], wl["coverage"], wl["k"]) != (args.reads, args.readlen, args.coverage, args.k) or dom not in pm["kernels"]:
-                    continue
-                kk = pm["kernels"][dom]
-                roof["traffic"] = int(kk["traffic_bytes_per_launch"])
-                for key in ("valu_issue_frac", "salu_issue_frac", "lds_issue_frac", "wait_frac", "resident_waves_per_cu", "pmc_kernel_ms"):
-                    if key in kk:
-                        roof[key] = kk[key]
-                dg = kk.get("diagnostics", {})
-                for key in ("valu_lane_util", "inflight_share", "tcc_hit_rate", "tcp_tcc_read_latency_cycles", "active_scalar_frac", "lds_bank_conflict"):
-                    if key in dg:
-                        roof[key] = dg[key]
-                roof["resident_waves_per_cu_by_kernel"] = {k: v.get("resident_waves_per_cu") for k, v in pm["kernels"].items() if v.get("resident_waves_per_cu")}
-                roof["traffic_all_kernels"] = {k: int(v["traffic_bytes_per_launch"]) for k, v in pm["kernels"].items()}
-                roof["pmc_source"] = ("NOT measured in this run: constants read from profiles/%s, collected by scripts/gpu_pmc.sh (separate rocprofv3 --pmc "
-                                      "passes, traffic = 2*FETCH_SIZE + WRITE_SIZE) on this workload and on the very device sources of this build (csrc %s); "
-                                      "lane utilisation / in-flight shares / L2 hit rate from a %s-read slice of the same workload"
-                                      % (os.path.basename(fn), cur, pm.get("diagnostics_workload_reads", "?")))
-                break
-            else:
-                roof["pmc_source"] = "none for this build (csrc %s): traffic is null until scripts/gpu_pmc.sh has run on it" % cur
-        except Exception:
-            pass
+        # workload AND on the very kernels this build runs -- never stale counters.  "The very kernels": the device sources are the
+        # same (csrc_hash), or the machine code of the kernel is (kernel_isa: instruction-stream hash per kernel, build.kernel_isa_hashes;
+        # a change to the generic engine leaves the code of the LDS tiers as it was).  Per-kernel numbers are quoted for unchanged kernels only.
+        roof.update(pmc_lookup(dom, args.reads, args.readlen, args.coverage, args.k))
         res = {
             "metric": "corrected Mbase/s (whole node), synthetic 20x PacBio piles",
             "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),

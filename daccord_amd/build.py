@@ -32,6 +32,42 @@ def csrc_hash():
     return h.hexdigest()[:16]
 
 
+def kernel_isa_hashes(lib=None):
+    """{kernel name: SHA-256 (16 hex digits) of its gfx950 instruction stream} of the code object inside the built library
+    (llvm-objdump --offloading, then -d per kernel symbol; addresses and encodings left out, mnemonics and operands kept).
+    A finer identity than csrc_hash(): a change to ONE kernel's sources (say the generic engine) leaves the machine code of
+    the others as it was, and counters collected on those stay valid -- bench.py accepts a PMC summary on either identity.
+    Returns {} when the tools are missing."""
+    import hashlib, re, shutil, tempfile
+    lib = lib or LIB
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(lib) and os.path.exists(objdump)):
+        return {}
+    d = tempfile.mkdtemp(prefix="dacc_isa_")
+    try:
+        t = os.path.join(d, "lib.so"); shutil.copy(lib, t)
+        subprocess.run([objdump, "--offloading", t], check=True, capture_output=True, cwd=d)
+        co = [os.path.join(d, f) for f in os.listdir(d) if "gfx950" in f]
+        if not co:
+            return {}
+        syms = [l.split()[-1] for l in subprocess.run([objdump, "-t", co[0]], check=True, capture_output=True, text=True).stdout.splitlines() if " F .text" in l]
+        out = {}
+        for sym in syms:
+            dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", "--disassemble-symbols=" + sym, co[0]], check=True, capture_output=True, text=True).stdout
+            ins = [m.group(1) for m in (re.match(r"^\s+(\S.*?)\s*//\s*[0-9A-Fa-f]+:.*$", l) for l in dis.splitlines()) if m]
+            # _Z<len><name>[ILi<N>EE...]: the kernels are plain functions or templates over one int (no tool needed to read that)
+            m = re.match(r"^_Z(\d+)", sym); name = sym
+            if m:
+                n = int(m.group(1)); rest = sym[m.end():]; name = rest[:n]
+                t = re.match(r"^ILi(\d+)EE", rest[n:])
+                if t:
+                    name += "<%s>" % t.group(1)
+            out[name] = hashlib.sha256("\n".join(ins).encode()).hexdigest()[:16]
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def _newer(target, srcs):
     return (not os.path.exists(target)) or os.path.getmtime(target) < max(os.path.getmtime(s) for s in srcs)
 

@@ -58,7 +58,7 @@ HDEV uint64_t arena_align(uint64_t o) { return (o + 15) & ~static_cast<uint64_t>
 #define DACC_CARVE(field,type,count) A.field = reinterpret_cast<type *>(base + o); o = arena_align(o + sizeof(type)*static_cast<uint64_t>(count));
 
 // carve the arena; returns total bytes (call with base = 0 to size it)
-HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C)
+HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C, uint32_t const w = 0)
 {
 	uint64_t o = 0;
 	uint32_t const keycap = next_pow2(C.maxs < 2 ? 2 : C.maxs);
@@ -154,10 +154,12 @@ HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C)
 	DACC_CARVE(ane,uint64_t,C.nodecap*4)
 	DACC_CARVE(tmpw,double,256)
 	DACC_CARVE(tmpp,uint32_t,256)
-	DACC_CARVE(alpv,uint64_t,MAXCONS+1)
-	DACC_CARVE(almv,uint64_t,MAXCONS+1)
-	DACC_CARVE(albot,uint16_t,MAXCONS+1)
-	DACC_CARVE(alops,uint8_t,2*MAXCONS+2*64+8)
+	// consensus -> A alignment: one column of vertical deltas per consensus symbol (two words per column for w in 65..128)
+	uint32_t const alcons = DACC_MAXCONS_OF(w), alw = DACC_WIDE_W(w) ? 2u : 1u;
+	DACC_CARVE(alpv,uint64_t,alw*(alcons+1))
+	DACC_CARVE(almv,uint64_t,alw*(alcons+1))
+	DACC_CARVE(albot,uint16_t,alcons+1)
+	DACC_CARVE(alops,uint8_t,2*alcons+2*64*alw+8)
 	return o;
 }
 

@@ -33,10 +33,10 @@ static inline void windowIv(uint64_t const l, uint64_t const a, uint64_t const w
 }
 
 // larger scratch capacities for the generic engine after a window reported WS_OVERFLOW (dense graphs at small k)
-static inline void growArenaCaps(ArenaCaps & c)
+static inline void growArenaCaps(ArenaCaps & c, uint32_t const w = 0)
 {
 	c.precap *= 2; c.nodecap *= 2;        // stays a power of two (bitonic sorts)
-	c.fcap *= 4; c.strcap *= 2; c.linkcap *= 4; c.sfcap *= 4; c.rlcap *= 4; c.poolcap *= 4; c.conscap = 4*(c.conscap-MAXCONS) + MAXCONS;
+	c.fcap *= 4; c.strcap *= 2; c.linkcap *= 4; c.sfcap *= 4; c.rlcap *= 4; c.poolcap *= 4; c.conscap = 4*(c.conscap-DACC_MAXCONS_OF(w)) + DACC_MAXCONS_OF(w);
 	c.blcap *= 2;                         // base lengths of the enumerated paths (long window strings make long paths)
 }
 
@@ -186,7 +186,11 @@ struct BatchPlan
 		// strings per window of the generic engine: as deep as the batch is, up to 8192 (the default -D keeps 5000 overlaps
 		// per read; the number of wavefronts is bounded by the arena budget, capi.hip: boundByArena)
 		caps.maxs = std::max<uint32_t>(2,static_cast<uint32_t>(std::min<uint64_t>(depthcap,8192)));
-		caps.precap = hostNextPow2(std::max<uint32_t>(256,std::max<uint32_t>(caps.maxs*72,maxdepth+1)));
+		// k-mer instances per string: 72 covers the windows the LDS tiers take (w <= 63 and the usual B strings); a wide window
+		// (w in 65..128) has w-k+1 instances in its A string and about as many per B string (maxspan bounds them), so its first
+		// capacities are sized for that instead of being grown by the overflow retry for most windows of the batch
+		uint32_t const perstr = DACC_WIDE_W(par.w) ? static_cast<uint32_t>(std::min<uint64_t>(LSTRMAX,std::max<uint64_t>(72,std::max<uint64_t>(par.w,maxspan)))) : 72u;
+		caps.precap = hostNextPow2(std::max<uint32_t>(256,std::max<uint32_t>(caps.maxs*perstr,maxdepth+1)));
 		caps.nodecap = caps.precap;
 		caps.fcap = caps.nodecap*24;
 		caps.strcap = 2*caps.precap;
@@ -195,7 +199,7 @@ struct BatchPlan
 		caps.rlcap = 2*caps.strcap;
 		caps.poolcap = 8192;
 		caps.blcap = 256;
-		caps.conscap = 32768 + MAXCONS;
+		caps.conscap = 32768 + DACC_MAXCONS_OF(par.w);
 		// string stride of the generic engine: what the longest possible B window string needs (LSTR for ordinary data:
 		// two blocks of a hundred bases; more only for badly aligned blocks), a multiple of 64, at most LSTRMAX
 		caps.lstr = static_cast<uint32_t>(std::min<uint64_t>(LSTRMAX,std::max<uint64_t>(LSTR,(maxspan+63)&~static_cast<uint64_t>(63))));

@@ -297,7 +297,7 @@ __device__ __forceinline__ VoteTile vote_stage(VoteBatch const & B, DevPile cons
 	uint32_t const ylo = (p0 > w) ? ((p0-w + a-1)/a) : 0;
 	uint32_t yhi = plast / a; if ( yhi > nwin-1 ) yhi = nwin-1;
 	__syncthreads();      // the previous tile's readers are done
-	if ( ylo <= yhi && yhi-ylo+1 <= VOTE_STAGE )
+	if ( ylo <= yhi && yhi-ylo+1 <= VOTE_STAGE && !DACC_WIDE_W(w) )      // (wide records, w > 64, are read where they lie)
 	{
 		VT.y0 = ylo; VT.n = yhi-ylo+1;
 		uint4 const * src = reinterpret_cast<uint4 const *>(B.wrec + (pile.winbase+ylo)*WREC);
@@ -490,7 +490,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 {
 	if ( !out || !p ) return DACC_EINVAL;
 	*out = 0;
-	if ( p->klow < 3 || p->khigh > 16 || p->klow > p->khigh || !p->w || !p->a || p->w > 64 || p->minfilterfreq < 0 ||
+	if ( p->klow < 3 || p->khigh > 16 || p->klow > p->khigh || !p->w || !p->a || p->w > DACC_WMAX || p->minfilterfreq < 0 ||
 	     p->maxfilterfreq < p->minfilterfreq || p->tspace <= 0 )
 		return DACC_EINVAL;
 	int ndev = 0;
@@ -601,6 +601,9 @@ static int runDevice(dacc_ctx * c)
 {
 	BatchPlan & BP = c->BP;
 	hipStream_t const s = c->stream;
+	// DACC_DEBUG_SYNC=1: wait for every kernel of the generic-only path and say so on stderr (a device fault then names its kernel)
+	static bool const dbgsync = getenv("DACC_DEBUG_SYNC") && getenv("DACC_DEBUG_SYNC")[0] == '1';
+	auto const mark = [&](char const * what) { if ( dbgsync ) { hipError_t const e = hipStreamSynchronize(s); std::fprintf(stderr,"[dacc] %s: %s\n",what,hipGetErrorString(e)); std::fflush(stderr); } };
 	if ( c->nruns && c->handwant > c->handcap )
 	{
 		// second use of this context: now the hand-over buffer pays (dacc_submit_piles); an optimisation only -- if the device
@@ -628,6 +631,7 @@ static int runDevice(dacc_ctx * c)
 		else if ( c->tr_words == 4 ) hipLaunchKernelGGL(k_trace_wide<4>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
 		else hipLaunchKernelGGL(k_trace_wide<8>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
 	}
+	mark("prep + trace");
 	HIPCHK(hipEventRecord(c->ev[1],s));
 	if ( BP.nwindows )
 	{
@@ -729,7 +733,7 @@ static int runDevice(dacc_ctx * c)
 			HIPCHK(hipStreamWaitEvent(s,c->evEarlyGeneric,0));
 		}
 		else
-			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0)); }
+			{ HIPCHK(hipMemsetAsync(c->d_work.p,0,64*sizeof(uint32_t),s)); hipLaunchKernelGGL(k_window,dim3(c->win_grid),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(0),(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0)); mark("k_window (all windows)"); }
 	}
 	HIPCHK(hipEventRecord(c->ev[2],s));
 	uint32_t herr[4] = {0,0,0,0};
@@ -745,7 +749,9 @@ static int runDevice(dacc_ctx * c)
 			VB.P = c->P; VB.bps = c->d_bps.p; VB.boff = c->d_boff.p; VB.rlen = c->d_rlen.p; VB.piles = c->d_piles.p; VB.npiles = BP.piles.size();
 			VB.wrec = c->d_wrec.p; VB.has = c->d_has.p; VB.ld0 = c->d_ld0.p; VB.oc = c->d_oc.p; VB.ocs = c->d_ocs.p; VB.outsym = c->d_outsym.p;
 			VB.frags = c->d_frags.p; VB.fragbase = c->d_fragbase.p; VB.nfrag = c->d_nfrag.p; VB.errflag = c->d_err.p + 1; VB.pilebad = c->d_pilebad.p;
+			mark("k_check_done");
 			hipLaunchKernelGGL(k_vote,dim3(BP.piles.size()),dim3(256),0,s,VB);
+			mark("k_vote");
 		}
 		HIPCHK(hipEventRecord(c->ev[3],s));
 		HIPCHK(hipGetLastError());
@@ -784,8 +790,8 @@ static int runDevice(dacc_ctx * c)
 	// windows again, then the vote (rare; the capacities stay grown for the rest of the batch geometry)
 	for ( int attempt = 0; herr[0] && !herr[1] && !herr[2] && attempt < 3; ++attempt )
 	{
-		growArenaCaps(BP.caps);
-		Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
+		growArenaCaps(BP.caps,c->par.w);
+		Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps,c->par.w);
 		uint32_t const g = boundByArena(c->retry_grid < 64 ? c->retry_grid : 64,BP.caps.bytes,4);
 		c->retry_grid = g; c->win_grid = g; if ( c->early_grid > g ) c->early_grid = g;     // later launches of this batch use the grown arenas
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(g)*BP.caps.bytes));
@@ -794,11 +800,14 @@ static int runDevice(dacc_ctx * c)
 		HIPCHK(hipMemsetAsync(c->d_err.p,0,4*sizeof(uint32_t),s));
 		HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
 		hipLaunchKernelGGL(k_collect_overflow,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_gearly.p);
+		mark("k_collect_overflow");
+		if ( dbgsync ) std::fprintf(stderr,"[dacc] scratch retry %d: grid %u, arena %llu bytes per wavefront\n",attempt,g,static_cast<unsigned long long>(BP.caps.bytes));
 		WindowBatch WB;
 		WB.P = c->P; WB.T = c->T; WB.C = BP.caps; WB.bps = c->d_bps.p; WB.boff = c->d_boff.p; WB.rlen = c->d_rlen.p;
 		WB.piles = c->d_piles.p; WB.npiles = BP.piles.size(); WB.ovl = c->d_ovl.p; WB.wt_b = c->d_wt_b.p; WB.wt_e = c->d_wt_e.p;
 		WB.nwindows = BP.nwindows; WB.wrec = c->d_wrec.p; WB.wout = c->d_wout.p; WB.arena = c->d_arena.p; WB.prof = 0; WB.pregen = 0;
 		hipLaunchKernelGGL(k_window,dim3(g),dim3(64),0,s,WB,c->d_err.p,static_cast<uint32_t const *>(c->d_gearly.p),static_cast<uint32_t *>(0));
+		mark("k_window (scratch retry)");
 		int const rc = voteAndFetch(); if ( rc ) return rc;
 	}
 	c->pile_status = BP.pile_status; c->pile_errors = BP.pile_errors;
@@ -909,7 +918,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		}
 	}
 	// window kernel geometry + arenas
-	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps);
+	Arena Atmp; BP.caps.bytes = arena_carve(Atmp,0,BP.caps,c->par.w);
 	uint64_t wg = ((BP.nwindows+7)/8)*8;
 	uint64_t const maxwg = 256*8;
 	if ( wg > maxwg ) wg = maxwg;
@@ -918,7 +927,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		c->usefast = !c->env_nofast;
 		c->sched = c->env_sched;
 		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
-		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP ) c->usefast = 0;
+		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP || c->par.w > 63 ) c->usefast = 0;     // (w = 64 and the wide windows, 65..128: generic engine)
 	}
 	if ( c->usefast )
 	{
@@ -995,7 +1004,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->win_grid)*BP.caps.bytes));
 	}
-	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*WREC)); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
+	HIPCHK(c->d_wrec.ensure((BP.nwindows+1)*static_cast<size_t>(DACC_WREC_OF(c->par.w)))); HIPCHK(c->d_wout.ensure(BP.nwindows+1));
 	HIPCHK(c->d_has.ensure(BP.npos+1)); HIPCHK(c->d_oc.ensure(BP.npos+1)); HIPCHK(c->d_ld0.ensure(BP.npos+1)); HIPCHK(c->d_ocs.ensure(BP.npos+1));
 	HIPCHK(c->d_outsym.ensure(2*BP.npos + 64*BP.piles.size() + 64));
 	HIPCHK(c->d_nfrag.ensure(BP.piles.size()+1)); HIPCHK(c->d_frags.ensure(BP.nfragslots+1)); HIPCHK(c->d_pilebad.ensure(BP.piles.size()+1));
@@ -1080,11 +1089,12 @@ int dacc_debug_windows(dacc_ctx * c, dacc_window_result * out, uint64_t cap, uin
 	*nwin = BP.nwindows;
 	if ( !out ) return DACC_OK;
 	hipSetDevice(c->device);
-	std::vector<WindowOut> wout(BP.nwindows); std::vector<uint8_t> wrec(BP.nwindows*WREC);
+	size_t const wrecb = DACC_WREC_OF(c->par.w);
+	std::vector<WindowOut> wout(BP.nwindows); std::vector<uint8_t> wrec(BP.nwindows*wrecb);
 	if ( BP.nwindows )
 	{
 		HIPCHK(hipMemcpy(wout.data(),c->d_wout.p,BP.nwindows*sizeof(WindowOut),hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(wrec.data(),c->d_wrec.p,BP.nwindows*WREC,hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(wrec.data(),c->d_wrec.p,BP.nwindows*wrecb,hipMemcpyDeviceToHost));
 	}
 	uint64_t i = 0;
 	for ( uint64_t pi = 0; pi < BP.piles.size() && i < cap; ++pi )
@@ -1097,10 +1107,13 @@ int dacc_debug_windows(dacc_ctx * c, dacc_window_result * out, uint64_t cap, uin
 			r.filterfreq = (o.status == WS_OK) ? o.filterfreq : 0; r.conslen = o.conslen; r.minrate = o.minrate;
 			if ( o.status == WS_OK )
 			{
-				uint8_t const * rec = wrec.data() + wdx*WREC;
-				uint8_t const * off = rec+1; uint8_t const * sym = rec+1+(c->P.w+2);
+				// (the consensus as text, cut at 79 symbols: a debugging view)
+				uint8_t const * rec = wrec.data() + wdx*wrecb;
+				uint32_t const w = c->P.w; bool const wide = DACC_WIDE_W(w);
+				uint8_t const * sym = wide ? rec+2+2*(w+2) : rec+1+(w+2);
+				uint32_t const nsym = wide ? (rec[2+2*(w+1)] | (static_cast<uint32_t>(rec[3+2*(w+1)])<<8)) : rec[1+(w+1)];
 				uint32_t cl = 0;
-				for ( uint32_t q = 0; q < off[c->P.w+1] && cl < 79; ++q ) if ( sym[q] < 4 ) r.cons[cl++] = "ACGT"[sym[q]];
+				for ( uint32_t q = 0; q < nsym && cl < 79; ++q ) if ( sym[q] < 4 ) r.cons[cl++] = "ACGT"[sym[q]];
 			}
 			out[i] = r;
 		}

@@ -992,7 +992,7 @@ struct WindowEngine
 		uint32_t need = k;
 		for ( uint32_t i = 0; i < cl; ++i ) need += A.sslen[chain[i]]-1;
 		for ( int32_t q = rp; q >= 0 && A.rp_len[q]; q = A.rp_parent[q] ) need += A.sslen[A.rp_stretch[q]]-1;
-		if ( o + need > C.conscap - MAXCONS ) { setOverflow(4096); return ~0u; } // the tail holds the accepted consensus
+		if ( o + need > C.conscap - DACC_MAXCONS_OF(P.w) ) { setOverflow(4096); return ~0u; } // the tail holds the accepted consensus
 		uint32_t const firstv = A.nv[A.sfirst[chain[cl-1]]];
 		for ( uint32_t i = 0; i < k; ++i ) A.cons[o++] = (firstv >> (2*(k-1-i))) & 3;
 		for ( uint32_t ii = 0; ii < cl; ++ii )
@@ -1359,7 +1359,7 @@ struct WindowEngine
 					uint32_t const cv = vlow | vhigh;
 					if ( findNode(cv) < 0 )
 					{
-						if ( nls >= lcap ) { setOverflow(8192); return; }
+						if ( nls >= lcap ) { setOverflow(8192); goto lsdone; }     // (lane 0 must reach the barrier below like the other lanes)
 						A.ls[4*nls+0] = i; A.ls[4*nls+1] = npi; A.ls[4*nls+2] = cv; A.ls[4*nls+3] = 1; ++nls;
 					}
 				}
@@ -1405,13 +1405,14 @@ struct WindowEngine
 					if ( pos + k <= A.slen[j] ) seqid = j;
 				if ( seqid != -1 )
 				{
-					if ( npre + added >= C.precap ) { setOverflow(1); return; }
+					if ( npre + added >= C.precap ) { setOverflow(1); goto lsdone; }
 					A.pre[npre+added] = ((A.ane[i]>>32)<<32) | (static_cast<uint64_t>(pos)<<16) | static_cast<uint32_t>(seqid);
 					++added;
 				}
 			}
 			npre += added;
 		}
+		lsdone:
 		wv_sync();
 		npre = wv_bcast(npre,0);
 		flags = wv_bcast(flags,0);
@@ -1499,6 +1500,7 @@ struct WindowEngine
 	// emits the window record: rec[0]=1, rec[1+r] = offset of group r (r = 0..w+1), then symbols
 	DEV void alignAndEmit(uint8_t const * cons, uint32_t const n, uint8_t * rec)
 	{
+		if ( DACC_WIDE_W(P.w) ) { alignAndEmitWide(cons,n,rec); return; }
 		uint32_t const m = P.w;
 		uint8_t const * a = A.str; // string 0 = A window
 		uint64_t const * PEQ = A.peq;
@@ -1560,6 +1562,83 @@ struct WindowEngine
 			}
 		}
 		off[m+1] = so;
+	}
+	// the same for w in 65..128: two words per column (rows 0..63 in word 0, 64..m-1 in word 1; column c of the stores at
+	// [2c], [2c+1]), the wide record layout (dev_types.hpp: 16 bit group offsets)
+	DEV void alignAndEmitWide(uint8_t const * cons, uint32_t const n, uint8_t * rec)
+	{
+		uint32_t const m = P.w;
+		uint8_t const * a = A.str;
+		uint64_t const * PEQ = A.peq;
+		uint32_t const lpw = C.lstr>>6;
+		uint64_t const mask1 = (m == 128) ? ~0ull : ((1ull<<(m-64))-1);
+		uint64_t Pv0 = ~0ull, Mv0 = 0, Pv1 = mask1, Mv1 = 0; uint32_t score = m;
+		A.alpv[0] = Pv0; A.alpv[1] = Pv1; A.almv[0] = Mv0; A.almv[1] = Mv1; A.albot[0] = m;
+		uint64_t const top = 1ull<<(m-65);
+		for ( uint32_t c = 0; c < n; ++c )
+		{
+			uint64_t const Eq0 = PEQ[lpw*cons[c]], Eq1 = PEQ[lpw*cons[c]+1];
+			uint64_t const Xv0 = Eq0 | Mv0;
+			uint64_t const Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
+			uint64_t Ph0 = Mv0 | ~(Xh0 | Pv0);
+			uint64_t Mh0 = Pv0 & Xh0;
+			uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
+			Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
+			Pv0 = Mh0 | ~(Xv0 | Ph0);
+			Mv0 = Ph0 & Xv0;
+			// word 1: the horizontal delta leaving word 0 enters here (a negative one acts like a match)
+			uint64_t const Eq1c = Eq1 | mhc;
+			uint64_t const Xv1 = Eq1 | Mv1;
+			uint64_t const Xh1 = (((Eq1c & Pv1) + Pv1) ^ Pv1) | Eq1c;
+			uint64_t Ph1 = Mv1 | ~(Xh1 | Pv1);
+			uint64_t Mh1 = Pv1 & Xh1;
+			if ( Ph1 & top ) ++score; else if ( Mh1 & top ) --score;
+			Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
+			Pv1 = (Mh1 | ~(Xv1 | Ph1)) & mask1;
+			Mv1 = (Ph1 & Xv1) & mask1;
+			A.alpv[2*c+2] = Pv0; A.alpv[2*c+3] = Pv1; A.almv[2*c+2] = Mv0; A.almv[2*c+3] = Mv1; A.albot[c+1] = score;
+		}
+		uint32_t i = m, j = n; uint32_t d = score; uint32_t nops = 0;
+		while ( i || j )
+		{
+			uint32_t op;
+			bool done = false;
+			if ( i && j )
+			{
+				// D[i-1][j-1] from column j-1: bottom minus the vertical deltas of rows i..m (rows sh.. of the two words)
+				uint32_t const sh = i-1;
+				uint64_t const p0 = A.alpv[2*(j-1)], p1 = A.alpv[2*(j-1)+1], q0 = A.almv[2*(j-1)], q1 = A.almv[2*(j-1)+1];
+				uint32_t const np_ = sh < 64 ? (dacc_popc64(p0>>sh) + dacc_popc64(p1)) : dacc_popc64(p1>>(sh-64));
+				uint32_t const nm_ = sh < 64 ? (dacc_popc64(q0>>sh) + dacc_popc64(q1)) : dacc_popc64(q1>>(sh-64));
+				uint32_t const dd = A.albot[j-1] - np_ + nm_;
+				uint32_t const neq = (a[i-1] != cons[j-1]);
+				if ( dd + neq == d ) { op = neq ? 1 : 0; --i; --j; d = dd; done = true; }
+			}
+			if ( !done && i )
+			{
+				uint32_t const r = i-1;
+				uint64_t const bit = 1ull<<(r&63);
+				uint64_t const pv = A.alpv[2*j+(r>>6)], mv = A.almv[2*j+(r>>6)];
+				int32_t const vd = (pv & bit) ? 1 : ((mv & bit) ? -1 : 0);
+				if ( vd == 1 ) { op = 3; --i; d = d-1; done = true; }
+			}
+			if ( !done ) { op = 2; --j; d = d-1; }
+			A.alops[nops++] = op;
+		}
+		uint8_t * off = rec+2; uint8_t * sym = rec + 2 + 2*(m+2);
+		rec[0] = 1; rec[1] = 0;
+		uint32_t so = 0, cpos = 0, t = nops;
+		for ( uint32_t r = 0; r <= m; ++r )
+		{
+			off[2*r] = so & 0xFF; off[2*r+1] = so >> 8;
+			while ( t && A.alops[t-1] == 2 ) { sym[so++] = cons[cpos++]; --t; }
+			if ( r < m )
+			{
+				uint32_t const op = A.alops[--t];
+				sym[so++] = (op == 3) ? 4 : cons[cpos++];
+			}
+		}
+		off[2*(m+1)] = so & 0xFF; off[2*(m+1)+1] = so >> 8;
 	}
 };
 

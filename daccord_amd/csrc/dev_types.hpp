@@ -83,8 +83,18 @@ struct ArenaCaps
 enum { LSTR = 256 };       // least string stride of the generic engine (ArenaCaps::lstr); up to here the Myers column state stays in registers
 enum { LPW = LSTR/64 };     // 64 bit words of such a column
 enum { LSTRMAX = 4096 };   // largest string stride the host plan asks for (a longer B window string drops its pile)
-enum { WREC = 256 };       // bytes per window output record
-enum { MAXCONS = 96 };     // max consensus length
+enum { WREC = 256 };       // bytes per window output record (w <= 64)
+enum { MAXCONS = 96 };     // max consensus length (w <= 64)
+// Wide windows (w in 65..128; generic engine only): consensus up to MAXCONSW symbols, records of WRECW bytes with 16 bit group
+// offsets: rec[0] = status, offset of group r (r = 0..w+1) little endian at rec[2+2r], symbols from rec[2+2(w+2)] on (at most
+// w + MAXCONSW of them: one per A position plus the inserted ones).  The narrow layout (rec[1+r], symbols from rec[1+(w+2)]) is
+// what the LDS tiers write and stays as it is.
+enum { WRECW = 640 };
+enum { MAXCONSW = 224 };
+#define DACC_WIDE_W(w_) ((w_) > 64u)
+#define DACC_WREC_OF(w_) (DACC_WIDE_W(w_) ? static_cast<uint32_t>(::dacc::WRECW) : static_cast<uint32_t>(::dacc::WREC))
+#define DACC_MAXCONS_OF(w_) (DACC_WIDE_W(w_) ? static_cast<uint32_t>(::dacc::MAXCONSW) : static_cast<uint32_t>(::dacc::MAXCONS))
+#define DACC_WMAX 128u     // largest window size (two 64 bit words of the consensus -> A alignment)
 
 // window status / flags
 enum { WS_INSUFFICIENT = 0, WS_OK = 1, WS_FAILED = 2, WS_OVERFLOW = 3 };

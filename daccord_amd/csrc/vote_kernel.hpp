@@ -60,11 +60,14 @@ struct VoteTile { LDSQ uint8_t const * stage; uint32_t y0, n; };
 // a window record, either in the LDS stage or in HBM (no generic pointers: the two address spaces stay apart)
 struct VRec { uint8_t const * g; LDSQ uint8_t const * l; bool lds; };     // an explicit flag: LDS address 0 is a valid address
 DEV uint32_t vrb(VRec const & R, uint32_t const i) { return R.lds ? static_cast<uint32_t>(R.l[i]) : static_cast<uint32_t>(R.g[i]); }
+// offset of group r and symbol o of a record: narrow layout (w <= 64) or wide (dev_types.hpp)
+DEV uint32_t vroff(VRec const & R, uint32_t const w, uint32_t const r) { return DACC_WIDE_W(w) ? (vrb(R,2+2*r) | (vrb(R,3+2*r)<<8)) : vrb(R,1+r); }
+DEV uint32_t vrsym(VRec const & R, uint32_t const w, uint32_t const o) { return vrb(R,(DACC_WIDE_W(w) ? 2+2*(w+2) : 1+(w+2)) + o); }
 DEV VRec voteRecord(VoteBatch const & B, DevPile const & pile, VoteTile const & VT, uint32_t const y)
 {
 	uint32_t const d = y - VT.y0;
 	VRec R;
-	if ( d < VT.n ) { R.l = VT.stage + d*WREC; R.g = B.wrec; R.lds = true; } else { R.l = VT.stage; R.g = B.wrec + (pile.winbase+y)*WREC; R.lds = false; }
+	if ( d < VT.n ) { R.l = VT.stage + d*WREC; R.g = B.wrec; R.lds = true; } else { R.l = VT.stage; R.g = B.wrec + (pile.winbase+y)*DACC_WREC_OF(B.P.w); R.lds = false; }     // (wide records are never staged)
 	return R;
 }
 DEV void coverBegin(VoteBatch const & B, DevPile const & pile, uint32_t const p, CoverIt & it)
@@ -111,7 +114,7 @@ DEV void votePass1(VoteBatch const & B, DevPile const & pile, uint32_t const p, 
 	VRec rec; uint32_t r;
 	while ( coverNext(B,pile,VT,p,it,rec,r) )
 	{
-		uint32_t const sz = vrb(rec,1+r+1)-vrb(rec,1+r);
+		uint32_t const sz = vroff(rec,w,r+1)-vroff(rec,w,r);
 		uint32_t const nins = sz - (r < w ? 1 : 0);
 		if ( r < w ) ++l0;
 		T = nins > T ? nins : T;
@@ -158,7 +161,7 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 		VRec rec; uint32_t r;
 		while ( coverNext(B,pile,VT,p,it,rec,r) )
 		{
-			uint32_t const nins = (vrb(rec,1+r+1)-vrb(rec,1+r)) - (r < w ? 1 : 0);
+			uint32_t const nins = (vroff(rec,w,r+1)-vroff(rec,w,r)) - (r < w ? 1 : 0);
 			T = nins > T ? nins : T;
 		}
 	}
@@ -171,9 +174,9 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 		VRec rec; uint32_t r;
 		while ( coverNext(B,pile,VT,p,it,rec,r) )
 		{
-			uint32_t const o0 = vrb(rec,1+r);
-			uint32_t const nins = (vrb(rec,1+r+1)-o0) - (r < w ? 1 : 0);
-			if ( nins >= t ) { colAdd(C,vrb(rec,1+(w+2)+o0+nins-t),1); ++ld; }
+			uint32_t const o0 = vroff(rec,w,r);
+			uint32_t const nins = (vroff(rec,w,r+1)-o0) - (r < w ? 1 : 0);
+			if ( nins >= t ) { colAdd(C,vrsym(rec,w,o0+nins-t),1); ++ld; }
 		}
 		if ( depth > static_cast<int32_t>(ld) ) C.c4 += depth-ld;
 		uint32_t best;
@@ -189,7 +192,7 @@ DEV uint32_t votePass2(VoteBatch const & B, DevPile const & pile, uint32_t const
 		VRec rec; uint32_t r;
 		while ( coverNext(B,pile,VT,p,it,rec,r) )
 		{
-			if ( r < w ) { colAdd(C,vrb(rec,1+(w+2)+vrb(rec,1+r+1)-1),1); ++real; }
+			if ( r < w ) { colAdd(C,vrsym(rec,w,vroff(rec,w,r+1)-1),1); ++real; }
 		}
 		if ( !real )
 		{

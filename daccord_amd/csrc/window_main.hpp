@@ -24,7 +24,7 @@ struct WindowBatch
 	uint32_t const * wt_b; uint32_t const * wt_e;   // per (overlap, active window): B start / end offset
 	uint64_t nwindows;
 	// outputs
-	uint8_t * wrec;            // [nwindows][WREC]
+	uint8_t * wrec;            // [nwindows][DACC_WREC_OF(w)]
 	WindowOut * wout;          // [nwindows]
 	uint8_t * arena;           // [gridDim][C.bytes]
 	uint64_t * prof;           // optional per-phase cycle counters (profiling builds)
@@ -60,9 +60,13 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 	for ( int i = 0; i < 16; ++i ) E.st[i] = 0;
 #endif
 	PROF_T0
-	arena_carve(E.A,arenabase,B.C);
+	arena_carve(E.A,arenabase,B.C,B.P.w);
 	Arena & A = E.A;
 	int const lane = E.lane;
+	// the per-length path heaps are drained by every enumeration that completes, so their fill counts are zero from one pair to
+	// the next -- but an enumeration that stops on a capacity overflow leaves them as they are, and the arena itself is whatever
+	// the allocation or the previous layout (scratch retry with grown capacities) left there: start every window from zero
+	for ( uint32_t i = lane; i < B.C.blcap; i += WSZ ) A.apq_n[i] = 0;
 
 	// pile of this window: binary search over winbase
 	uint32_t lo = 0, hi = B.npiles;
@@ -73,7 +77,7 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 	windowInterval(pile.l,B.P.a,B.P.w,y,astart,aend);
 
 	WindowOut out; out.status = WS_INSUFFICIENT; out.mao = 0; out.elength = 0; out.k = 0; out.filterfreq = -1; out.conslen = 0; out.minrate = 0; out.flags = 0;
-	uint8_t * rec = B.wrec + widx*WREC;
+	uint8_t * rec = B.wrec + widx*DACC_WREC_OF(B.P.w);
 	if ( lane == 0 ) rec[0] = 0;
 
 	// ---- active set: overlaps with abpos <= astart and aepos >= aend (HandleContext.hpp:1904-1977) ----
@@ -146,7 +150,7 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 		bool haveMin = false;
 		uint32_t bestlen = 0;
 		// the accepted consensus is kept at the tail of the candidate text buffer
-		uint8_t * best = A.cons + (B.C.conscap - MAXCONS);
+		uint8_t * best = A.cons + (B.C.conscap - DACC_MAXCONS_OF(B.P.w));
 		for ( uint32_t k = B.P.klow; k <= B.P.khigh && !E.flags; ++k )
 		{
 			E.k = k; E.kmask = (k >= 32) ? ~0ull : ((1ull<<(2*k))-1);
@@ -194,7 +198,7 @@ DEV void processWindow(WindowBatch const & B, uint64_t const widx, uint8_t * are
 						{
 							lconsok = true; minrate = err; haveMin = true;
 							bestlen = A.acc[0].l;
-							if ( bestlen > MAXCONS ) { E.setOverflow(0x80000); break; }
+							if ( bestlen > DACC_MAXCONS_OF(B.P.w) ) { E.setOverflow(0x80000); break; }
 							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = A.cons[A.acc[0].o+i];
 							out.k = k; out.filterfreq = ff;
 							wv_sync();

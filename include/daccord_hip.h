@@ -42,7 +42,7 @@ extern "C" {
 /* Run parameters: the daccord command line options that shape the path
  * (src/daccord.cpp:101-169 defaults, :1282-1305 parsing). */
 typedef struct dacc_params {
-	uint32_t w;              /* -w window size            (default 40) */
+	uint32_t w;              /* -w window size            (default 40); 1 <= w <= 128 (w <= 63: LDS tiers; 64..128: generic engine) */
 	uint32_t a;              /* -a advance size           (default 10) */
 	uint32_t klow, khigh;    /* -k single value or lo,hi  (default 8,8); 3 <= k <= 16 */
 	int32_t  minfilterfreq;  /* --minfilterfreq           (default 0) */
@@ -198,7 +198,7 @@ int  dacc_rerun_resident(dacc_ctx *ctx);
 
 /* Debug/parity hook: per-window results of the last batch.
  * For window i: status (0 insufficient depth, 1 consensus found, 2 path failed),
- * consensus length and bases (<= 64), number of strings, elength. */
+ * consensus length and bases (the first 79), number of strings, elength. */
 typedef struct dacc_window_result {
 	int32_t  pile;           /* pile index in the batch */
 	int32_t  y;              /* window index */

@@ -42,7 +42,7 @@ def main():
     dreads = int(sys.argv[8]) if len(sys.argv) > 8 else reads
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from daccord_amd import build as _b
-    out = {"workload": {"reads": reads, "readlen": readlen, "coverage": cov, "k": k}, "diagnostics_workload_reads": dreads, "csrc_hash": _b.csrc_hash(), "kernels": {},
+    out = {"workload": {"reads": reads, "readlen": readlen, "coverage": cov, "k": k}, "diagnostics_workload_reads": dreads, "csrc_hash": _b.csrc_hash(), "kernel_isa": _b.kernel_isa_hashes(), "kernels": {},
            "note": "rocprofv3 --pmc, one pass per counter group, mean per launch; traffic = 2*FETCH_SIZE + WRITE_SIZE (KB->bytes); "
                    "the diagnostic groups (lane utilisation, in-flight levels, L2 hit rate, L1->L2 latency) were collected on a smaller slice: ratios only"}
     F, dF = load(os.path.join(root, "pmc_FETCH_SIZE")); W, dW = load(os.path.join(root, "pmc_WRITE_SIZE")); S, dS = load(os.path.join(root, "pmc_SQ_WAVE_CYCLES"))

@@ -139,12 +139,16 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 	for ( uint64_t i = 0; i < BP.nwt; ++i ) if ( wt_b[i] == 0xDEADBEEF || wt_e[i] == 0xDEADBEEF ) { c->err = "window table entry not written"; return DACC_EHIP; }
 
 	// window kernel
-	std::vector<uint8_t> wrec(BP.nwindows*WREC+WREC,0);
+	size_t const wrecb = DACC_WREC_OF(P.w);
+	std::vector<uint8_t> wrec(BP.nwindows*wrecb+wrecb,0);
 	std::vector<WindowOut> wout(BP.nwindows+1);
 	{
 		Arena A; ArenaCaps caps = BP.caps;
-		caps.bytes = arena_carve(A,0,caps);
-		std::vector<uint8_t> arena(caps.bytes+64);
+		caps.bytes = arena_carve(A,0,caps,P.w);
+		// (filled with a pattern, not zeros: on the device a scratch arena holds whatever the last window -- or, after a scratch retry, the
+		// last LAYOUT -- left in it; code that reads a field before writing it must show up here)
+		uint8_t const arenafill = getenv("DACC_EMUL_ARENA_FILL") ? static_cast<uint8_t>(std::strtoul(getenv("DACC_EMUL_ARENA_FILL"),0,0)) : 0xCD;
+		std::vector<uint8_t> arena(caps.bytes+64,arenafill);
 		WindowBatch WB;
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
@@ -309,9 +313,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			bool any = false;
 			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) any = true;
 			if ( !any ) break;
-			if ( getenv("DACC_EMUL_VERBOSE") ) { uint64_t n = 0; for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) n += (wout[wdx].status == WS_OVERFLOW); std::fprintf(stderr,"[emul] scratch retry %d: %llu windows\n",attempt,static_cast<unsigned long long>(n)); }
-			growArenaCaps(caps); caps.bytes = arena_carve(A,0,caps);
-			arena.assign(caps.bytes+64,0);
+			if ( getenv("DACC_EMUL_VERBOSE") ) { uint64_t n = 0; uint32_t fl = 0; for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) { ++n; fl |= wout[wdx].flags; } std::fprintf(stderr,"[emul] scratch retry %d: %llu windows, flags 0x%x\n",attempt,static_cast<unsigned long long>(n),fl); }
+			growArenaCaps(caps,P.w); caps.bytes = arena_carve(A,0,caps,P.w);
+			arena.assign(caps.bytes+64,arenafill);
 			WB.C = caps; WB.arena = arena.data();
 			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) wave_run([&]() { processWindow(WB,wdx,arena.data()); });
 		}
@@ -329,10 +333,12 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			if ( o.status == WS_OVERFLOW ) overflow = true;
 			if ( o.status == WS_OK )
 			{
-				uint8_t const * rec = wrec.data() + wdx*WREC;
-				uint8_t const * off = rec+1; uint8_t const * sym = rec+1+(P.w+2);
+				uint8_t const * rec = wrec.data() + wdx*wrecb;
+				uint32_t const w = P.w; bool const wide = DACC_WIDE_W(w);
+				uint8_t const * sym = wide ? rec+2+2*(w+2) : rec+1+(w+2);
+				uint32_t const nsym = wide ? (rec[2+2*(w+1)] | (static_cast<uint32_t>(rec[3+2*(w+1)])<<8)) : rec[1+(w+1)];
 				uint32_t cl = 0;
-				for ( uint32_t q = 0; q < off[P.w+1] && cl < 79; ++q ) if ( sym[q] < 4 ) r.cons[cl++] = "ACGT"[sym[q]];
+				for ( uint32_t q = 0; q < nsym && cl < 79; ++q ) if ( sym[q] < 4 ) r.cons[cl++] = "ACGT"[sym[q]];
 			}
 			else r.filterfreq = (o.status == WS_FAILED) ? 0 : 0;
 			c->windows.push_back(r);

@@ -43,7 +43,7 @@ def test_no_cpu_fallback():
 
 
 def test_bad_params_rejected():
-    for kw in (dict(k=2), dict(k=17), dict(klow=9, khigh=8), dict(w=0), dict(w=65)):
+    for kw in (dict(k=2), dict(k=17), dict(klow=9, khigh=8), dict(w=0), dict(w=129)):
         h = C.c_void_p()
         rc = engine.lib().dacc_create(C.byref(h), C.byref(default_params(**kw)))
         assert rc == -1

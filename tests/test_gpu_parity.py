@@ -153,6 +153,46 @@ def test_windows_with_long_strings():
     assert frags_equal(fo, bo, fx, bx)
 
 
+@pytest.mark.parametrize("kw,erate", [(dict(w=100, a=25, k=8), 0.12), (dict(w=128, a=32, k=12), 0.15), (dict(w=65, a=16, k=8), 0.15),
+                                      (dict(w=96, a=24, k=9, producefull=1), 0.2), (dict(w=128, a=10, klow=13, khigh=14), 0.12), (dict(w=64, a=16, k=8), 0.12)])
+def test_wide_windows(kw, erate):
+    """-w 64..128 (free in the reference, src/daccord.cpp:1282-1305): generic engine, two-word consensus -> A alignment, 640 byte
+    window records with 16 bit group offsets, the vote over them (the emulation runs the same cases: test_emul_parity.py)"""
+    d = SynthData(60000, 150, 3000, seed=kw["w"] + kw.get("k", 13), erate=erate)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E = _pair(d, **kw)
+    fo, bo = O.run(piles[:6], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:6], ovl, d.trace)
+    wo = O.windows()
+    assert (wo["status"] == 1).sum() > 50
+    bad = windows_equal(wo, E.debug_windows())
+    assert bad == [], (len(bad), bad[:5])
+    assert len(bo) > 8000 and frags_equal(fo, bo, fx, bx)
+    assert engine.fasta(fx, bx) == pyoracle.fasta(fo, bo)
+    # and once more on the same context (buffers sized for the wide records are reused)
+    fy, by = E(piles[2:5], ovl, d.trace)
+    f2, b2 = O.run(piles[2:5], ovl, d.trace, nthreads=8)
+    assert frags_equal(f2, b2, fy, by)
+
+
+def test_scratch_retry_of_the_generic_engine(monkeypatch):
+    """A dense graph at k = 6 overflows the generic engine's first scratch capacities: the windows are run again in a re-carved (larger)
+    arena.  With DACC_NOFAST=1 every window goes through the generic engine, as it does for w >= 64.  (Round 4: the per-length path heap
+    counts were never cleared -- the first layout found zeros from the allocation, the re-carved one did not: a device fault.  The
+    emulation now fills its arenas with a pattern instead of zeros.)"""
+    monkeypatch.setenv("DACC_NOFAST", "1")
+    d = SynthData(60000, 300, 3000, erate=0.28, seed=481075, ins_frac=0.2, del_frac=0.7, sub_frac=0.1)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    O, E = _pair(d, k=6, w=63, a=20, maxalign=3)
+    fo, bo = O.run(piles[:2], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:2], ovl, d.trace)
+    assert windows_equal(O.windows(), E.debug_windows()) == []
+    assert len(bo) > 3000 and frags_equal(fo, bo, fx, bx)
+    fy, by = E(piles[1:2], ovl, d.trace)
+    f2, b2 = O.run(piles[1:2], ovl, d.trace, nthreads=8)
+    assert frags_equal(f2, b2, fy, by)
+
+
 def test_ont_like_profile_k_sweep():
     d = SynthData(60000, 150, 3000, erate=0.15, ins_frac=1 / 3, del_frac=1 / 3, sub_frac=1 / 3, seed=5)
     ovl, piles = pyoracle.pile_select(d.ovl, d.piles)

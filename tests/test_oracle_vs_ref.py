@@ -116,6 +116,21 @@ def test_estimator_pile_selection_against_the_reference_loop(maxinput):
     assert len(oo) < len(d.ovl) if maxinput < 20 else True
 
 
+@pytest.mark.parametrize("kw,erate", [(dict(w=100, a=25, k=8), 0.12), (dict(w=128, a=32, k=12), 0.15), (dict(w=65, a=16, k=8), 0.15), (dict(w=80, a=10, k=10), 0.08)])
+def test_wide_windows_against_the_reference_build(kw, erate):
+    """-w above 64 is plain reference semantics (src/daccord.cpp:1282-1305 takes any -w): tables and FASTA of the oracle equal the reference build there too"""
+    from daccord_amd.synth import SynthData
+    d = SynthData(60000, 150, 3000, seed=kw["w"] + kw["k"], erate=erate)
+    ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    p = default_params(**kw)
+    O, R = _pair(p, d)
+    to, tr = O.tables(), R.tables()
+    assert len(to) == len(tr) and np.array_equal(to, tr)
+    fo, bo = O.run(piles[:5], ovl, d.trace, nthreads=5)
+    fr, br = R.run(piles[:5], ovl, d.trace, nthreads=5)
+    assert len(bo) > 8000 and pyoracle.fasta(fo, bo) == pyoracle.fasta(fr, br)
+
+
 def _selection_piles(seed, npiles, tbytes):
     """piles in file order with many ties in score and abpos, trace lengths that make records of 60...400 bytes, sizes from 0 to a few
     64 KiB input blocks (with records straddling the block ends)"""
