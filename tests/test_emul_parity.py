@@ -291,7 +291,7 @@ def test_twice_split_stretch_stays_in_the_lds_tiers():
 
 @pytest.mark.parametrize("lanes,kw,erate", [(1, dict(w=100, a=25, k=8), 0.12), (1, dict(w=128, a=32, k=12), 0.15), (1, dict(w=65, a=16, k=8), 0.15),
                                             (1, dict(w=96, a=24, k=9, producefull=1), 0.2), (1, dict(w=110, a=55, k=10, minwindowcov=4), 0.1),
-                                            (1, dict(w=128, a=10, klow=13, khigh=14), 0.12),
+                                            (1, dict(w=128, a=16, klow=13, khigh=14), 0.12),
                                             (64, dict(w=128, a=64, k=8, maxalign=6), 0.15), (64, dict(w=80, a=10, k=10), 0.08)])
 def test_wide_windows_run_in_the_generic_engine(lanes, kw, erate):
     """-w 65..128 (free in the reference, src/daccord.cpp:1282-1305): the generic engine with the two-word consensus -> A alignment,
@@ -302,12 +302,13 @@ def test_wide_windows_run_in_the_generic_engine(lanes, kw, erate):
     p = default_params(**kw)
     O = pyoracle.Oracle(p); O.set_error_profile(*d.error_profile()); O.load_db(d.bps, d.boff, d.rlen)
     E = emul_lib.Emul(p, lanes=lanes); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
-    fo, bo = O.run(piles[:4], ovl, d.trace, nthreads=4, want_windows=True)
-    fe, be = E.run(piles[:4], ovl, d.trace)
+    n = 2 if "klow" in kw else 4                            # (the k range at w = 128 is the slowest case)
+    fo, bo = O.run(piles[:n], ovl, d.trace, nthreads=4, want_windows=True)
+    fe, be = E.run(piles[:n], ovl, d.trace)
     wo = O.windows()
     assert (wo["status"] == 1).sum() > 50 and (wo["conslen"] > 64).any()
     assert windows_equal(wo, E.windows()) == []
-    assert len(bo) > 5000 and frags_equal(fo, bo, fe, be)
+    assert len(bo) > 1200 * n and frags_equal(fo, bo, fe, be)
     assert E.counts()[:3] == (0, 0, 0)                      # no LDS tier takes a window wider than 63 bases
 
 
