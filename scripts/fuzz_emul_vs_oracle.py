@@ -1,6 +1,6 @@
 """Randomized parity runs: kernel logic (1-lane emulation, tests/emul) vs the CPU oracle over random run parameters
 (w, a, k ranges, filter frequencies, -d, -m, -f, -l, -e), error profiles and coverages.
-usage: python scripts/fuzz_emul_vs_oracle.py <seed> <rounds> [--wide] [--lanes64] [--warp]      (found the -f / empty pile and the scratch overflow bugs)"""
+usage: python scripts/fuzz_emul_vs_oracle.py <seed> <rounds> [--wide] [--w128] [--lanes64] [--warp]      (found the -f / empty pile and the scratch overflow bugs)"""
 import sys, os, time, random, collections
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,9 +11,9 @@ import pyoracle, emul_lib
 seed0=int(sys.argv[1]); nrounds=int(sys.argv[2]); wide = '--wide' in sys.argv; lanes = 64 if '--lanes64' in sys.argv else 1
 rng=random.Random(seed0)
 bad=0
-from common import random_run_config, random_run_config_wide
+from common import random_run_config, random_run_config_wide, random_run_config_w128
 for r in range(nrounds):
-    kw, data, maxin, nplc = (random_run_config_wide if wide else random_run_config)(rng)
+    kw, data, maxin, nplc = (random_run_config_w128 if '--w128' in sys.argv else random_run_config_wide if wide else random_run_config)(rng)
     if '--warp' in sys.argv and not data.get('warp'):   # every round with badly aligned trace blocks
         data['warp'] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000) if data['tspace'] > 125 else (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
     try:

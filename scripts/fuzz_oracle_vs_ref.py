@@ -2,7 +2,7 @@
 REFERENCE'S OWN headers compiled against the libmaus2 stand-in, oracle/ref_shim/): same random run parameters, error profiles,
 coverages, trace spacings and warped traces as the emulation / GPU fuzzing (tests/common.py).  Compares the model tables bit
 for bit and the FASTA of every pile.  k above 12 runs in the k16 build (our factory around the reference's graph template).
-usage: python scripts/fuzz_oracle_vs_ref.py <seed> <rounds> [--wide] [--warp]"""
+usage: python scripts/fuzz_oracle_vs_ref.py <seed> <rounds> [--wide] [--w128] [--warp]"""
 import sys, os, time, random
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,13 +10,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.
 from daccord_amd.synth import SynthData
 from daccord_amd._structs import default_params
 import pyoracle, pyref
-from common import random_run_config, random_run_config_wide, warp_trace
+from common import random_run_config, random_run_config_wide, random_run_config_w128, warp_trace
 
 seed0 = int(sys.argv[1]); nrounds = int(sys.argv[2]); wide = "--wide" in sys.argv
 rng = random.Random(seed0)
 bad = 0
 for r in range(nrounds):
-    kw, data, maxin, nplc = (random_run_config_wide if wide else random_run_config)(rng)
+    kw, data, maxin, nplc = (random_run_config_w128 if '--w128' in sys.argv else random_run_config_wide if wide else random_run_config)(rng)
     if "--warp" in sys.argv and not data.get("warp"):
         data["warp"] = (rng.choice([3, 5]), rng.choice([300, 580, 900]), 2000) if data["tspace"] > 125 else (rng.choice([2, 3, 5]), rng.choice([60, 115, 150]))
     try:

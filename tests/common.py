@@ -98,6 +98,19 @@ def random_run_config_wide(rng):
     return kw, data, maxin, npl
 
 
+def random_run_config_w128(rng):
+    """random_run_config with a window of 64 ... 128 bases (generic engine only; round 4): k from 8 up (dense graphs at small k make
+    the oracle slow at these sizes), advances up to the window size, sometimes a trace spacing beyond 125 (two byte trace values)."""
+    kw, data, maxin, npl = random_run_config(rng)
+    w = rng.choice([64, 65, 72, 80, 96, 100, 112, 127, 128]); kw["w"] = w; kw["a"] = rng.choice([10, 16, 25, 32, 40, 64, w])
+    kw["klow"] = rng.choice([8, 9, 10, 12, 14, 16]); kw["khigh"] = min(16, kw["klow"] + rng.choice([0, 0, 0, 1]))
+    kw.pop("minfilterfreq", None)
+    data["nreads"] = rng.choice([60, 120, 150]); data["read_len"] = rng.choice([1500, 3000]); data["genome_len"] = rng.choice([30000, 60000])
+    if rng.random() < 0.3:
+        ts = rng.choice([126, 128, 150, 200]); kw["tspace"] = ts; data["tspace"] = ts
+    return kw, data, maxin, min(npl, 3)
+
+
 def warp_trace(ovl, piles, trace, pile_ids, every=3, extra=115, cap=250):
     """Synthetic bad alignments: for every `every`-th overlap of the given piles, one interior trace block gets `extra`
     more B bases (taken from the overlap's other blocks, so that the B lengths still sum to bepos-bbpos).  The windows

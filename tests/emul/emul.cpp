@@ -139,15 +139,17 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 	for ( uint64_t i = 0; i < BP.nwt; ++i ) if ( wt_b[i] == 0xDEADBEEF || wt_e[i] == 0xDEADBEEF ) { c->err = "window table entry not written"; return DACC_EHIP; }
 
 	// window kernel
+	// Device buffers are NOT zero when a kernel first sees them (an allocation may be recycled memory, a scratch arena holds what the
+	// last window or the last layout left): every buffer the library does not clear is filled with a pattern here, so that code that
+	// reads a field before writing it shows up on the CPU (DACC_EMUL_ARENA_FILL=<byte>, default 0xCD).
+	uint8_t const arenafill = getenv("DACC_EMUL_ARENA_FILL") ? static_cast<uint8_t>(std::strtoul(getenv("DACC_EMUL_ARENA_FILL"),0,0)) : 0xCD;
 	size_t const wrecb = DACC_WREC_OF(P.w);
-	std::vector<uint8_t> wrec(BP.nwindows*wrecb+wrecb,0);
+	std::vector<uint8_t> wrec(BP.nwindows*wrecb+wrecb,arenafill);
 	std::vector<WindowOut> wout(BP.nwindows+1);
+	std::memset(static_cast<void *>(wout.data()),arenafill,wout.size()*sizeof(WindowOut));
 	{
 		Arena A; ArenaCaps caps = BP.caps;
 		caps.bytes = arena_carve(A,0,caps,P.w);
-		// (filled with a pattern, not zeros: on the device a scratch arena holds whatever the last window -- or, after a scratch retry, the
-		// last LAYOUT -- left in it; code that reads a field before writing it must show up here)
-		uint8_t const arenafill = getenv("DACC_EMUL_ARENA_FILL") ? static_cast<uint8_t>(std::strtoul(getenv("DACC_EMUL_ARENA_FILL"),0,0)) : 0xCD;
 		std::vector<uint8_t> arena(caps.bytes+64,arenafill);
 		WindowBatch WB;
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
@@ -157,7 +159,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		// hand-over slots as in the library (DACC_HAND=0: off)
 		uint32_t const handwords = (BP.deep ? 2048u + 128u : 1024u + 64u) + 4u;
 		bool const handon = !(getenv("DACC_HAND") && getenv("DACC_HAND")[0] == '0') && c->par.klow == c->par.khigh;
-		std::vector<uint64_t> hand(handon ? static_cast<size_t>(BP.nwindows+1)*handwords : 1); uint32_t handctr = 0;
+		std::vector<uint64_t> hand(handon ? static_cast<size_t>(BP.nwindows+1)*handwords : 1,0x0101010101010101ull*arenafill); uint32_t handctr = 0;
 		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3]; std::vector<uint8_t> lds0, gslab0;
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
@@ -182,9 +184,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		for ( int t = 0; t < 3; ++t )
 		{
 			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].retry = 0; FB[t].gearly = 0;
-			gslab[t].assign(BP.ftier[t].gbytes+64,0); FB[t].gslab = gslab[t].data(); FB[t].gstride = 0; FB[t].tab32 = c->H.tab32.data();
+			gslab[t].assign(BP.ftier[t].gbytes+64,arenafill); FB[t].gslab = gslab[t].data(); FB[t].gstride = 0; FB[t].tab32 = c->H.tab32.data();
 			FB[t].hand = handon ? hand.data() : 0; FB[t].handctr = &handctr; FB[t].handcap = handon ? static_cast<uint32_t>(BP.nwindows) : 0u; FB[t].handwords = handwords;
-			lds[t].resize(BP.ftier[t].ldsbytes+64);
+			lds[t].assign(BP.ftier[t].ldsbytes+64,arenafill);
 			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftier[t].tabcap;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
@@ -195,9 +197,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		if ( tier0ok )
 		{
 			FB0.W = WB; FB0.F = BP.ftier0; FB0.dpsq_vst = c->H.dpsq_vst.data(); FB0.retry = 0; FB0.gearly = 0;
-			gslab0.assign(BP.ftier0.gbytes+64,0); FB0.gslab = gslab0.data(); FB0.gstride = 0; FB0.tab32 = c->H.tab32.data();
+			gslab0.assign(BP.ftier0.gbytes+64,arenafill); FB0.gslab = gslab0.data(); FB0.gstride = 0; FB0.tab32 = c->H.tab32.data();
 			FB0.hand = handon ? hand.data() : 0; FB0.handctr = &handctr; FB0.handcap = handon ? static_cast<uint32_t>(BP.nwindows) : 0u; FB0.handwords = handwords;
-			lds0.resize(BP.ftier0.ldsbytes+64);
+			lds0.assign(BP.ftier0.ldsbytes+64,arenafill);
 			wave_run([&]() { FastLds< FastTier<0> > L; L.base = lds0.data(); fast_load_tables(L,BP.ftier0.nrows,BP.ftier0.nsup,T,c->H.dpsq_vst.data()); });
 		}
 		auto loadTables = [&](int const t)
@@ -281,7 +283,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		// the library's launch on the second stream (k_window_long): tier 5 (strings of up to 128 bases) first, the generic
 		// engine for what it cannot hold
 		FastBatch FBL; FBL.W = WB; FBL.W.pregen = 0; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0; FBL.gslab = 0; FBL.gstride = 0; FBL.tab32 = c->H.tab32.data(); FBL.hand = 0; FBL.handctr = 0; FBL.handcap = 0; FBL.handwords = 0;
-		std::vector<uint8_t> ldsL(BP.ftierL.ldsbytes+64);
+		std::vector<uint8_t> ldsL(BP.ftierL.ldsbytes+64,arenafill);
 		bool const longok = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap;
 		auto loadTablesL = [&]() { wave_run([&]() { FastLds< FastTier<5> > L; L.base = ldsL.data(); fast_load_tables(L,BP.ftierL.nrows,BP.ftierL.nsup,T,c->H.dpsq_vst.data()); }); };
 		if ( longok ) loadTablesL();
@@ -351,9 +353,11 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 	}
 
 	// vote
-	std::vector<uint8_t> has(BP.npos+1), oc(BP.npos+1); std::vector<uint16_t> ld0(BP.npos+1); std::vector<uint32_t> ocs(BP.npos+1);
-	std::vector<uint8_t> outsym(2*BP.npos + 64*BP.piles.size() + 64);
-	std::vector<VoteFragment> vf(BP.nfragslots+1); std::vector<uint32_t> nfrag(BP.piles.size()+1);
+	uint8_t const votefill = getenv("DACC_EMUL_ARENA_FILL") ? static_cast<uint8_t>(std::strtoul(getenv("DACC_EMUL_ARENA_FILL"),0,0)) : 0xCD;
+	std::vector<uint8_t> has(BP.npos+1,votefill), oc(BP.npos+1,votefill); std::vector<uint16_t> ld0(BP.npos+1,0x0101u*votefill); std::vector<uint32_t> ocs(BP.npos+1,0x01010101u*votefill);
+	std::vector<uint8_t> outsym(2*BP.npos + 64*BP.piles.size() + 64,votefill);
+	std::vector<VoteFragment> vf(BP.nfragslots+1); std::memset(static_cast<void *>(vf.data()),votefill,vf.size()*sizeof(VoteFragment));
+	std::vector<uint32_t> nfrag(BP.piles.size()+1,0x01010101u*votefill);
 	VoteBatch VB;
 	VB.P = P; VB.bps = c->bps.data(); VB.boff = c->boff.data(); VB.rlen = c->rlen.data(); VB.piles = BP.piles.data(); VB.npiles = BP.piles.size();
 	VB.wrec = wrec.data(); VB.has = has.data(); VB.ld0 = ld0.data(); VB.oc = oc.data(); VB.ocs = ocs.data(); VB.outsym = outsym.data();
