@@ -306,9 +306,11 @@ def test_cli_two_databases_and_estimated_profile(small_data, tmp_path):
     assert r.stdout.decode() == pyoracle.fasta(fo, bo)
 
 
-def _random_configs(first, last, seed=20260921):
+def _random_configs(first, last, seed=20260921, gen=None):
     import random
     from common import random_run_config
+    if gen is not None:
+        random_run_config = gen
     rng = random.Random(seed)
     tiers = np.zeros(3, dtype=np.int64)
     nwin = 0
@@ -321,8 +323,8 @@ def _random_configs(first, last, seed=20260921):
         ovl, piles = pyoracle.pile_select(d.ovl, d.piles, maxinput=maxin)
         sel = piles[:min(len(piles), npl)]
         O, E = _pair(d, **kw)
-        fo, bo = O.run(sel, ovl, d.trace, nthreads=8, want_windows=True)
-        fx, bx = E(sel, ovl, d.trace)
+        fo, bo = O.run(sel, ovl, d.trace, trace_bytes=d.trace_bytes, nthreads=8, want_windows=True)
+        fx, bx = E(sel, ovl, d.trace, trace_bytes=d.trace_bytes)
         t = E.timing()
         tiers += np.array(list(t.tier_out), dtype=np.int64); nwin += int(t.nwindows)
         print("fuzz seed %d config %d: %s %s windows %d handed on %s" % (seed, i, kw, data, t.nwindows, list(t.tier_out)))
@@ -340,6 +342,13 @@ def test_random_parameter_sets():
     """Random run parameters / error profiles / trace spacings / depths (tests/common.py:random_run_config) through the
     C ABI on the GPU: windows and fragments must equal the oracle's bit for bit.  Seeds and configurations are printed."""
     _random_configs(0, 10)
+
+
+def test_random_wide_window_sets():
+    """Random parameter sets with a window of 64 ... 128 bases (tests/common.py:random_run_config_w128; generic engine only): the first
+    six of the thirty sets the emulation ran against the oracle in profiles/r04t_cpu_fuzz_emul_w128.log (same seed)."""
+    from common import random_run_config_w128
+    _random_configs(0, 6, seed=4128, gen=random_run_config_w128)
 
 
 def test_random_parameter_sets_fifty():
