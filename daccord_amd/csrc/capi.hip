@@ -501,6 +501,11 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	if ( !c ) return DACC_ENOMEM;
 	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->long_hint = -1; c->handcap = 0; c->handwords = 0; c->handwant = 0; c->nruns = 0;
 	std::memset(&c->timing,0,sizeof(c->timing));
+	// launch geometry of the LDS tiers: set by every batch that uses them; a generic-only batch (DACC_NOFAST, w >= 64, a model table no
+	// tier holds) reads retry_grid in its scratch retry and must not find an indeterminate value there
+	c->retry_grid = c->early_grid = c->win_grid = 0; c->tier0_grid = 0; c->tier0_ok = false; c->tier0_ran = false; c->tierL_ok = 0; c->usefast = 0; c->sched = 0;
+	for ( int i = 0; i < 3; ++i ) { c->tier_grid[i] = 0; c->tier_ok[i] = 0; c->tier_out[i] = 0; c->gstride[i] = 0; }
+	c->gstride0 = 0; c->tr_grid = c->tr_lds = c->tr_words = c->tr_lanes = c->trace_bytes = 0;
 	{
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
@@ -1001,6 +1006,9 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	else
 	{
 		c->win_grid = boundByArena(wg,BP.caps.bytes,8);
+		c->retry_grid = c->win_grid; c->early_grid = 0;
+		for ( int t = 0; t < 3; ++t ) c->tier_ok[t] = 0;
+		c->tier0_ok = false; c->tierL_ok = 0;
 		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->win_grid)*BP.caps.bytes));
 	}
