@@ -55,7 +55,18 @@ struct Arena
 
 HDEV uint64_t arena_align(uint64_t o) { return (o + 15) & ~static_cast<uint64_t>(15); }
 
-#define DACC_CARVE(field,type,count) A.field = reinterpret_cast<type *>(base + o); o = arena_align(o + sizeof(type)*static_cast<uint64_t>(count));
+// Host emulation only (tests/emul): a guard gap behind every field.  The harness fills the arena with a pattern and checks the gaps after
+// every window, so a write past a field's capacity is caught where it happens instead of landing in the next field unnoticed.  On the
+// device the gap is zero bytes and the layout is what it always was.
+#if defined(DACC_EMUL)
+  #include <vector>
+  enum : uint64_t { ARENA_GUARD = 64 };
+  inline std::vector<uint64_t> * & arenaGuardSink() { static std::vector<uint64_t> * p = 0; return p; }
+  #define DACC_CARVE_GUARD { if ( arenaGuardSink() ) arenaGuardSink()->push_back(o); o += ARENA_GUARD; }
+#else
+  #define DACC_CARVE_GUARD
+#endif
+#define DACC_CARVE(field,type,count) A.field = reinterpret_cast<type *>(base + o); o = arena_align(o + sizeof(type)*static_cast<uint64_t>(count)); DACC_CARVE_GUARD
 
 // carve the arena; returns total bytes (call with base = 0 to size it)
 HDEV uint64_t arena_carve(Arena & A, uint8_t * base, ArenaCaps const & C, uint32_t const w = 0)

@@ -149,8 +149,21 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 	std::memset(static_cast<void *>(wout.data()),arenafill,wout.size()*sizeof(WindowOut));
 	{
 		Arena A; ArenaCaps caps = BP.caps;
-		caps.bytes = arena_carve(A,0,caps,P.w);
+		// guard gaps behind every arena field (arena.hpp): their offsets, and a check that they still hold the fill pattern
+		std::vector<uint64_t> guards;
+		arenaGuardSink() = &guards; caps.bytes = arena_carve(A,0,caps,P.w); arenaGuardSink() = 0;
 		std::vector<uint8_t> arena(caps.bytes+64,arenafill);
+		uint64_t guardbad = 0;
+		auto checkGuards = [&](uint64_t const wdx)
+		{
+			for ( size_t g = 0; g < guards.size(); ++g )
+				for ( uint64_t b = 0; b < ARENA_GUARD; ++b )
+					if ( arena[guards[g]+b] != arenafill )
+					{
+						if ( !guardbad ) std::fprintf(stderr,"[emul] window %llu wrote behind arena field %zu (offset %llu + %llu)\n",static_cast<unsigned long long>(wdx),g,static_cast<unsigned long long>(guards[g]),static_cast<unsigned long long>(b));
+						++guardbad; arena[guards[g]+b] = arenafill;
+					}
+		};
 		WindowBatch WB;
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
@@ -298,14 +311,14 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				wave_run([&]() { int const r = processWindowFast< FastTier<5> >(FBL,earlysnap[i],ldsL.data(),false); if ( wv_lane() == 0 ) rc = r; });
 			}
 			if ( rc == FW_DONE ) { ++c->nlong; continue; }
-			++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); wave_run([&]() { processWindow(WB,earlysnap[i],arena.data()); });
+			++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); wave_run([&]() { processWindow(WB,earlysnap[i],arena.data()); }); checkGuards(earlysnap[i]);
 		}
 		{
 			uint64_t const n = haveList ? cur.size() : BP.nwindows;
 			for ( uint64_t i = 0; i < n; ++i )
 			{
 				uint64_t const wdx = haveList ? cur[i] : i;
-				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); wave_run([&]() { processWindow(WB,wdx,arena.data()); });
+				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); wave_run([&]() { processWindow(WB,wdx,arena.data()); }); checkGuards(wdx);
 			}
 		}
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_RETRY ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
@@ -316,11 +329,13 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) any = true;
 			if ( !any ) break;
 			if ( getenv("DACC_EMUL_VERBOSE") ) { uint64_t n = 0; uint32_t fl = 0; for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) { ++n; fl |= wout[wdx].flags; } std::fprintf(stderr,"[emul] scratch retry %d: %llu windows, flags 0x%x\n",attempt,static_cast<unsigned long long>(n),fl); }
-			growArenaCaps(caps,P.w); caps.bytes = arena_carve(A,0,caps,P.w);
+			growArenaCaps(caps,P.w);
+			guards.clear(); arenaGuardSink() = &guards; caps.bytes = arena_carve(A,0,caps,P.w); arenaGuardSink() = 0;
 			arena.assign(caps.bytes+64,arenafill);
 			WB.C = caps; WB.arena = arena.data();
-			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) wave_run([&]() { processWindow(WB,wdx,arena.data()); });
+			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) { wave_run([&]() { processWindow(WB,wdx,arena.data()); }); checkGuards(wdx); }
 		}
+		if ( guardbad ) { c->err = "a window wrote behind the capacity of an arena field (guard gap overwritten)"; return DACC_EHIP; }
 	}
 	c->windows.clear();
 	bool overflow = false;
