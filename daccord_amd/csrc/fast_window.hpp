@@ -1242,7 +1242,7 @@ struct FastEngine
 				wv_sync();
 				nm = wv_bcast(nm,0);
 				if ( nm > MIDCAP || npool + nm > CT::scap || npool + nm > SMAX ) { over(32); return; }
-				if ( static_cast<uint32_t>(lane) < nm ) makePiece(npool+lane,L.midpar()[lane],L.midA()[lane],L.midB()[lane]);
+				for ( uint32_t m = lane; m < nm; m += WSZ ) makePiece(npool+m,L.midpar()[m],L.midA()[m],L.midB()[m]);      // (nm <= MIDCAP < 64: one round on the device; the 1-lane emulation needs the loop)
 				nmid = nm; npool += nm;
 				wv_sync();
 			}

@@ -34,6 +34,9 @@ struct EmulCtx
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
 
+// (diagnostics: the window and tier being emulated, for a debugger or a signal handler)
+extern "C" { volatile uint64_t dacc_emul_curwin = 0; volatile int dacc_emul_curtier = -1; }
+
 static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 {
 	dacc_params const & p = c.par;
@@ -172,7 +175,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		// hand-over slots as in the library (DACC_HAND=0: off)
 		uint32_t const handwords = (BP.deep ? 2048u + 128u : 1024u + 64u) + 4u;
 		bool const handon = !(getenv("DACC_HAND") && getenv("DACC_HAND")[0] == '0') && c->par.klow == c->par.khigh;
-		std::vector<uint64_t> hand(handon ? static_cast<size_t>(BP.nwindows+1)*handwords : 1,0x0101010101010101ull*arenafill); uint32_t handctr = 0;
+		std::vector<uint64_t> hand(handon ? static_cast<size_t>(BP.nwindows+1)*handwords : 1); uint32_t handctr = 0;
+		// (pattern in the slots that can be used first; the whole buffer is 8 KB per window of the batch and stays untouched pages otherwise)
+		std::fill(hand.begin(),hand.begin()+std::min<size_t>(hand.size(),(64u<<20)/8u),0x0101010101010101ull*arenafill);
 		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3]; std::vector<uint8_t> lds0, gslab0;
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
@@ -232,6 +237,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		// list and, at the end, what the last tier handed over.
 		auto runTier = [&](int const t, uint64_t const wdx, bool const resume) -> int
 		{
+			dacc_emul_curwin = wdx; dacc_emul_curtier = t;
 			if ( getenv("DACC_EMUL_POISON") )
 			{
 				// debugging aid: no window may depend on what an earlier window (or kernel) left in LDS
