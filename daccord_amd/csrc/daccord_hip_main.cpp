@@ -44,7 +44,7 @@ namespace {
 struct Options
 {
 	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
-	bool f = false; int V = 1; bool haveI = false, haveJ = false; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
+	bool f = false; int V = 1; bool haveI = false, haveJ = false; std::string Itext, Jtext; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
 	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
 	bool eprofonly = false, keepeprof = false, deepprofileonly = false; int device = 0; int gpus = 1; uint64_t batch = 2000;
 	std::vector<std::string> pos;
@@ -112,8 +112,8 @@ Options parse(int argc, char ** argv)
 			case 'f': o.f = v.empty() ? true : (num("-f",v) != 0); break;
 			case 't': case 'T': break;
 			case 'E': o.E = v; break;
-			case 'I': o.haveI = true; if ( !parsePair(v,o.Ilo,o.Ihi) ) die("unable to parse " + v); break;
-			case 'J': o.haveJ = true; if ( !parsePair(v,o.Jc,o.Jd) ) die("unable to parse " + v); break;
+			case 'I': o.haveI = true; o.Itext = v; if ( !parsePair(v,o.Ilo,o.Ihi) ) die("unable to parse " + v); break;
+			case 'J': o.haveJ = true; o.Jtext = v; if ( !parsePair(v,o.Jc,o.Jd) ) die("unable to parse " + v); break;
 			case 'k':
 			{
 				int64_t x, y;
@@ -188,21 +188,13 @@ int main(int argc, char ** argv)
 	uint64_t tot = 0; for ( uint64_t i = 0; i < DB2.n; ++i ) tot += DB2.rlen[i];
 	uint64_t const avgrl = DB2.n ? tot/DB2.n : 0;
 
-	// read interval (daccord.cpp:1096-1230)
-	int64_t minaread = lasmin, maxaread = lasmax;
-	if ( o.haveJ )
+	// read interval (daccord.cpp:1115-1227): dacc_read_interval, which tests/test_oracle_vs_ref.py runs against the reference's lines
+	int64_t minaread = 0, toparead = 0;
 	{
-		int64_t const toparead = maxaread + 1, span = toparead > minaread ? toparead-minaread : 0;
-		if ( span && !o.Jd ) die("denominator of J argument cannot be zero");
-		if ( toparead > minaread )
-		{
-			int64_t const part = o.Jd ? (span + o.Jd - 1)/o.Jd : 0;
-			int64_t const ilow = std::min(minaread + o.Jc*part,toparead), ihigh = std::min(ilow+part,toparead);
-			if ( ihigh > ilow ) { minaread = ilow; maxaread = ihigh-1; } else { minaread = 0; maxaread = -1; }
-		}
+		char ebuf[256]; ebuf[0] = 0;
+		if ( dacc_read_interval(lasmin,lasmax,o.haveJ ? o.Jtext.c_str() : 0,o.haveI ? o.Itext.c_str() : 0,&minaread,&toparead,ebuf,sizeof(ebuf)) ) die(ebuf);
 	}
-	else if ( o.haveI ) { minaread = std::max(o.Ilo,minaread); maxaread = std::min(o.Ihi,maxaread); }
-	int64_t const toparead = maxaread >= 0 ? maxaread+1 : maxaread;
+	int64_t const maxaread = toparead - 1;     // (-2 for an empty interval: only compared against minaread below)
 	if ( o.V ) std::fprintf(stderr,"[V] minaread=%lld toparead=%lld\n",static_cast<long long>(minaread),static_cast<long long>(toparead));
 
 	// the .las must belong to this database: the reference's readers throw on an id beyond it

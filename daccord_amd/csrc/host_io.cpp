@@ -387,3 +387,46 @@ int dacc_las_write(const char * path, int32_t tspace, const dacc_overlap * ovl, 
 }
 
 }
+
+// ---- read interval of a run (src/daccord.cpp:1115-1227) ----
+#include <sstream>
+namespace {
+// "<int>,<int>" and nothing else (the reference parses with operator>>, get() == ',', operator>>, peek() == eof: :1122-1153)
+bool parseIntPair(char const * text, int64_t & x, int64_t & y)
+{
+	std::istringstream is((std::string(text)));
+	if ( !(is >> x) ) return false;
+	int const c = is.get();
+	if ( !is || c == std::istringstream::traits_type::eof() || c != ',' ) return false;
+	if ( !(is >> y) ) return false;
+	return is.peek() == std::istringstream::traits_type::eof();
+}
+void setErr(char * err, uint64_t const cap, std::string const & m) { if ( err && cap ) { std::snprintf(err,cap,"%s",m.c_str()); } }
+}
+extern "C" int dacc_read_interval(int64_t las_min, int64_t las_max, char const * J, char const * I, int64_t * minaread_out, int64_t * toparead_out, char * err, uint64_t errcap)
+{
+	if ( !minaread_out || !toparead_out ) return -1;
+	int64_t minaread = las_min, maxaread = las_max;
+	if ( J )
+	{
+		int64_t cnt, div;
+		if ( !parseIntPair(J,cnt,div) ) { setErr(err,errcap,std::string("unable to parse ") + J); return -1; }
+		int64_t const toparead = maxaread + 1, span = toparead > minaread ? toparead-minaread : 0;
+		if ( span && !div ) { setErr(err,errcap,"denominator of J argument cannot be zero"); return -1; }
+		if ( toparead > minaread )
+		{
+			int64_t const part = div ? (span + div - 1)/div : 0;
+			int64_t const ilow = std::min(minaread + cnt*part,toparead), ihigh = std::min(ilow+part,toparead);
+			if ( ihigh > ilow ) { minaread = ilow; maxaread = ihigh-1; } else { minaread = 0; maxaread = -1; }
+		}
+	}
+	else if ( I )
+	{
+		int64_t lo, hi;
+		if ( !parseIntPair(I,lo,hi) ) { setErr(err,errcap,std::string("unable to parse ") + I); return -1; }
+		minaread = std::max(lo,minaread); maxaread = std::min(hi,maxaread);
+	}
+	*minaread_out = minaread;
+	*toparead_out = maxaread >= 0 ? maxaread+1 : maxaread;
+	return 0;
+}

@@ -35,6 +35,7 @@ def lib():
         L.dacc_eprof_set_deep.argtypes = [vp, C.c_int]
         L.dacc_eprof_deep.argtypes = [vp, vp, vp]
         L.dacc_eprof_skipped.argtypes = [vp, vp, vp]
+        L.dacc_read_interval.argtypes = [C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_uint64]
         _lib = L
     return _lib
 
@@ -154,3 +155,14 @@ def estimate_profile(bps, boff, rlen, tspace, piles, ovl, trace, trace_bytes=1, 
         return counts, us.value, un.value, tuple(float(x) for x in prof)
     finally:
         L.dacc_eprof_destroy(h)
+
+
+def read_interval(las_min, las_max, J=None, I=None):
+    """The A reads [minaread, toparead) of a run: -J "part,parts" or -I "first,last" applied to the A reads of the overlap file
+    (include/daccord_io.h: dacc_read_interval; src/daccord.cpp:1115-1227).  ValueError with the message for text that does not parse."""
+    lo = C.c_int64(); top = C.c_int64(); err = C.create_string_buffer(256)
+    rc = lib().dacc_read_interval(las_min, las_max, J.encode() if J is not None else None, I.encode() if I is not None else None,
+                                  C.byref(lo), C.byref(top), err, 256)
+    if rc:
+        raise ValueError(err.value.decode())
+    return lo.value, top.value

@@ -58,6 +58,14 @@ const char *dacc_las_error(dacc_las *las);
 int  dacc_las_write(const char *path, int32_t tspace, const dacc_overlap *ovl, uint64_t novl,
                     const void *trace, uint64_t ntrace, int trace_bytes);
 
+/* ---- the A reads of a run: -J part,parts or -I first,last applied to the A reads [las_min,las_max] of the overlap file
+ * (src/daccord.cpp:1115-1227; -J is also how N processes / GPUs share one file, :1156-1183).  J / I: the option's text
+ * ("2,8", "100,199") or NULL; J wins when both are given, as in the reference (else-if).  The run covers the A reads
+ * [*minaread,*toparead); an empty part comes back as minaread = 0, toparead = -1 (the reference's "maxaread = -1").
+ * DACC_EINVAL: text that does not parse as <int>,<int>, or a zero denominator over a non-empty span (message in err). ---- */
+int  dacc_read_interval(int64_t las_min, int64_t las_max, const char *J, const char *I,
+                        int64_t *minaread, int64_t *toparead, char *err, uint64_t errcap);
+
 /* ---- truth-based accuracy check of a corrected fragment (the measurement of the package's checkconsensus tool,
  * src/checkconsensus.cpp:730-1075): the fragment (ASCII) is aligned completely to a window of the true sequence with free
  * ends, inside a band of +-band around the line from column c0 (fragment start) to c1 (fragment end).

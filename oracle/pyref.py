@@ -57,6 +57,7 @@ def lib(k16=False):
         L.ref_tables.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
         L.ref_pile_select_lowest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.ref_pile_select.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_read_interval.argtypes = [C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_uint64]
         L.ref_estimate_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _libs[k16] = L
     return _libs[k16]
@@ -95,6 +96,18 @@ def pile_select(ovl, piles, trace_bytes=1, maxinput=5000, vard=0, rl=None, avgre
             raise RuntimeError("ref_pile_select: %d (-9: oracle/_ref built without the selection lines, -2: a copied record differs)" % rc)
         out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value; lm.append(l.value)
     return out[:o].copy(), newp, lm
+
+
+def read_interval(las_min, las_max, J=None, I=None):
+    """src/daccord.cpp:1119-1224 + :1227 compiled from the reference's lines: (minaread, toparead), or ValueError with its message"""
+    L = lib(False)
+    lo = C.c_int64(); top = C.c_int64(); err = C.create_string_buffer(512)
+    rc = L.ref_read_interval(las_min, las_max, J.encode() if J is not None else None, I.encode() if I is not None else None, C.byref(lo), C.byref(top), err, 512)
+    if rc == -9:
+        raise RuntimeError("oracle/_ref was built without the read interval lines")
+    if rc:
+        raise ValueError(err.value.decode())
+    return lo.value, top.value
 
 
 class Reference:

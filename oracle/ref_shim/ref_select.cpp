@@ -157,4 +157,37 @@ int ref_pile_select(dacc_overlap const * in, uint64_t n, int trace_bytes, uint64
 #endif
 }
 
+
+// The A reads of a run, src/daccord.cpp:1119-1224 (the -J part,parts and -I first,last branches with their parsing) and :1227
+// (toparead), compiled from the reference's lines: arg is the two options' text, minaread / maxaread enter as the first and last
+// A read of the overlap file (:1115-1116).  Returns 1 with the reference's message when its code throws.
+int ref_read_interval(int64_t lasmin, int64_t lasmax, char const * J, char const * I, int64_t * minout, int64_t * topout, char * err, uint64_t errcap)
+{
+#if defined(DACC_REF_IVL_A_EXCERPT) && defined(DACC_REF_IVL_B_EXCERPT)
+	struct Arg
+	{
+		char const * J; char const * I;
+		bool uniqueArgPresent(std::string const & k) const { return k == "J" ? (J != 0) : (k == "I" ? (I != 0) : false); }
+		std::string operator[](std::string const & k) const { return std::string(k == "J" ? J : I); }
+	} arg; arg.J = J; arg.I = I;
+	int64_t minaread = lasmin;
+	int64_t maxaread = lasmax;
+	try
+	{
+		#include DACC_REF_IVL_A_EXCERPT
+	}
+	catch(std::exception const & ex)
+	{
+		if ( err && errcap ) std::snprintf(err,errcap,"%s",ex.what());
+		return 1;
+	}
+	#include DACC_REF_IVL_B_EXCERPT
+	*minout = minaread; *topout = toparead;
+	return 0;
+#else
+	(void)lasmin; (void)lasmax; (void)J; (void)I; (void)minout; (void)topout; (void)err; (void)errcap;
+	return -9;
+#endif
+}
+
 }

@@ -186,6 +186,55 @@ def test_main_pile_selection_vard_formula():
             assert oo.tobytes() == orf[pr[i]["first_ovl"]:pr[i]["first_ovl"] + pr[i]["novl"]].tobytes()
 
 
+def test_read_interval_against_the_reference_lines():
+    """-J part,parts (how N processes / GPUs share one overlap file) and -I first,last: src/daccord.cpp:1119-1224 + :1227 compiled
+    from its lines against the product (dacc_read_interval, which the C++ front end calls) and daccord_amd.shard.shard_range (what
+    bench.py shards with) -- values, the empty part, and which texts are refused"""
+    from daccord_amd import io as dio
+    from daccord_amd.shard import shard_range
+    import itertools
+    n = 0
+    for (lo, hi) in ((0, 9999), (0, 0), (5, 4), (17, 1016), (0, -1), (3, 3), (100, 107)):
+        for G in (1, 2, 3, 4, 7, 8, 16, 1000, 20000):
+            for g in list(range(min(G, 9))) + [G - 1, G, G + 5]:
+                J = "%d,%d" % (g, G)
+                r = pyref.read_interval(lo, hi, J=J); x = dio.read_interval(lo, hi, J=J)
+                assert r == x, (lo, hi, J, r, x)
+                if hi >= lo and 0 <= g:
+                    a, b = shard_range(lo, hi + 1, g, G)
+                    assert (r[1] - r[0] if r[1] > r[0] else 0) == b - a and (b == a or (a, b) == r), (lo, hi, J, r, (a, b))
+                n += 1
+        for I in ("0,5", "3,3", "10,5", "-5,100000", "50,60", "9999,9999", "0,-1"):
+            assert pyref.read_interval(lo, hi, I=I) == dio.read_interval(lo, hi, I=I), (lo, hi, I)
+        # J wins over I (else-if)
+        assert pyref.read_interval(lo, hi, J="1,2", I="0,1") == dio.read_interval(lo, hi, J="1,2", I="0,1")
+    # the parts of -J g,G cover the A reads exactly once, in order
+    for (lo, hi, G) in ((0, 9999, 8), (17, 1016, 7), (0, 6, 8), (3, 3, 2)):
+        got = []
+        for g in range(G):
+            a, b = dio.read_interval(lo, hi, J="%d,%d" % (g, G))
+            got += list(range(a, b)) if b > a else []
+        assert got == list(range(lo, hi + 1))
+    # what is refused, by both: not <int>,<int>; a zero denominator over a non-empty span
+    for bad in ("", "1", "1,", ",2", "1;2", "1,2,3", "1,2x", "a,b", "1 ,2", "1,2 "):
+        for kw in (dict(J=bad), dict(I=bad)):
+            er = ex = None
+            try:
+                pyref.read_interval(0, 99, **kw)
+            except ValueError as e:
+                er = str(e)
+            try:
+                dio.read_interval(0, 99, **kw)
+            except ValueError as e:
+                ex = str(e)
+            assert (er is None) == (ex is None), (kw, er, ex)
+    for f in (pyref.read_interval, dio.read_interval):
+        with pytest.raises(ValueError):
+            f(0, 99, J="0,0")
+        assert f(5, 4, J="0,0") == f(5, 4, J="0,1")       # empty span: the denominator is not looked at
+    assert n > 500
+
+
 def test_random_parameter_sets():
     """a few rounds of scripts/fuzz_oracle_vs_ref.py (narrow and wide) inside the CPU suite"""
     for args in (["20260922", "3"], ["22", "1", "--wide"]):      # (k = 14, 9, 8; a two-byte trace set; the k = 14...16 sets are in the profiles/ log)
