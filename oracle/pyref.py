@@ -58,6 +58,7 @@ def lib(k16=False):
         L.ref_pile_select_lowest.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
         L.ref_pile_select.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_read_interval.argtypes = [C.c_int64, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, C.c_uint64]
+        L.ref_defaults.argtypes = [C.c_void_p]
         L.ref_estimate_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
         _libs[k16] = L
     return _libs[k16]
@@ -96,6 +97,15 @@ def pile_select(ovl, piles, trace_bytes=1, maxinput=5000, vard=0, rl=None, avgre
             raise RuntimeError("ref_pile_select: %d (-9: oracle/_ref built without the selection lines, -2: a copied record differs)" % rc)
         out[o:o + n.value] = dst[:n.value]; newp[i]["first_ovl"] = o; newp[i]["novl"] = n.value; o += n.value; lm.append(l.value)
     return out[:o].copy(), newp, lm
+
+
+def defaults():
+    """src/daccord.cpp:106-169 compiled from its lines: the option defaults as a dict"""
+    L = lib(False)
+    out = (C.c_uint64 * 13)()
+    if L.ref_defaults(out):
+        raise RuntimeError("oracle/_ref was built without the option defaults")
+    return dict(zip(("V", "k", "D", "vard", "d", "w", "a", "f", "m", "e", "l", "minfilterfreq", "maxfilterfreq"), [int(x) for x in out]))
 
 
 def read_interval(las_min, las_max, J=None, I=None):

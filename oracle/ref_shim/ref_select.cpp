@@ -96,6 +96,12 @@ struct OverlapParser
 #undef NDEBUG
 #include <cassert>
 
+#if defined(DACC_REF_DEFAULTS_EXCERPT)
+namespace refdefaults {
+#include DACC_REF_DEFAULTS_EXCERPT
+}
+#endif
+
 extern "C" {
 
 // One pile's records (file order) -> raw .las bytes -> the reference's selection (:2120-2288) -> the selected records in the
@@ -187,6 +193,21 @@ int ref_read_interval(int64_t lasmin, int64_t lasmax, char const * J, char const
 #else
 	(void)lasmin; (void)lasmax; (void)J; (void)I; (void)minout; (void)topout; (void)err; (void)errcap;
 	return -9;
+#endif
+}
+
+
+// The option defaults of src/daccord.cpp:106-169 (compiled from its lines): V, k, D, vard, d, w, a, f, m, e, l, minfilterfreq, maxfilterfreq
+int ref_defaults(uint64_t * out)
+{
+#if defined(DACC_REF_DEFAULTS_EXCERPT)
+	using namespace refdefaults;
+	out[0] = getDefaultVerbose(); out[1] = getDefaultK(); out[2] = getDefaultMaxInput(); out[3] = getDefaultVarD(); out[4] = getDefaultMaxAlign();
+	out[5] = getDefaultWindowSize(); out[6] = getDefaultAdvanceSize(); out[7] = getDefaultProduceFull(); out[8] = getDefaultMinWindowCoverage();
+	out[9] = getDefaultMinWindowError(); out[10] = getDefaultMinLen(); out[11] = getDefaultMinFilterFreq(); out[12] = getDefaultMaxFilterFreq();
+	return 0;
+#else
+	(void)out; return -9;
 #endif
 }
 

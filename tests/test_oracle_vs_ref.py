@@ -186,6 +186,22 @@ def test_main_pile_selection_vard_formula():
             assert oo.tobytes() == orf[pr[i]["first_ovl"]:pr[i]["first_ovl"] + pr[i]["novl"]].tobytes()
 
 
+def test_option_defaults_are_the_reference_ones():
+    """src/daccord.cpp:106-169 (getDefault*), compiled from its lines, against default_params() (the mirror the tests and bench.py use)
+    and the usage text of the C++ front end"""
+    import re
+    d = pyref.defaults()
+    p = default_params()
+    assert (p.w, p.a, p.klow, p.khigh, p.minwindowcov, p.maxalign, p.eminrate, p.minlen, p.producefull, p.minfilterfreq, p.maxfilterfreq) == \
+           (d["w"], d["a"], d["k"], d["k"], d["m"], d["d"], d["e"], d["l"], d["f"], d["minfilterfreq"], d["maxfilterfreq"])
+    assert d["D"] == 5000 and d["vard"] == 0 and d["d"] == 2 ** 64 - 1 and d["e"] == 2 ** 64 - 1
+    src = open(os.path.join(ROOT, "daccord_amd", "csrc", "daccord_hip_main.cpp")).read()
+    m = re.search(r"uint32_t w = (\d+), a = (\d+), m = (\d+); uint64_t d = UINT64_MAX, e = UINT64_MAX, l = (\d+), D = (\d+), vard = (\d+);", src)
+    assert m and tuple(int(x) for x in m.groups()) == (d["w"], d["a"], d["m"], d["l"], d["D"], d["vard"])
+    m = re.search(r"uint32_t klow = (\d+), khigh = (\d+); int32_t minff = (\d+), maxff = (\d+);", src)
+    assert m and tuple(int(x) for x in m.groups()) == (d["k"], d["k"], d["minfilterfreq"], d["maxfilterfreq"])
+
+
 def test_read_interval_against_the_reference_lines():
     """-J part,parts (how N processes / GPUs share one overlap file) and -I first,last: src/daccord.cpp:1119-1224 + :1227 compiled
     from its lines against the product (dacc_read_interval, which the C++ front end calls) and daccord_amd.shard.shard_range (what
