@@ -30,12 +30,16 @@ head -1 "$EXC5" | grep -q "struct OverlapEntry" && grep -q "inputbuffersize = 64
 EXC7="$OUT/.ivl_a_excerpt.$$.hpp"; EXC8="$OUT/.ivl_b_excerpt.$$.hpp"
 sed -n '1119,1224p' "$REF/daccord.cpp" > "$EXC7"; sed -n '1227,1227p' "$REF/daccord.cpp" > "$EXC8"
 head -1 "$EXC7" | grep -q 'if ( arg.uniqueArgPresent("J") )' && grep -q "int64_t const toparead = maxaread >= 0 ? maxaread + 1 : maxaread;" "$EXC8" || { echo "ref_shim/build.sh: read interval code not at the expected lines of daccord.cpp"; rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4" "$EXC5" "$EXC6" "$EXC7" "$EXC8"; exit 1; }
+# ... the error rates derived from the estimator's counts (:1867-1878: len, numerr, est_cor, p_i, p_d)
+EXC10="$OUT/.rates_excerpt.$$.hpp"
+sed -n '1867,1878p' "$REF/daccord.cpp" > "$EXC10"
+head -1 "$EXC10" | grep -q "uint64_t const len = GAS.matches + GAS.mismatches + GAS.deletions;" && grep -q "double const p_d = " "$EXC10" || { echo "ref_shim/build.sh: rate formulas not at the expected lines of daccord.cpp"; rm -f "$EXC10"; exit 1; }
 # ... and the defaults of the options (:106-169, the getDefault* functions behind the help text and the argument parser)
 EXC9="$OUT/.defaults_excerpt.$$.hpp"
 sed -n '106,169p' "$REF/daccord.cpp" > "$EXC9"
 head -1 "$EXC9" | grep -q "static uint64_t getDefaultVerbose()" && grep -q "static uint64_t getDefaultMaxFilterFreq()" "$EXC9" || { echo "ref_shim/build.sh: option defaults not at the expected lines of daccord.cpp"; rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4" "$EXC5" "$EXC6" "$EXC7" "$EXC8" "$EXC9"; exit 1; }
-trap 'rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4" "$EXC5" "$EXC6" "$EXC7" "$EXC8" "$EXC9"' EXIT
-FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\" -DDACC_REF_CMP_EXCERPT=\"$EXC2\" -DDACC_REF_PFG_EXCERPT=\"$EXC3\" -DDACC_REF_SEL_EXCERPT=\"$EXC4\" -DDACC_REF_MAINSEL_A_EXCERPT=\"$EXC5\" -DDACC_REF_MAINSEL_B_EXCERPT=\"$EXC6\" -DDACC_REF_IVL_A_EXCERPT=\"$EXC7\" -DDACC_REF_IVL_B_EXCERPT=\"$EXC8\" -DDACC_REF_DEFAULTS_EXCERPT=\"$EXC9\""
+trap 'rm -f "$EXC" "$EXC2" "$EXC3" "$EXC4" "$EXC5" "$EXC6" "$EXC7" "$EXC8" "$EXC9" "$EXC10"' EXIT
+FLAGS="-O2 -std=c++17 -fPIC -fopenmp -ffp-contract=off -shared -DNDEBUG -w -DDACC_REF_ESTIMATE_EXCERPT=\"$EXC\" -DDACC_REF_CMP_EXCERPT=\"$EXC2\" -DDACC_REF_PFG_EXCERPT=\"$EXC3\" -DDACC_REF_SEL_EXCERPT=\"$EXC4\" -DDACC_REF_MAINSEL_A_EXCERPT=\"$EXC5\" -DDACC_REF_MAINSEL_B_EXCERPT=\"$EXC6\" -DDACC_REF_IVL_A_EXCERPT=\"$EXC7\" -DDACC_REF_IVL_B_EXCERPT=\"$EXC8\" -DDACC_REF_DEFAULTS_EXCERPT=\"$EXC9\" -DDACC_REF_RATES_EXCERPT=\"$EXC10\""
 g++ $FLAGS -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref.so" "$HERE/ref_capi.cpp" "$HERE/ref_select.cpp" &
 g++ $FLAGS -DDACC_REF_K16 -I"$HERE/k16" -I"$HERE" -I"$REF" -o "$OUT/libdaccord_ref_k16.so" "$HERE/ref_capi.cpp" "$HERE/ref_select.cpp" &
 wait

@@ -313,12 +313,16 @@ int ref_estimate_profile(void * v, dacc_pile const * piles, uint64_t npiles, dac
 			for ( uint64_t i = 0; i < D.size() && i < cap; ++i ) out[i] = D[i];
 			*ndeep = D.size();
 		}
-		uint64_t const len = GAS.matches + GAS.mismatches + GAS.deletions;                   // daccord.cpp:1867-1878
-		uint64_t const numerr = GAS.mismatches + GAS.deletions + GAS.insertions;
-		if ( !len ) return -1;
-		double const est_erate = static_cast<double>(numerr) / len;
-		prof[0] = static_cast<double>(GAS.insertions) / len; prof[1] = static_cast<double>(GAS.deletions) / len; prof[2] = 1.0 - est_erate;
+		if ( !(GAS.matches + GAS.mismatches + GAS.deletions) ) return -1;
+		// the rates the tables are built from, daccord.cpp:1867-1878 (len, numerr, est_cor, p_i, p_d, ...), compiled from its lines
+		#if defined(DACC_REF_RATES_EXCERPT)
+		#include DACC_REF_RATES_EXCERPT
+		(void)est_i_frac; (void)est_d_frac; (void)est_s_frac; (void)p_s;
+		prof[0] = p_i; prof[1] = p_d; prof[2] = est_cor;
 		return 0;
+		#else
+		return -9;
+		#endif
 	}
 	catch ( std::exception const & ex ) { c->err = ex.what(); return -2; }
 #else
