@@ -344,13 +344,6 @@ def test_random_parameter_sets():
     _random_configs(0, 10)
 
 
-def test_random_wide_window_sets():
-    """Random parameter sets with a window of 64 ... 128 bases (tests/common.py:random_run_config_w128; generic engine only): the first
-    six of the thirty sets the emulation ran against the oracle in profiles/r04t_cpu_fuzz_emul_w128.log (same seed)."""
-    from common import random_run_config_w128
-    _random_configs(0, 6, seed=4128, gen=random_run_config_w128)
-
-
 def test_random_parameter_sets_fifty():
     """The randomized parity runs on the real 64-lane build (the CPU fuzzing covers the same generator on the host
     emulation): 50 more parameter sets from a second seed."""

@@ -1,6 +1,7 @@
 """GPU parity of what was written after round 2's last GPU run: B window strings beyond 128 / 256 bases in the generic engine
-(string stride from the host plan).  Last in the collection order on purpose: these two have only run on
-the 1- and 64-lane emulation (tests/test_emul_parity.py) so far."""
+(string stride from the host plan).  Last in the collection order on purpose: what is here had only run
+on the 1- and 64-lane emulation (tests/test_emul_parity.py) when it was written -- the long-string tests in round 2 (green on the
+device since), the random wide-window sets in round 4 (the wide-window path itself ran on the device: profiles/r04t_*)."""
 import numpy as np
 import pytest
 import pyoracle
@@ -46,3 +47,12 @@ def test_window_strings_beyond_256_bases():
     fo, bo = O.run(piles[:2], ovl, tr, trace_bytes=2, nthreads=8, want_windows=True)
     assert windows_equal(O.windows(), E.debug_windows()) == []
     assert frags_equal(fo, bo, fx, bx) and len(bo) > 3000
+
+
+@pytest.mark.gpu
+def test_random_wide_window_sets():
+    """Random parameter sets with a window of 64 ... 128 bases (tests/common.py:random_run_config_w128; generic engine only): the first
+    six of the thirty sets the emulation ran against the oracle in profiles/r04t_cpu_fuzz_emul_w128.log (same seed)."""
+    from common import random_run_config_w128
+    from test_gpu_parity import _random_configs
+    _random_configs(0, 6, seed=4128, gen=random_run_config_w128)
