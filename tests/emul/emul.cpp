@@ -6,6 +6,7 @@
  */
 #define DACC_EMUL 1
 #include <vector>
+#include <time.h>
 #include <cstdio>
 #include <string>
 #include <cstring>
@@ -84,6 +85,41 @@ int emul_load_db(void * v, uint8_t const * bps, uint64_t nb, uint64_t const * bo
 	EmulCtx * c = static_cast<EmulCtx *>(v);
 	c->bps.assign(bps,bps+nb); c->bps.resize(nb+16,0); c->boff.assign(boff,boff+nreads); c->rlen.assign(rlen,rlen+nreads);
 	return 0;
+}
+
+// FNV-1a over everything BatchPlan::plan produces (tests/test_plan.py: the plan of a batch is a pure function of its input, and its
+// digest for a set of inputs -- malformed piles included -- is committed; a faster planner must reproduce it)
+static void fnv(uint64_t & h, void const * p, size_t n) { uint8_t const * b = static_cast<uint8_t const *>(p); for ( size_t i = 0; i < n; ++i ) { h ^= b[i]; h *= 1099511628211ull; } }
+uint64_t emul_plan_digest(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes, int * rcout)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	BatchPlan BP; std::string err;
+	int const rc = BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->rlen.data(),c->rlen.size(),err,c->H.nrows,c->H.nsup);
+	if ( rcout ) *rcout = rc;
+	uint64_t h = 1469598103934665603ull;
+	fnv(h,&rc,sizeof(rc)); fnv(h,err.data(),err.size());
+	if ( rc ) return h;
+	for ( size_t i = 0; i < BP.piles.size(); ++i ) { DevPile const & d = BP.piles[i]; uint64_t f[9] = { static_cast<uint64_t>(static_cast<int64_t>(d.aread)),d.novl,d.first_ovl,d.l,d.nwin,d.winbase,d.posbase,d.rl,d.pad }; fnv(h,f,sizeof(f)); }
+	for ( size_t i = 0; i < BP.ovl.size(); ++i ) { DevOvl const & o = BP.ovl[i]; int64_t f[13] = { o.bread,static_cast<int64_t>(o.flags),o.abpos,o.aepos,o.bbpos,o.bepos,static_cast<int64_t>(o.ekey),o.y0,o.ny,o.nblk,static_cast<int64_t>(o.wtoff),static_cast<int64_t>(o.blk0),static_cast<int64_t>(o.trace_off) }; fnv(h,f,sizeof(f)); }
+	if ( BP.ovl_pile.size() ) fnv(h,BP.ovl_pile.data(),BP.ovl_pile.size()*sizeof(uint32_t));
+	if ( BP.fragbase.size() ) fnv(h,BP.fragbase.data(),BP.fragbase.size()*sizeof(uint64_t));
+	uint64_t sc[12] = { BP.nwindows,BP.nblocks,BP.nwt,BP.npos,BP.nfragslots,BP.algo_bytes,BP.maxdepth,BP.maxcols,BP.maxspan,BP.ndeepwin,BP.deep ? 1u : 0u,BP.piles.size() };
+	fnv(h,sc,sizeof(sc));
+	uint64_t cp[13] = { BP.caps.maxs,BP.caps.precap,BP.caps.nodecap,BP.caps.fcap,BP.caps.strcap,BP.caps.linkcap,BP.caps.sfcap,BP.caps.rlcap,BP.caps.poolcap,BP.caps.blcap,BP.caps.conscap,BP.caps.lstr,BP.caps.bytes };
+	fnv(h,cp,sizeof(cp));
+	if ( BP.pile_status.size() ) fnv(h,BP.pile_status.data(),BP.pile_status.size()*sizeof(int32_t));
+	for ( size_t i = 0; i < BP.pile_errors.size(); ++i ) { fnv(h,BP.pile_errors[i].data(),BP.pile_errors[i].size()); fnv(h,"|",1); }
+	return h;
+}
+
+// host planning of a batch alone (BatchPlan::plan, what dacc_submit_piles does before any upload): seconds of `reps` runs
+double emul_plan_seconds(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes, int reps)
+{
+	EmulCtx * c = static_cast<EmulCtx *>(v);
+	struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC,&t0);
+	for ( int r = 0; r < reps; ++r ) { BatchPlan BP; if ( BP.plan(c->par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,c->rlen.data(),c->rlen.size(),c->err,c->H.nrows,c->H.nsup) ) return -1.0; }
+	clock_gettime(CLOCK_MONOTONIC,&t1);
+	return (t1.tv_sec-t0.tv_sec) + 1e-9*(t1.tv_nsec-t0.tv_nsec);
 }
 
 int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes)
