@@ -21,7 +21,13 @@ from daccord_amd import engine  # noqa: E402
 GOLD = os.path.join(HERE, "golden", "plan_digests.json")
 
 
+_CASES = None
+
+
 def _cases():
+    global _CASES
+    if _CASES is not None:
+        return _CASES
     out = []
     specs = [("narrow_k8", dict(k=8), dict(genome_len=60000, nreads=150, read_len=3000, seed=1), 5000),
              ("narrow_k14_top10", dict(k=14), dict(genome_len=60000, nreads=300, read_len=3000, seed=2, erate=0.2), 10),
@@ -47,6 +53,7 @@ def _cases():
         if name == "narrow_k8":
             p3 = piles.copy(); p3[2]["aread"] = 10 ** 6                                # pile out of range: the whole call fails
             out.append((name + "_pile_out_of_range", kw, d, ovl.copy(), p3, d.trace.copy()))
+    _CASES = out
     return out
 
 
