@@ -88,6 +88,19 @@ def test_plan_reproduces_the_committed_digests(threads):
     assert G["narrow_k8_pile_out_of_range"][1] != 0 and G["narrow_k8_malformed"][1] == 0 and G["narrow_k8"][0] != G["narrow_k8_malformed"][0]
 
 
+def test_plan_has_no_data_race(tmp_path):
+    """the planner's threads under ThreadSanitizer (tests/emul/plan_tsan.cpp): no report, one digest for 1 / 8 / 3 / 16 threads"""
+    import subprocess
+    exe = str(tmp_path / "plan_tsan")
+    cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-o", exe, os.path.join(HERE, "emul", "plan_tsan.cpp")],
+                        capture_output=True, text=True)
+    if cc.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for this compiler: " + cc.stderr[-300:])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ThreadSanitizer" not in (r.stdout + r.stderr) and "MISMATCH" not in r.stdout, (r.stdout + r.stderr)[-2000:]
+    assert len(set(l.split()[-1] for l in r.stdout.splitlines() if l.startswith("threads"))) == 1
+
+
 if __name__ == "__main__":
     if "--write" in sys.argv:
         json.dump(_all(), open(GOLD, "w"), indent=1, sort_keys=True)
