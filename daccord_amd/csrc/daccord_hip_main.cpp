@@ -14,9 +14,10 @@
  *                        numbering; with -t>1 its numbering depends on the thread schedule)
  *   :2464-2478           a read that fails is logged on stderr and skipped
  * -t and -T are accepted and ignored (no host worker threads, no temporary files).  The error profile comes from
- * --eprof<p_i,p_d,est_cor>, from -E<file> / <las>.eprof holding the three numbers as text (our own format: the binary
- * .eprof of the reference is a libmaus2 serialisation that is not in the reference tree), or is estimated from the
- * first 1024 piles like src/daccord.cpp:1653-1878 does and written to that file (--eprofonly: stop there; no GPU needed).
+ * --eprof<p_i,p_d,est_cor>, from -E<file> / <las>.eprof -- the three numbers as text (our own form) or the reference's 48-byte
+ * binary form (src/daccord.cpp:1855-1864: libmaus2 AlignmentStatistics + two doubles; the form is detected) --, or is estimated from the
+ * first 1024 piles like src/daccord.cpp:1653-1878 does and written to that file as text, with --binaryeprof in the reference's form
+ * (--eprofonly: stop there; no GPU needed).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +47,7 @@ struct Options
 	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
 	bool f = false; int V = 1; bool haveI = false, haveJ = false; std::string Itext, Jtext; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
 	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
-	bool eprofonly = false, keepeprof = false, deepprofileonly = false; int device = 0; int gpus = 1; uint64_t batch = 2000;
+	bool eprofonly = false, keepeprof = false, deepprofileonly = false, binaryeprof = false; int device = 0; int gpus = 1; uint64_t batch = 2000;
 	std::vector<std::string> pos;
 };
 
@@ -90,6 +91,7 @@ Options parse(int argc, char ** argv)
 			else if ( val("vard",v) ) o.vard = num("--vard",v);
 			else if ( val("eprofonly",v) ) o.eprofonly = v.empty() || v != "0";
 			else if ( val("keepeprof",v) ) o.keepeprof = v.empty() || v != "0";
+			else if ( val("binaryeprof",v) ) o.binaryeprof = v.empty() || v != "0";
 			else if ( val("eprof",v) ) o.eprof = v;
 			else if ( val("device",v) ) o.device = static_cast<int>(num("--device",v));
 			else if ( val("gpus",v) ) { o.gpus = static_cast<int>(num("--gpus",v)); if ( o.gpus < 1 || o.gpus > 64 ) die("--gpus needs a number between 1 and 64"); }
@@ -130,6 +132,7 @@ Options parse(int argc, char ** argv)
 			"  -m<3> min window coverage  -e<max window error>  -l<0> min output length  -f produce full reads\n"
 			"  -I<lo,hi> read interval (inclusive)  -J<i,j> part i of j  --minfilterfreq<0> --maxfilterfreq<2>\n"
 			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof  --deepprofileonly\n"
+			"  --binaryeprof             write an estimated profile in the reference's binary form (read in either form)\n"
 			"  --device<0> first HIP device  --gpus<1> devices used by this process (batches are dealt to them, output stays ordered)\n"
 			"  --batch<2000> A reads per GPU batch  (or one process per GPU like the reference: -J<g,G> --device<g>)\n");
 		std::exit(EXIT_FAILURE);
@@ -137,11 +140,51 @@ Options parse(int argc, char ** argv)
 	return o;
 }
 
-bool readProfileText(std::string const & fn, double v[3])
+// The reference's own .eprof (daccord.cpp:1855-1860: GAS.serialise + two serialiseDouble; read back by GAS.deserialise, :1864): 48
+// bytes -- libmaus2 AlignmentStatistics {matches, mismatches, insertions, deletions} as four 8-byte big-endian numbers
+// (NumberSerialisation::serialiseNumber), then eavg and edif as raw host-order doubles.  libmaus2 is not in the reference tree: the layout
+// is its published one, restated here, and has not met a file written by the reference.  The rates follow from the counts
+// exactly as daccord.cpp:1867-1878 computes them after deserialising.
+size_t const refProfileBytes = 48;
+bool decodeProfileBinary(std::string const & s, double v[3], uint64_t counts[4])
 {
-	std::ifstream in(fn.c_str());
+	if ( s.size() != refProfileBytes ) return false;
+	for ( int i = 0; i < 4; ++i )
+	{
+		uint64_t x = 0;
+		for ( int j = 0; j < 8; ++j ) x = (x << 8) | static_cast<uint8_t>(s[8*i+j]);
+		counts[i] = x;
+	}
+	// matches + mismatches + deletions is a sum of base counts of at most 1024 piles: anything near 2^63 is not a profile
+	for ( int i = 0; i < 4; ++i ) if ( counts[i] >> 56 ) return false;
+	uint64_t const len = counts[0] + counts[1] + counts[3], numerr = counts[1] + counts[3] + counts[2];
+	if ( !len ) return false;
+	v[0] = static_cast<double>(counts[2])/len; v[1] = static_cast<double>(counts[3])/len; v[2] = 1.0 - static_cast<double>(numerr)/len;
+	return true;
+}
+std::string encodeProfileBinary(uint64_t const counts[4], double eavg, double edif)
+{
+	std::string s(refProfileBytes,'\0');
+	for ( int i = 0; i < 4; ++i ) for ( int j = 0; j < 8; ++j ) s[8*i+j] = static_cast<char>((counts[i] >> (8*(7-j))) & 0xff);
+	std::memcpy(&s[32],&eavg,8); std::memcpy(&s[40],&edif,8);
+	return s;
+}
+
+// an error profile file: our text form (three numbers p_i p_d est_cor, blanks or commas between them) or the reference's binary form;
+// *binary says which one it was
+bool readProfile(std::string const & fn, double v[3], bool * binary)
+{
+	std::ifstream in(fn.c_str(),std::ios::binary);
 	if ( !in ) return false;
 	std::string s((std::istreambuf_iterator<char>(in)),std::istreambuf_iterator<char>());
+	bool text = !s.empty();
+	for ( size_t i = 0; i < s.size() && text; ++i )
+	{
+		unsigned char const c = static_cast<unsigned char>(s[i]);
+		text = (c >= 0x20 && c < 0x7f) || c == '\n' || c == '\r' || c == '\t';
+	}
+	if ( binary ) *binary = !text;
+	if ( !text ) { uint64_t counts[4]; return decodeProfileBinary(s,v,counts); }
 	for ( size_t i = 0; i < s.size(); ++i ) if ( s[i] == ',' ) s[i] = ' ';
 	std::istringstream is(s);
 	return static_cast<bool>(is >> v[0] >> v[1] >> v[2]);
@@ -251,7 +294,9 @@ int main(int argc, char ** argv)
 			( se.st_mtim.tv_sec < sl.st_mtim.tv_sec || (se.st_mtim.tv_sec == sl.st_mtim.tv_sec && se.st_mtim.tv_nsec < sl.st_mtim.tv_nsec) );
 		if ( exists && !(older && !o.keepeprof) )
 		{
-			if ( !readProfileText(eproffn,prof) ) die("cannot parse the error profile " + eproffn + " (three numbers: p_i p_d est_cor)");
+			bool bin = false;
+			if ( !readProfile(eproffn,prof,&bin) ) die("cannot parse the error profile " + eproffn + " (three numbers p_i p_d est_cor as text, or the reference's 48-byte binary profile)");
+			if ( o.V ) std::fprintf(stderr,"[V] error profile %s read (%s)\n",eproffn.c_str(),bin ? "reference binary form" : "text");
 			have = true;
 		}
 	}
@@ -327,8 +372,9 @@ int main(int argc, char ** argv)
 		// temp file + rename (daccord.cpp:1855-1860): parallel -J jobs on one .las never see a partly written profile
 		std::string const tmpfn = eproffn + ".tmp." + std::to_string(static_cast<long long>(::getpid()));
 		{
-			std::ofstream out(tmpfn.c_str());
-			char buf[128]; std::snprintf(buf,sizeof(buf),"%.17g %.17g %.17g\n",prof[0],prof[1],prof[2]); out << buf;
+			std::ofstream out(tmpfn.c_str(),std::ios::binary);
+			if ( o.binaryeprof ) out << encodeProfileBinary(counts,eavg,edif);       // what the reference's GAS.deserialise reads (daccord.cpp:1864)
+			else { char buf[128]; std::snprintf(buf,sizeof(buf),"%.17g %.17g %.17g\n",prof[0],prof[1],prof[2]); out << buf; }
 			out.flush();
 			if ( !out ) { std::remove(tmpfn.c_str()); die("cannot write the error profile " + tmpfn); }
 		}

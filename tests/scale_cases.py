@@ -19,6 +19,11 @@ CASES = {
     "cfg2t": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
                   pile_ranges=[[1250 * q + 562, 1250 * q + 687] for q in range(8)],
                   params=[dict(k=14)]),
+    # config 2, a third stratified sample (round 4, last session): 125 piles from the first QUARTER of each of the eight per-XCD queue
+    # ranges (offset 250) -- with cfg2, cfg2s, cfg2t that is 4062 of the headline batch's 10 000 piles against the oracle
+    "cfg2u": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
+                  pile_ranges=[[1250 * q + 250, 1250 * q + 375] for q in range(8)],
+                  params=[dict(k=14)]),
     # config 3 stand-in (D. melanogaster 20x is 140 Mbase; the files are not in the container): a 100-pile slice of a 20x set
     # with a larger genome and longer reads than config 2
     "cfg3": dict(genome_len=7000000, nreads=10000, read_len=14000, seed=7, synth={}, first=4000, npiles=100,

@@ -57,3 +57,38 @@ def test_eprofonly_estimates_and_writes_the_profile(files, tmp_path):
     # an existing profile file is used as it is
     r2 = cli.run(["--eprofonly", "-E" + ef, las, db])
     assert ("p_i=%.17g" % prof[0]) in r2.stderr.decode() and "usable=" not in r2.stderr.decode()
+
+
+def test_reference_binary_profile_is_written_and_read(files, tmp_path):
+    """--binaryeprof writes the reference's own .eprof (src/daccord.cpp:1855-1860: libmaus2 AlignmentStatistics::serialise = matches,
+    mismatches, insertions, deletions as 8-byte big-endian numbers, then eavg and edif as raw doubles -- libmaus2's published layout,
+    restated; no file written by the reference exists here) and either form is read back to the same rates (:1867-1878)."""
+    import struct
+    d, las, db = files
+    ef, et = str(tmp_path / "b.eprof"), str(tmp_path / "t.eprof")
+    r = cli.run(["--eprofonly", "--binaryeprof", "-E" + ef, las, db])
+    assert r.returncode == 0, r.stderr.decode()
+    raw = open(ef, "rb").read()
+    assert len(raw) == 48
+    m, mm, ins, dele = struct.unpack(">4Q", raw[:32])
+    eavg, edif = struct.unpack("=2d", raw[32:])
+    se = r.stderr.decode()
+    assert ("AlignmentStatistics(matches=%d,mismatches=%d,insertions=%d,deletions=%d)" % (m, mm, ins, dele)) in se
+    assert ("eavg=%g edif=%g" % (eavg, edif)) in se
+    # the text form of the same estimate
+    assert cli.run(["--eprofonly", "-E" + et, las, db]).returncode == 0
+    prof = [float(x) for x in open(et).read().split()]
+    ln = m + mm + dele
+    assert prof == [ins / ln, dele / ln, 1.0 - (mm + dele + ins) / ln]
+    # read back: the binary file gives the same three rates as the text one, and is reported as such
+    rb, rt = cli.run(["--eprofonly", "-V2", "-E" + ef, las, db]), cli.run(["--eprofonly", "-V2", "-E" + et, las, db])
+    assert rb.returncode == 0 and rt.returncode == 0
+    line = "[V] p_i=%.17g p_d=%.17g est_cor=%.17g" % tuple(prof)
+    assert line in rb.stderr.decode() and line in rt.stderr.decode()
+    assert "reference binary form" in rb.stderr.decode() and "(text)" in rt.stderr.decode() and "usable=" not in rb.stderr.decode()
+    # a file of 48 bytes that is not a profile, and a truncated one, are refused
+    bad = str(tmp_path / "bad.eprof")
+    open(bad, "wb").write(b"\xff" * 48)
+    assert cli.run(["--eprofonly", "-E" + bad, "--keepeprof", las, db]).returncode != 0
+    open(bad, "wb").write(raw[:40])
+    assert cli.run(["--eprofonly", "-E" + bad, "--keepeprof", las, db]).returncode != 0
