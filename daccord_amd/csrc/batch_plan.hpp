@@ -12,6 +12,8 @@
 #include <limits>
 #include <algorithm>
 #include <thread>
+#include <mutex>
+#include <exception>
 #include <atomic>
 #include <cstdlib>
 #include <cstdint>
@@ -184,16 +186,36 @@ struct BatchPlan
 		if ( n > byload ) n = static_cast<unsigned>(byload);
 		return n ? n : 1;
 	}
+	// Runs f(tid,lo,hi) over [0,np) in chunks on nthreads threads (the caller is thread 0).  Nothing escapes a worker thread: an exception
+	// there (bad_alloc of a per-thread buffer) is kept and rethrown in the caller after all threads have been joined, so that the C ABI's
+	// catch blocks see it as they saw the serial planner's; a thread that cannot be started (system limit) is done without.
 	template<typename F> static void planParallel(uint64_t const np, unsigned const nthreads, F const & f)
 	{
 		std::atomic<uint64_t> next(0);
+		std::atomic<bool> failed(false);
+		std::exception_ptr first; std::mutex firstlock;
 		uint64_t const chunk = 32;
-		auto const work = [&](unsigned const tid) { while ( true ) { uint64_t const lo = next.fetch_add(chunk); if ( lo >= np ) break; f(tid,lo,std::min<uint64_t>(np,lo+chunk)); } };
-		if ( nthreads <= 1 ) { work(0); return; }
+		auto const work = [&](unsigned const tid) {
+			try
+			{
+				while ( !failed.load(std::memory_order_relaxed) ) { uint64_t const lo = next.fetch_add(chunk); if ( lo >= np ) break; f(tid,lo,std::min<uint64_t>(np,lo+chunk)); }
+			}
+			catch ( ... )
+			{
+				std::lock_guard<std::mutex> g(firstlock);
+				if ( !first ) first = std::current_exception();
+				failed.store(true);
+			}
+		};
 		std::vector<std::thread> T;
-		for ( unsigned t = 1; t < nthreads; ++t ) T.emplace_back(work,t);
+		if ( nthreads > 1 )
+		{
+			try { T.reserve(nthreads-1); for ( unsigned t = 1; t < nthreads; ++t ) T.emplace_back(work,t); }
+			catch ( ... ) {}      // fewer threads than asked for: the chunks are handed out dynamically, the plan is the same
+		}
 		work(0);
 		for ( size_t t = 0; t < T.size(); ++t ) T[t].join();
+		if ( first ) std::rethrow_exception(first);
 	}
 
 	// Three passes: (1) every pile on its own (planPile, threads), (2) the running offsets of the device arrays, serial and in pile

@@ -475,6 +475,16 @@ static int upload(dacc_ctx * c, DevBuf<T> & b, T const * src, size_t n)
 	return DACC_OK;
 }
 
+// The host side of these entry points allocates (plans, tables, staging vectors; the planner also runs threads): nothing leaves through
+// the C ABI but a return code.  Their bodies are the *_body functions below.
+template<typename F> static int guarded(dacc_ctx * c, F const & f)
+{
+	try { return f(); }
+	catch ( std::bad_alloc const & ) { if ( c ) { try { c->err = "out of host memory"; } catch ( ... ) {} } return DACC_ENOMEM; }
+	catch ( std::exception const & ex ) { if ( c ) { try { c->err = std::string("host side failed: ") + ex.what(); } catch ( ... ) {} } return DACC_ENOMEM; }
+	catch ( ... ) { return DACC_ENOMEM; }
+}
+
 extern "C" {
 
 // number of HIP devices this process sees (0 if there is none or the runtime fails): lets a caller that spreads workers over
@@ -542,7 +552,7 @@ void dacc_destroy(dacc_ctx * c)
 
 char const * dacc_last_error(dacc_ctx * c) { return c ? c->err.c_str() : "null context"; }
 
-int dacc_set_error_profile(dacc_ctx * c, double p_i, double p_d, double est_cor)
+static int dacc_set_error_profile_body(dacc_ctx * c, double p_i, double p_d, double est_cor)
 {
 	if ( !c ) return DACC_EINVAL;
 	if ( !(p_i >= 0 && p_i < 1 && p_d >= 0 && p_d < 1 && est_cor >= 0 && est_cor <= 1) ) { c->err = "error profile out of range"; return DACC_EINVAL; }
@@ -584,7 +594,7 @@ int dacc_debug_tables(dacc_ctx * c, uint64_t * out, uint64_t cap, uint64_t * n, 
 	return DACC_OK;
 }
 
-int dacc_load_db(dacc_ctx * c, uint8_t const * bps, uint64_t bps_bytes, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads)
+static int dacc_load_db_body(dacc_ctx * c, uint8_t const * bps, uint64_t bps_bytes, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads)
 {
 	if ( !c || !bps || !boff || !rlen || !nreads ) return DACC_EINVAL;
 	hipSetDevice(c->device);
@@ -859,7 +869,7 @@ static int runDevice(dacc_ctx * c)
 	return DACC_OK;
 }
 
-int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl,
+static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl,
 	void const * trace, uint64_t ntrace, int trace_bytes)
 {
 	if ( !c ) return DACC_EINVAL;
@@ -1024,7 +1034,7 @@ int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, da
 	return DACC_OK;
 }
 
-int dacc_rerun_resident(dacc_ctx * c)
+static int dacc_rerun_resident_body(dacc_ctx * c)
 {
 	if ( !c ) return DACC_EINVAL;
 	if ( !c->havebatch ) { c->err = "no resident batch"; return DACC_ESTATE; }
@@ -1127,5 +1137,12 @@ int dacc_debug_windows(dacc_ctx * c, dacc_window_result * out, uint64_t cap, uin
 		}
 	return DACC_OK;
 }
+
+
+// guarded entry points (bodies: the *_body functions above)
+int dacc_set_error_profile(dacc_ctx * c, double p_i, double p_d, double est_cor) { return guarded(c,[&]() { return dacc_set_error_profile_body(c,p_i,p_d,est_cor); }); }
+int dacc_load_db(dacc_ctx * c, uint8_t const * bps, uint64_t bps_bytes, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads) { return guarded(c,[&]() { return dacc_load_db_body(c,bps,bps_bytes,boff,rlen,nreads); }); }
+int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes) { return guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); }); }
+int dacc_rerun_resident(dacc_ctx * c) { return guarded(c,[&]() { return dacc_rerun_resident_body(c); }); }
 
 }

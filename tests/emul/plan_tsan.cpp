@@ -41,5 +41,18 @@ int main()
 		std::printf("threads %d rc %d piles %zu ovl %zu windows %llu maxdepth %u digest %016llx\n",th,rc,BP.piles.size(),BP.ovl.size(),(unsigned long long)BP.nwindows,BP.maxdepth,(unsigned long long)h);
 		if ( !h0 ) h0 = h; else if ( h != h0 ) { std::printf("MISMATCH\n"); return 1; }
 	}
+	// an exception inside a worker thread (a bad_alloc of a per-thread buffer) must reach the caller, after all threads have been joined,
+	// and never terminate the process: thrown on whichever thread takes the chunk at 640, with 8 threads and with 1
+	for ( unsigned th : {8u,1u} )
+	{
+		std::atomic<uint64_t> done(0); bool caught = false;
+		try
+		{
+			BatchPlan::planParallel(4096,th,[&](unsigned, uint64_t const lo, uint64_t const hi) { if ( lo <= 640 && 640 < hi ) throw std::bad_alloc(); done += hi-lo; });
+		}
+		catch ( std::bad_alloc const & ) { caught = true; }
+		std::printf("exception threads %u caught %d chunks done before the stop %llu\n",th,int(caught),(unsigned long long)done.load());
+		if ( !caught || done.load() >= 4096 ) { std::printf("MISMATCH\n"); return 1; }
+	}
 	return 0;
 }

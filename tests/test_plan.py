@@ -89,7 +89,8 @@ def test_plan_reproduces_the_committed_digests(threads):
 
 
 def test_plan_has_no_data_race(tmp_path):
-    """the planner's threads under ThreadSanitizer (tests/emul/plan_tsan.cpp): no report, one digest for 1 / 8 / 3 / 16 threads"""
+    """the planner's threads under ThreadSanitizer (tests/emul/plan_tsan.cpp): no report, one digest for 1 / 8 / 3 / 16 threads;
+    an exception in a worker is rethrown in the caller after the join"""
     import subprocess
     exe = str(tmp_path / "plan_tsan")
     cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-o", exe, os.path.join(HERE, "emul", "plan_tsan.cpp")],
@@ -99,6 +100,8 @@ def test_plan_has_no_data_race(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ThreadSanitizer" not in (r.stdout + r.stderr) and "MISMATCH" not in r.stdout, (r.stdout + r.stderr)[-2000:]
     assert len(set(l.split()[-1] for l in r.stdout.splitlines() if l.startswith("threads"))) == 1
+    # an exception thrown inside a worker thread reaches the caller (the C ABI turns it into DACC_ENOMEM: capi.hip `guarded`)
+    assert r.stdout.count("caught 1") == 2, r.stdout
 
 
 if __name__ == "__main__":
