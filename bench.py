@@ -20,7 +20,7 @@ Prints ONE JSON line on rank 0 (see the driver contract), including
   cpu_baseline : the CPU oracle (a port of the reference's algorithm, oracle/) timed on this host's cores on a
                  bounded sample of the same piles, single thread and all cores (N=1, rank 0 only)
   parity       : SHA-256 of the GPU FASTA of every committed stratum of the batch (tests/golden/scale_cfg2*.json: the first
-                 1000 piles, the boundaries and the middles of the eight per-XCD queue ranges) against the digests the oracle
+                 1000 piles, the boundaries, middles and quarter points of the eight per-XCD queue ranges) against the digests the oracle
                  produced in the build container (default workload only), the full-batch digest, and the live CPU samples
   value_incl_plan_h2d : the same rate over the FIRST pass, which includes the host plan and the upload of piles / overlaps /
                  trace points ("piles in host RAM" to fragments); `value` is the resident-batch rate the contract asks for
@@ -294,10 +294,19 @@ def main():
                 out["piles_that_differ"] = bad[:50]
             return out
         if default_set:
-            cmp_ = [c for c in (compare_golden("cfg2s"), compare_golden("cfg2t"), compare_golden("cfg2")) if c]
+            # every committed stratum of this batch: cfg2s (boundaries of the queue ranges), cfg2t (their middles), cfg2u (their first
+            # quarters), cfg2v (three-quarter points), cfg2 (the first 1000 piles)
+            import glob
+            names = sorted(os.path.basename(f)[len("scale_"):-len(".json")] for f in glob.glob(os.path.join(ROOT, "tests", "golden", "scale_cfg2*.json")))
+            cmp_ = [c for c in (compare_golden(n) for n in sorted(names, key=lambda n: (n == "cfg2", n))) if c]
             if cmp_:
-                par.update({"piles_compared": int(sum(c["piles_compared"] for c in cmp_)), "identical": all(c["identical"] for c in cmp_), "fixtures": cmp_,
-                            "oracle_source": "oracle run in the build container (tests/golden/make_golden_scale.py): the first 1000 piles, the boundaries and the middles of all eight queue ranges of the batch; "
+                distinct = set()
+                for c in cmp_:
+                    for a, b in c["pile_ranges"]:
+                        distinct.update(range(a, b))
+                par.update({"piles_compared": int(sum(c["piles_compared"] for c in cmp_)), "piles_compared_distinct": len(distinct),       # the strata of the first range overlap the first 1000 piles
+                            "identical": all(c["identical"] for c in cmp_), "fixtures": cmp_,
+                            "oracle_source": "oracle run in the build container (tests/golden/make_golden_scale.py): the first 1000 piles and stratified samples of all eight queue ranges of the batch (boundaries, middles, quarter points); "
                                              "the oracle itself is pinned to the reference's own sources (oracle/_ref, tests/test_oracle_vs_ref.py)"})
         res["parity"] = par
         # ---- accuracy against the known truth of the synthetic reads (checkconsensus measurement, README.md:406-472):

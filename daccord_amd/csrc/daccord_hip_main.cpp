@@ -137,6 +137,14 @@ Options parse(int argc, char ** argv)
 			"  --batch<2000> A reads per GPU batch  (or one process per GPU like the reference: -J<g,G> --device<g>)\n");
 		std::exit(EXIT_FAILURE);
 	}
+	// what dacc_create would refuse, said before any file is read and in the option's own words.  The reference compiles k = 3 ... 12 and
+	// throws "k-mer size k is not compiled in" beyond (DebruijnGraphContainer.hpp:41-110); its k-mer words hold 32 bits (DebruijnGraph.hpp:956-961),
+	// which defines the algorithm up to k = 16 -- what this build runs; k = 17 has no reference semantics.
+	if ( o.klow < 3 || o.khigh > 16 || o.klow > o.khigh )
+		die("k-mer size " + std::to_string(o.klow) + (o.khigh != o.klow ? "," + std::to_string(o.khigh) : std::string()) + " is not compiled in (3 <= k <= 16, low <= high)");
+	if ( !o.w || o.w > 128 ) die("-w must be in [1,128]");      // DACC_WMAX (dev_types.hpp): two 64 bit words of the consensus -> A alignment
+	if ( !o.a ) die("-a must be at least 1");
+	if ( o.minff < 0 || o.maxff < o.minff ) die("--minfilterfreq / --maxfilterfreq: need 0 <= min <= max");
 	return o;
 }
 

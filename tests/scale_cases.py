@@ -24,6 +24,10 @@ CASES = {
     "cfg2u": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
                   pile_ranges=[[1250 * q + 250, 1250 * q + 375] for q in range(8)],
                   params=[dict(k=14)]),
+    # config 2, a fourth, smaller sample: 25 piles at the three-quarter point of each of the eight per-XCD queue ranges (offset 937)
+    "cfg2v": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=0, npiles=10000,
+                  pile_ranges=[[1250 * q + 937, 1250 * q + 962] for q in range(8)],
+                  params=[dict(k=14)]),
     # config 3 stand-in (D. melanogaster 20x is 140 Mbase; the files are not in the container): a 100-pile slice of a 20x set
     # with a larger genome and longer reads than config 2
     "cfg3": dict(genome_len=7000000, nreads=10000, read_len=14000, seed=7, synth={}, first=4000, npiles=100,

@@ -29,6 +29,12 @@ def test_usage_and_unknown_options_fail_loudly(files):
                 ["--gpus0", "--eprofonly", las, db], ["--gpus65", "--eprofonly", las, db], ["--gpusx", "--eprofonly", las, db]):
         r = cli.run(bad)
         assert r.returncode != 0 and (b"[E]" in r.stderr or b"usage" in r.stderr), bad
+    # parameter ranges are refused before any file is opened, in the option's words (the reference: "k-mer size k is not compiled in",
+    # DebruijnGraphContainer.hpp:41-110; here k = 3 ... 16, w <= 128)
+    for bad, word in ((["-k17"], b"not compiled in"), (["-k2"], b"not compiled in"), (["-k12,9"], b"not compiled in"), (["-w129"], b"-w must"),
+                      (["-w0"], b"-w must"), (["-a0"], b"-a must"), (["--minfilterfreq3", "--maxfilterfreq2"], b"filterfreq")):
+        r = cli.run(bad + ["/nonexistent.las", "/nonexistent.db"])
+        assert r.returncode != 0 and word in r.stderr and b"cannot open" not in r.stderr, (bad, r.stderr)
 
 
 def test_read_intervals_follow_the_reference(files):
