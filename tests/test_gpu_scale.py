@@ -40,7 +40,10 @@ def test_scale_case_matches_oracle_digests(name):
         print("%s %s: %d windows, %d bases, window kernel %.1f ms, tiers handed on %s"
               % (name, run["params"], len(w), len(bx), t.window_ms, list(t.tier_out)))
         assert len(w) == run["nwindows"]
-        if name in ("cfg2", "cfg2s", "cfg2t", "cfg2u", "cfg2v", "cfg3", "cfg3b"):
+        if name in ("cfg2u", "cfg2v"):
+            # strata added after the round's last GPU call: the shares below were never measured on them, only that the size classes ran
+            assert t.tier0_in > 0 and t.tier0_ms > 0, (t.tier0_in, t.tier0_out, t.tier0_ms)
+        if name in ("cfg2", "cfg2s", "cfg2t", "cfg3", "cfg3b"):
             # shallow batches: the size classes ran -- the pre-pass sent a good part of the windows to tier 0 (8 wavefronts per CU),
             # which finished most of them (a fifth is handed on at the default threshold: node overflows; round 4)
             assert t.tier0_in > 0.25 * len(w) and t.tier0_out < 0.35 * t.tier0_in and t.tier0_ms > 0, (t.tier0_in, t.tier0_out, t.tier0_ms)
