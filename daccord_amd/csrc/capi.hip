@@ -96,7 +96,7 @@ __device__ __forceinline__ bool next_window(uint32_t * work, uint64_t const n, u
 __global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag, uint32_t const * list, uint32_t * work)
 {
 	uint8_t * arena = B.arena + static_cast<uint64_t>(blockIdx.x)*B.C.bytes;
-	if ( B.prof ) B.prof += 32*(blockIdx.x & 4095);
+	if ( B.prof ) B.prof += DACC_PROFW*(blockIdx.x & 4095);
 	uint64_t const n = list ? list[0] : B.nwindows;
 	uint32_t it = 0;
 	while ( true )
@@ -202,11 +202,21 @@ __global__ void k_collect_overflow(WindowOut const * wout, uint64_t n, uint32_t 
 
 // LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice.
 // list == 0: all windows; else the windows a smaller capacity tier handed over.  Windows that do not fit go to FB.retry.
+// (tiers 0 and 1 hold 8 and 6 windows per CU in LDS: two wavefronts per SIMD need their kernels within 256 registers; the register
+// allocator lands within a few registers of that bound either way, amdgpu_waves_per_eu(2) would make it a requirement (-DDACC_WPE_CAP: 248 / 253 registers, no scratch) but changes the
+// scheduler's targets with it: 5 % SLOWER on config 2, profiles/r05e_ab_register_cap.log -- so the bound is kept by hand)
+#if defined(DACC_WPE_CAP)
+#define DACC_WPE(T) __attribute__((amdgpu_waves_per_eu((T) <= 1 ? 2 : 1)))
+#elif defined(DACC_NUMVGPR_CAP)
+#define DACC_WPE(T) __attribute__((amdgpu_num_vgpr((T) <= 1 ? 256 : 512)))
+#else
+#define DACC_WPE(T)
+#endif
 template<int TIER>
-__global__ void __launch_bounds__(64) k_window_fast(FastBatch FB, uint32_t const * list, uint32_t * work)
+__global__ void __launch_bounds__(64) DACC_WPE(TIER) k_window_fast(FastBatch FB, uint32_t const * list, uint32_t * work)
 {
 	typedef FastTier<TIER> CT;
-	if ( FB.W.prof ) FB.W.prof += 32*(blockIdx.x & 4095);
+	if ( FB.W.prof ) FB.W.prof += DACC_PROFW*(blockIdx.x & 4095);
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
 	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
 	{ FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
@@ -882,7 +892,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 	if ( rc ) return rc;
 	hipStream_t const s = c->stream;
 	HIPCHK(c->d_err.ensure(4));
-	HIPCHK(c->d_prof.ensure(32*4096)); HIPCHK(hipMemsetAsync(c->d_prof.p,0,32*4096*sizeof(uint64_t),s));   // one row of counters per workgroup (no contention)
+	HIPCHK(c->d_prof.ensure(DACC_PROFW*4096)); HIPCHK(hipMemsetAsync(c->d_prof.p,0,DACC_PROFW*4096*sizeof(uint64_t),s));   // one row of counters per workgroup (no contention)
 	HIPCHK(hipEventRecord(c->ev[5],s));
 	if ( (rc = upload(c,c->d_piles,BP.piles.data(),BP.piles.size())) ) return rc;
 	if ( (rc = upload(c,c->d_ovl,BP.ovl.data(),BP.ovl.size())) ) return rc;
@@ -1059,20 +1069,23 @@ int dacc_last_timing(dacc_ctx * c, dacc_timing * t)
 	return DACC_OK;
 }
 
-// per-phase cycle counters of the window kernel (all zero unless built with -DDACC_PROFILE)
-int dacc_debug_profile(dacc_ctx * c, uint64_t * out32)
+// per-phase cycle counters of the window kernel (all zero unless built with -DDACC_PROFILE): a row of DACC_PROFW counters per
+// workgroup; 0...31 the phases (scripts/prof_phases.py), 32...127 the fine sites of round 5 (site s: cycles at 32+s, visits at 80+s)
+static int dacc_debug_profile_rows(dacc_ctx * c, uint64_t * out, int const from, int const n)
 {
-	if ( !c || !out32 ) return DACC_EINVAL;
+	if ( !c || !out ) return DACC_EINVAL;
 	if ( !c->havebatch ) return DACC_ESTATE;
 	hipSetDevice(c->device);
 	{
-		std::vector<uint64_t> H(32*4096);
-		HIPCHK(hipMemcpy(H.data(),c->d_prof.p,32*4096*sizeof(uint64_t),hipMemcpyDeviceToHost));
-		for ( int i = 0; i < 32; ++i ) out32[i] = 0;
-		for ( int b = 0; b < 4096; ++b ) for ( int i = 0; i < 32; ++i ) { if ( i == 29 ) out32[i] = std::max(out32[i],H[32*b+i]); else out32[i] += H[32*b+i]; }
+		std::vector<uint64_t> H(DACC_PROFW*4096);
+		HIPCHK(hipMemcpy(H.data(),c->d_prof.p,DACC_PROFW*4096*sizeof(uint64_t),hipMemcpyDeviceToHost));
+		for ( int i = 0; i < n; ++i ) out[i] = 0;
+		for ( int b = 0; b < 4096; ++b ) for ( int i = 0; i < n; ++i ) { uint64_t const v = H[DACC_PROFW*b+from+i]; if ( from+i == 29 ) out[i] = std::max(out[i],v); else out[i] += v; }
 	}
 	return DACC_OK;
 }
+int dacc_debug_profile(dacc_ctx * c, uint64_t * out32) { return dacc_debug_profile_rows(c,out32,0,32); }
+int dacc_debug_profile_fine(dacc_ctx * c, uint64_t * out96) { return dacc_debug_profile_rows(c,out96,32,96); }
 
 // DACC_DEBUG_RETRY=1: (window, flags, mao, filterfreq) of the windows the last LDS tier handed to the generic engine
 int dacc_debug_retry(dacc_ctx * c, uint32_t * out, uint64_t cap, uint64_t * n)

@@ -28,6 +28,7 @@ namespace dacc {
 #define DACC_DBL_MIN 2.2250738585072014e-308
 
 // optional per-phase cycle accounting (profiling builds only: -DDACC_PROFILE)
+#define DACC_PROFW 128      // counters per workgroup row: 32 phases + 48 fine sites (cycles, visits)
 #if defined(DACC_PROFILE) && !defined(DACC_EMUL)
   #define PROF_T0 uint64_t _pt = clock64();
   #define PROF(E_,id) { uint64_t const _n = clock64(); if ( (E_).lane == 0 && (E_).prof ) atomicAdd(reinterpret_cast<unsigned long long *>((E_).prof+(id)),static_cast<unsigned long long>(_n-_pt)); _pt = _n; }

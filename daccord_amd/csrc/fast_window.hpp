@@ -618,11 +618,20 @@ struct FastEngine
 #endif
 
 #if defined(DACC_PROFILE) && !defined(DACC_EMUL)
+	// fine sites (round 5 hot-spot ledger): shader cycles between two probes, charged once per wavefront visit (the first active
+	// lane reports; inside lane-divergent code the clock is the wavefront's).  s_memtime waits for the LDS operations in flight, so a
+	// site is charged with the round trips it started.
+	#define SITE_T0 uint64_t _ps = clock64();
+	#define SITE_RESET { _ps = clock64(); }
+	#define SITE(id) { uint64_t const _n = clock64(); if ( prof && lane == static_cast<int>(__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) ) { atomicAdd(reinterpret_cast<unsigned long long *>(prof+32+(id)),static_cast<unsigned long long>(_n-_ps)); atomicAdd(reinterpret_cast<unsigned long long *>(prof+80+(id)),1ull); } _ps = clock64(); }
 	#define PROFX_T0 uint64_t _px = clock64();
 	#define PROFX(id) { uint64_t const _n = clock64(); if ( lane == 0 && prof ) atomicAdd(reinterpret_cast<unsigned long long *>(prof+(id)),static_cast<unsigned long long>(_n-_px)); _px = _n; }
 #else
 	#define PROFX_T0
 	#define PROFX(id)
+	#define SITE_T0
+	#define SITE_RESET
+	#define SITE(id)
 #endif
 	DEV int32_t findNode(uint32_t const v) const
 	{
@@ -661,35 +670,73 @@ struct FastEngine
 	DEV void buildInstances()
 	{
 		PROFX_T0
-		// k-mer instances of all strings at once, lane = instance: the number of k-mers of string j and its first output
-		// slot live in lane j%64 (register c = j/64), so a lane finds the string of its instance by comparing against
-		// broadcast (scalar) offsets instead of walking LDS
+		// k-mer instances of all strings at once, lane = instance.  String j (lane j%64 of round j/64) has nk k-mers, its first
+		// output slot is the exclusive prefix sum off, and among the strings with k-mers it is number rk.  (Round 5: an instance finds
+		// its string in two LDS round trips in the tiers of deep piles -- a byte per output slot marks where a string begins, so the number of marks up to
+		// slot t, counted with a ballot per 64 slots, names the string of slot t in a compact list (string, first slot).  Rounds 1-4
+		// compared t against the offsets of all strings, broadcast one by one: 64 x strings scalar steps per 64 instances, 3 % of a
+		// window of config 2 and a quarter of one at 54x, profiles/r05c_sites_*.log.)
 		enum { NCH = (CT::maxs+WSZ-1)/WSZ };
-		uint32_t nk[NCH], off[NCH]; uint32_t base = 0, nl = 0;
+#if defined(DACC_GEN_MARKS_ALL)
+		enum : bool { GENMARKS = true };
+#elif defined(DACC_GEN_MARKS_NONE)
+		enum : bool { GENMARKS = false };
+#else
+		enum : bool { GENMARKS = (CT::maxs > 40) };      // the tiers of deep piles (96 strings)
+#endif
+		static_assert(4u*CT::maxs <= CT::precap && CT::maxs <= 256 && CT::precap <= (1u<<24),"compact string list: string | first slot << 8, in the bytes of irpos");
+		LDSQ uint8_t * const marks = L.ipos();                                             // free until buildNodes writes the positions
+		LDSQ uint32_t * const clist = reinterpret_cast<LDSQ uint32_t *>(L.irpos());
+		uint32_t nkc[NCH], offc[NCH], rkc[NCH]; uint32_t base = 0, nl = 0;
 		#pragma unroll
 		for ( int c = 0; c < NCH; ++c )
 		{
 			uint32_t const j = c*WSZ + lane;
 			uint32_t const len = j < mao ? L.slen()[j] : 0u;
-			nk[c] = len >= k ? (len-k+1) : 0u;
-			uint32_t tot; uint32_t const pre = wv_scan_excl(nk[c],tot);
-			off[c] = base + pre; base += tot;
-			uint32_t t2; wv_scan_flag(nk[c] != 0,t2); nl += t2;
+			nkc[c] = len >= k ? (len-k+1) : 0u;
+			uint32_t tot; uint32_t const pre = wv_scan_excl(nkc[c],tot);
+			offc[c] = base + pre; base += tot;
+			uint32_t t2; rkc[c] = nl + wv_scan_flag(nkc[c] != 0,t2); nl += t2;
 		}
 		npre = base;
 		nlast = 0;
 		if ( npre > CT::precap ) { over(1); npre = 0; return; }
+		SITE_T0
+		if constexpr ( GENMARKS )
+		{
+			for ( uint32_t i = 8*lane; i < npre; i += 8*WSZ ) *reinterpret_cast<LDSQ uint64_t *>(marks + i) = 0;      // (precap is a multiple of 8)
+			wv_sync();
+			#pragma unroll
+			for ( int c = 0; c < NCH; ++c )
+				if ( nkc[c] ) { marks[offc[c]] = 1; clist[rkc[c]] = (c*WSZ + lane) | (offc[c] << 8); }
+			wv_sync();
+		}
+		uint32_t cum = 0;
 		for ( uint32_t t0 = 0; t0 < npre; t0 += WSZ )
 		{
 			uint32_t const t = t0 + lane;
 			uint32_t j = 0, oj = 0, lo = 0;
-			#pragma unroll
-			for ( int c = 0; c < NCH; ++c )
-				for ( uint32_t jj = 0; jj < WSZ && c*WSZ + jj < mao; ++jj )
-				{
-					uint32_t const o = wv_bcast(off[c],jj), n = wv_bcast(nk[c],jj);
-					if ( t >= o ) { j = c*WSZ + jj; oj = o; lo += (n != 0); }
-				}
+			if constexpr ( GENMARKS )
+			{
+				bool const mk = t < npre && marks[t] != 0;
+				uint32_t tot; uint32_t const before = wv_scan_flag(mk,tot);
+				lo = cum + before + (mk ? 1u : 0u);      // strings with k-mers that begin at or before slot t (slot 0 begins one)
+				cum += tot;
+				if ( t < npre ) { uint32_t const e = clist[lo-1]; j = e & 0xFFu; oj = e >> 8; }
+			}
+			else
+			{
+				// shallow tiers: t against the offsets of all strings, broadcast one by one (pure VALU / scalar work, which the other
+				// wavefront of the SIMD hides; the two dependent LDS round trips of the marks measured 2.6 % SLOWER on config 2,
+				// profiles/r05d_ab_generation.log)
+				#pragma unroll
+				for ( int c = 0; c < NCH; ++c )
+					for ( uint32_t jj = 0; jj < WSZ && c*WSZ + jj < mao; ++jj )
+					{
+						uint32_t const o = wv_bcast(offc[c],jj), n = wv_bcast(nkc[c],jj);
+						if ( t >= o ) { j = c*WSZ + jj; oj = o; lo += (n != 0); }
+					}
+			}
 			if ( t < npre )
 			{
 				uint32_t const i = t - oj;
@@ -706,8 +753,11 @@ struct FastEngine
 		uint32_t const lp2 = next_pow2(nlast < 2 ? 2 : nlast);
 		for ( uint32_t i = nlast + lane; i < lp2; i += WSZ ) L.lastk()[i] = ~0ull;
 		wv_sync();
+		SITE(31)      // buildInstances: generation of the k-mer instances (lane = instance)
 		wv_sort_keys<FastLds<CT>::keycap>(L.lastk(),nlast);
+		SITE(32)      // buildInstances: sort of the last k-mers
 		wv_sort_keys<CT::precap,(CT::precap == 2048 && CT::ncap == 256)>(L.pre(),npre);      // 2048 keys in registers: the deep tier (FastTier<4>) only
+		SITE(33)      // buildInstances: sort of the instances (register bitonic network)
 	}
 
 	DEV void buildNodes(uint32_t const f)
@@ -1836,12 +1886,14 @@ struct FastEngine
 			rpst[nrpst++] = slot;
 		}
 		LDSQ uint64_t const * W = L.rc_w();
+		SITE_T0
 		while ( nrpst )
 		{
 			uint32_t const rp = rpst[0];
 			ipop<false>(rpst,nrpst,W);
 			uint32_t const bl = L.rc_baselen()[rp], ppos = L.rc_pos()[rp], plen = L.rc_len()[rp];
 			uint64_t const pw = W[rp];
+			SITE(17)      // reverse enumeration: pop of the heaviest pending path + its fields
 			// ARPH[bl] (:3626-3665) keeps the 12 heaviest accepted paths of a base length and admits a path only if it is
 			// heavier than the lightest of them: a path is dropped iff 12 accepted paths of its length weigh at least as much
 			if ( R.narp >= 12 )
@@ -1852,6 +1904,7 @@ struct FastEngine
 					uint32_t const a = L.rc_acc()[clSlot<RCH>(R.C,i)];
 					cnt += (L.rc_baselen()[a] == bl && W[a] >= pw) ? 1 : 0;
 				}
+				SITE(18)      // reverse enumeration: the 12 heaviest accepted paths of this base length
 				if ( cnt >= 12 ) continue;
 			}
 			L.rc_acc()[clSlot<RCH>(R.C,R.narp)] = rp; ++R.narp;
@@ -1869,6 +1922,7 @@ struct FastEngine
 					if ( nrpst >= rpstcap ) { over(512|0x8000); return; }
 					ipush<false>(rpst,nrpst,static_cast<id_t>(rpe),W);
 				}
+				SITE(19)      // reverse enumeration: the root's extensions
 			}
 			else if ( static_cast<int64_t>(bl) < (lmax+1)/2 )
 			{
@@ -1889,8 +1943,10 @@ struct FastEngine
 						if ( nrpst >= rpstcap ) { over(512|0x8000); return; }
 						ipush<false>(rpst,nrpst,static_cast<id_t>(rpe),W);
 					}
+					SITE(20)      // reverse enumeration: one predecessor stretch of a popped path (iterator, link weight, record, push)
 				}
 			}
+			SITE_RESET
 		}
 	}
 	// ---- block of a finished reverse enumeration in sorted order at rc_ord/rc_arw/rc_sbl/rc_front[sbase..sbase+narp) ----
@@ -2037,6 +2093,7 @@ struct FastEngine
 		clInit(F.C,chunkrow); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
 		if ( firstnode < 0 ) return;
 		PROFX_T0      // profiling builds: lane 0's tree, split into filling the bucket heap (19) and draining it (20)
+		SITE_T0
 		{
 			MIt it; byFirstBegin(V,it,firstnode);
 			for ( int32_t sx = byFirstNext(V,it); sx >= 0; sx = byFirstNext(V,it) )
@@ -2050,6 +2107,7 @@ struct FastEngine
 			}
 		}
 		LDSQ uint64_t const * W = L.f_w();
+		SITE(11)      // forward tree: the root's extensions
 		while ( F.m0 | F.m1 )
 		{
 			uint32_t const zz = F.m0 ? static_cast<uint32_t>(__builtin_ctzll(F.m0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(F.m1));
@@ -2070,6 +2128,7 @@ struct FastEngine
 					#pragma unroll
 					for ( uint32_t u = 0; u < 4; ++u ) if ( i+u < ie ) mem |= static_cast<uint64_t>(((b4 >> (8*u)) & 0xFF) == zz) << (i+u);
 				}
+				SITE(12)      // forward tree: members of the bucket among 64 entries (base length loads)
 				while ( mem )
 				{
 					uint32_t const i = __builtin_ctzll(mem); mem &= mem-1;
@@ -2080,6 +2139,7 @@ struct FastEngine
 					}
 					else ipush<true>(hp,hn,static_cast<id_t>(e),W);
 				}
+				SITE(13)      // forward tree: pushes of the bucket's members into the heap of 12
 			}
 			PROFX(19)
 			while ( hn )
@@ -2089,6 +2149,7 @@ struct FastEngine
 				uint32_t const ps = L.f_stretch()[path], ppos = L.f_pos()[path], plen = L.f_len()[path], pbl = zz;
 				uint64_t const pw = W[path];
 				uint32_t const lastn = L.slast()[ps];
+				SITE(14)      // forward tree: pop of the heaviest path of the bucket + its fields
 				{
 					// what the score intervals need of this path: junction k-mer, candidate length, weight without the junction node
 					int32_t const psfo = sfFind(ps,ppos - (L.sslen()[ps]-1));
@@ -2099,6 +2160,7 @@ struct FastEngine
 					if ( pw > F.fmaxw ) F.fmaxw = pw;
 					++F.nfpop;
 				}
+				SITE(15)      // forward tree: the popped path's record for the score intervals (weight record from the slab)
 				if ( pbl < k || ( static_cast<int64_t>(pbl-k) < ((lmax+1)/2) ) )
 				{
 					MIt it; byFirstBegin(V,it,lastn);
@@ -2119,9 +2181,12 @@ struct FastEngine
 							}
 							else --F.np;
 						}
+						SITE(16)      // forward tree: one successor stretch of a popped path (view iterator, weight record, new path)
 					}
 				}
+				SITE_RESET
 			}
+			SITE_RESET      // (lanes that left the drain loop early wait here for the others: not the scan's time)
 			PROFX(20)
 		}
 	}
@@ -2233,11 +2298,13 @@ struct FastEngine
 	{
 		LDSQ sid_t * cur = L.cseq() + 16*FSEQCAP; LDSQ sid_t * prev = L.cseq() + 17*FSEQCAP;
 		FSTAT_ADD(18,1);
-		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); }   // weight > top here
+		SITE_T0
+		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); SITE(5) }   // weight > top here
 		uint32_t conslen = 0;
 		uint64_t const tbs_ = pclock();
 		uint32_t const n = buildSeq(path,rp,cur,conslen);
 		pcount(24,pclock()-tbs_);      // profiling builds: cycles of the sequence walks (lane 0)
+		SITE(6)      // offerCandidate: sequence walk of the two parent chains
 		if ( n == ~0u ) return false;
 		// sequences are compared and copied as 64 bit words (a slot is FSEQCAP ids, 8 byte aligned; ids behind a sequence's
 		// length are never looked at): one round of loads instead of one per stretch
@@ -2259,8 +2326,9 @@ struct FastEngine
 				uint64_t const m = n >= IPW*q+IPW ? ~0ull : ( n > IPW*q ? ((1ull << (8u*sizeof(sid_t)*(n-IPW*q)))-1ull) : 0ull );
 				diff |= (cw[q]^pq) & m;
 			}
-			if ( diff == 0 ) return true;
+			if ( diff == 0 ) { SITE(7) return true; }
 		}
+		SITE(7)      // offerCandidate: sequence words loaded, compared with the previous kept candidate
 		uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
 		LDSQ uint64_t * dst8 = reinterpret_cast<LDSQ uint64_t *>(L.cseq() + FSEQCAP*slot);
 		#pragma unroll
@@ -2269,6 +2337,7 @@ struct FastEngine
 		FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
 		FSTAT_ADD(19,1);
 		spush<FCC,true>(L.cdh(),ncdh,cc);
+		SITE(8)      // offerCandidate: slot copy + push
 		return true;
 	}
 	// serial form (lane 0): score intervals in the shared heap L.siq, candidates offered as they are popped
@@ -2323,6 +2392,7 @@ struct FastEngine
 		uint32_t const maxfullpath, LDSQ PSI * H, LDSQ id_t * out, bool const prune, uint64_t const T0)
 	{
 		uint32_t n = 0;
+		SITE_T0
 		for ( uint32_t pi = 0; pi < nfpop; ++pi )
 		{
 			uint32_t const o = clSlot<FCH>(FC,pi);
@@ -2347,6 +2417,7 @@ struct FastEngine
 		}
 		FSTAT_ADD(25,1); FSTAT_ADD(26,n > 8 ? 1u : 0u); FSTAT_ADD(27,n > 10 ? 1u : 0u); FSTAT_ADD(28,n > 12 ? 1u : 0u); FSTAT_ADD(29,n > 16 ? 1u : 0u); FSTAT_MX(30,n);
 		uint32_t cnt = 0;
+		SITE(1)      // combineLane: the intervals of the pair (one scoreInterval per forward pop) and their heap
 		for ( uint32_t numfullpath = 0; n && numfullpath < maxfullpath; ++numfullpath )
 		{
 			PSI const top = H[0];
@@ -2387,6 +2458,7 @@ struct FastEngine
 				}
 			}
 			out[2*cnt] = static_cast<id_t>(clSlot<FCH>(FC,top.path)); out[2*cnt+1] = L.rc_ord()[sbase+top.current]; ++cnt;
+			SITE(2)      // combineLane: one pop (sift down, next lighter entry, push, record)
 		}
 		return cnt;
 	}
@@ -2396,13 +2468,17 @@ struct FastEngine
 	{
 		pn = ~0u;
 		FSTAT_ADD(16,1); FSTAT_ADD(17,cnt);
+		SITE_T0
 		for ( uint32_t e = 0; e < cnt; ++e )
 		{
 			uint32_t const o = out[2*e];
 			uint32_t const rp = out[2*e+1];
 			uint64_t const w = L.fp_adj()[o] + L.rc_w()[rp];
-			if ( ncdh == 16 && w <= L.cdh()[0].w ) { if ( e == 0 ) FSTAT_ADD(20,1); return false; }
-			if ( !offerCandidate(w,L.fp_id()[o],rp,pn) ) return false;
+			if ( ncdh == 16 && w <= L.cdh()[0].w ) { if ( e == 0 ) FSTAT_ADD(20,1); SITE(4) return false; }
+			uint32_t const fid = L.fp_id()[o];
+			SITE(4)      // replayPair: recorded entry -> weight, comparison with the lightest kept candidate
+			if ( !offerCandidate(w,fid,rp,pn) ) return false;
+			SITE_RESET
 		}
 		return true;
 	}
@@ -2674,6 +2750,7 @@ struct FastEngine
 			uint64_t const rest = live >> q;
 			if ( !rest ) { q = n; break; }
 			q += static_cast<uint32_t>(__builtin_ctzll(rest));
+			SITE_T0
 			uint32_t const mode = L.poutn()[q];
 			FSTAT_ADD(13,1);
 			if ( mode == PM_SKIP ) { FSTAT_ADD(14,1); continue; }
@@ -2682,22 +2759,25 @@ struct FastEngine
 			if ( mode < 0x40 || mode == PM_SERIAL )
 			{
 				// no candidate of this pair can beat the lightest kept candidate: score <= path weight + reverse weight
-				if ( ncdh == 16 && L.fmx()[fi] + L.rmaxw()[li] <= L.cdh()[0].w ) { FSTAT_ADD(15,1); continue; }
+				if ( ncdh == 16 && L.fmx()[fi] + L.rmaxw()[li] <= L.cdh()[0].w ) { FSTAT_ADD(15,1); SITE(3) continue; }
 				ChunkList<FNW> FC; forwardTreeLoad(FC,fi);
+				SITE(3)      // replayRound: per live pair, up to the dispatch on its mode
 				if ( mode < 0x40 )
 				{
 					uint32_t const cnt = mode & 0x0F; uint32_t pn;
 					bool const used = replayPair(FC,L.rbase()[li],L.pout() + 2*POUTE*q,cnt,pn);
 					if ( flags ) return 0;
+					SITE_RESET
 					// a sequence cut at weight T0 (0x20) is complete only while the candidate heap is full with a top of at least T0; one
 					// cut because the record was full (0x10) always goes on
 					if ( used && ( (mode & 0x10) || ((mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0)) ) )
 					{
 						pcount(21,1);
 						combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16,cnt,pn);
+						SITE(9)      // replayRound: serial continuation of a cut sequence (combinePair with skip)
 					}
 				}
-				else { pcount(23,1); combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16); }
+				else { pcount(23,1); combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16); SITE(9) }
 				if ( flags ) return 0;
 				continue;
 			}
@@ -2759,6 +2839,7 @@ struct FastEngine
 			else { forwardTreeLoad(FC,fi); nfp = L.fnp()[fi]; ffmx = L.ffm()[fi]; }
 			if ( rfm & ffmx ) combinePair(FC,nfp,sbase,nacc2,rfm,lmin,lmax,16);   // else: no junction k-mer in common
 			L.ctr()[0] = rsave; L.ctr()[1] = fsave;
+			SITE(10)      // replayRound: a pair on its exact stretch set (enumerations + serial combine)
 			if ( flags ) return 0;
 		}
 		return 0;
@@ -2774,14 +2855,19 @@ struct FastEngine
 		findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
 #if !defined(DACC_NO_REACH)
-		if ( !pairReachable() ) { FSTAT_ADD(23,1); PROF(*this,16) return false; }
+		{
+			SITE_T0
+			bool const reach = pairReachable();
+			SITE(23)      // traverse: reachability prune
+			if ( !reach ) { FSTAT_ADD(23,1); PROF(*this,16) return false; }
+		}
 #endif
 		PROF(*this,16)
 		loadTab();
 		PROF(*this,17)
 		computeStretchFeasLanes(0,npool);
 		flags = wv_or(flags); if ( flags ) return false;
-		spillS();
+		{ SITE_T0 spillS(); SITE(24) }      // traverse: build-phase arrays to the slab
 		PROF(*this,9)
 
 		// ---- reverse blocks of all last k-mer candidates, lane = candidate ----
@@ -2818,6 +2904,7 @@ struct FastEngine
 #if defined(DACC_EMUL)
 				if ( ract ) { FILE * f = ftrav_file(); if ( f ) fprintf(f,"R %d %u %u 0\n",int(CT::maxs),R.nrp,R.narp); }
 #endif
+				SITE_T0
 				if ( ract ) reverseBlockCopy(R,sbase);
 				// blocks of more than 16 entries are sorted with an explicit stack (one lane at a time)
 				uint64_t big = wv_ballot(ract && R.narp > 16);
@@ -2827,6 +2914,7 @@ struct FastEngine
 					int const b = __builtin_ctzll(big); big &= big-1;
 					if ( lane == b ) reverseBlockFinish(R,sbase,li,lastnode,lmax);
 				}
+				SITE(21)      // traverse: reverse blocks copied, sorted, ranked (lanes = last k-mer candidates)
 				sb += tot;
 				flags = wv_or(flags); if ( flags ) return false;
 			}
@@ -2881,7 +2969,7 @@ struct FastEngine
 			}
 			// a batch that did not fit sets the width of the next ones
 			bw = fo ? nb : ((2*bw < WSZ) ? 2*bw : static_cast<uint32_t>(WSZ));
-			if ( fact && static_cast<uint32_t>(lane) < nb ) forwardTreeFinish(F,fi,firstnode,lmax);
+			{ SITE_T0 if ( fact && static_cast<uint32_t>(lane) < nb ) forwardTreeFinish(F,fi,firstnode,lmax); SITE(22) }
 			wv_sync();
 			PROF(*this,10)
 			if ( lane == 0 ) { pcount(26,1); pcount(25,nb*nL); }
@@ -2898,7 +2986,9 @@ struct FastEngine
 				{
 					uint32_t const p = p0 + t;
 					uint32_t const pfi = fstart + p/nL, pli = p%nL;
+					SITE_T0
 					uint32_t const cl = classifyPair(pfi,pli,lmax);
+					SITE(26)      // pair generation: classification of a pair (cached enumerations valid?)
 					uint32_t mode;
 					if ( cl != 3 ) mode = PM_EXACT | cl;
 					else if ( (L.rfmask()[pli] & L.ffm()[pfi]) == 0 ) mode = PM_SKIP;     // the forward tree and the reverse block share no junction k-mer
@@ -2939,7 +3029,7 @@ struct FastEngine
 			if ( restart ) continue;
 			fstart += nb; pskip = 0;
 		}
-		restoreS();
+		{ SITE_T0 restoreS(); SITE(25) }
 		PROF(*this,12)
 		// CDH -> CH -> ACC (:5099-5136) leaves the kept candidates in descending weight order.  With pairwise distinct
 		// weights that order does not depend on the heaps: one lane per candidate counts the heavier ones and stores its
@@ -3253,6 +3343,9 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 #endif
 	}
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
+#if defined(DACC_PROFILE) && !defined(DACC_EMUL)
+	uint64_t * const prof = E.prof;
+#endif
 #if defined(DACC_EMUL)
 	g_fstats.clear();
 #endif
@@ -3389,8 +3482,10 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				// traversed has saved them to the slab first (gw tiers)
 				if ( !instvalid )
 				{
-					if ( instsaved ) E.restoreInstances();
-					else if ( !(hslot && !handloaded && E.loadHand(FB,hslot)) ) E.buildInstances();      // handed over by the tier before: no second sort
+					SITE_T0
+					if ( instsaved ) { E.restoreInstances(); SITE(27) }
+					else if ( !(hslot && !handloaded && E.loadHand(FB,hslot)) ) { E.buildInstances(); SITE(28) }      // handed over by the tier before: no second sort
+					else { SITE(30) }
 					handloaded = true;
 				}
 				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only
@@ -3405,7 +3500,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				// traversal structures then never overwrite the instance array, which the next pass takes over.
 				instvalid = false;
 				if ( ff != 0 && E.passIsDead() ) { instvalid = true; continue; }
-				if ( CT::gw != 0 && ff > B.P.minff && !instsaved ) { E.saveInstances(); instsaved = true; }
+				if ( CT::gw != 0 && ff > B.P.minff && !instsaved ) { SITE_T0 E.saveInstances(); instsaved = true; SITE(29) }
 				E.buildSuccessors(mao);
 				PROF(E,4)
 				if ( ff == 0 )

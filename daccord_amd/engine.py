@@ -53,6 +53,8 @@ def lib():
         L.dacc_debug_windows.argtypes = [vp, vp, C.c_uint64, vp]
         L.dacc_debug_tables.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
         L.dacc_debug_profile.argtypes = [vp, vp]
+        if hasattr(L, "dacc_debug_profile_fine"):      # (variant libraries of earlier rounds, DACC_LIB, lack it)
+            L.dacc_debug_profile_fine.argtypes = [vp, vp]
         L.dacc_debug_retry.argtypes = [vp, vp, C.c_uint64, vp]
         L.dacc_pile_status.argtypes = [vp, vp, C.c_uint64, vp]
         L.dacc_pile_errors.restype = C.c_char_p
@@ -63,7 +65,7 @@ def lib():
 
 EXPORTS = ["dacc_device_count", "dacc_create", "dacc_destroy", "dacc_set_error_profile", "dacc_load_db", "dacc_submit_piles", "dacc_collect",
            "dacc_release", "dacc_last_error", "dacc_pile_select", "dacc_last_timing", "dacc_rerun_resident",
-           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile", "dacc_debug_retry", "dacc_pile_status", "dacc_pile_errors"]
+           "dacc_debug_windows", "dacc_debug_tables", "dacc_debug_profile", "dacc_debug_profile_fine", "dacc_debug_retry", "dacc_pile_status", "dacc_pile_errors"]
 
 
 def _ptr(a):
@@ -157,6 +159,12 @@ class Engine:
         out = np.zeros(32, dtype=np.uint64)
         self._chk(self.L.dacc_debug_profile(self.h, _ptr(out)))
         return out
+
+    def profile_fine(self):
+        """(cycles[48], visits[48]) of the fine sites of a -DDACC_PROFILE build (scripts/prof_sites.py)."""
+        out = np.zeros(96, dtype=np.uint64)
+        self._chk(self.L.dacc_debug_profile_fine(self.h, _ptr(out)))
+        return out[:48], out[48:]
 
     def pile_status(self):
         """(status per pile of the last batch, list of messages for dropped piles)."""

@@ -220,6 +220,9 @@ int  dacc_debug_tables(dacc_ctx *ctx, uint64_t *out, uint64_t cap, uint64_t *n, 
 /* Profiling hook: 32 per-phase shader-cycle counters of the window kernel (zero unless the library was
  * built with -DDACC_PROFILE). */
 int  dacc_debug_profile(dacc_ctx *ctx, uint64_t *out32);
+/* The fine sites of the same build (round 5 hot-spot ledger, scripts/prof_sites.py): out96[s] = shader cycles spent at site s,
+ * out96[48+s] = visits, s < 48. */
+int  dacc_debug_profile_fine(dacc_ctx *ctx, uint64_t *out96);
 
 /* Debugging hook (environment DACC_DEBUG_RETRY=1 at dacc_create): quadruples (window, flags, strings, filter frequency)
  * of the windows the last LDS capacity tier handed to the generic engine in the last run. */
