@@ -180,9 +180,13 @@ struct BatchPlan
 	static unsigned planThreads(uint64_t const np)
 	{
 		unsigned n = 0;
-		if ( char const * e = getenv("DACC_PLAN_THREADS") ) n = static_cast<unsigned>(atoi(e));
+		//  the environment value is a request within [1,64]; zero, negative or unparsable counts as unset
+		if ( char const * e = getenv("DACC_PLAN_THREADS") ) { long const v = strtol(e,0,10); if ( v > 0 ) n = static_cast<unsigned>(v > 64 ? 64 : v); }
 		if ( !n ) { n = std::thread::hardware_concurrency(); if ( !n ) n = 1; if ( n > 16 ) n = 16; }
-		uint64_t const byload = np/64 + 1;
+		// DACC_PLAN_PILES_PER_THREAD (tests): piles a thread must have before another one is started, default 64
+		uint64_t per = 64;
+		if ( char const * e = getenv("DACC_PLAN_PILES_PER_THREAD") ) { long const v = strtol(e,0,10); if ( v > 0 ) per = static_cast<uint64_t>(v); }
+		uint64_t const byload = np/per + 1;
 		if ( n > byload ) n = static_cast<unsigned>(byload);
 		return n ? n : 1;
 	}

@@ -464,7 +464,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
 	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
-	int64_t long_hint;      // windows the second stream ran in the last pass of this context (-1: unknown): grid of k_window_long
+	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
 	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_t0inst;     // debugging knobs, read once in dacc_create
@@ -491,8 +491,10 @@ template<typename F> static int guarded(dacc_ctx * c, F const & f)
 {
 	try { return f(); }
 	catch ( std::bad_alloc const & ) { if ( c ) { try { c->err = "out of host memory"; } catch ( ... ) {} } return DACC_ENOMEM; }
-	catch ( std::exception const & ex ) { if ( c ) { try { c->err = std::string("host side failed: ") + ex.what(); } catch ( ... ) {} } return DACC_ENOMEM; }
-	catch ( ... ) { return DACC_ENOMEM; }
+	//  anything that is not an allocation failure -- std::system_error of a planner thread, length_error -- is an internal error,
+	// not "out of memory", and the message names it instead of leaving the previous call's text in place
+	catch ( std::exception const & ex ) { if ( c ) { try { c->err = std::string("host side failed: ") + ex.what(); } catch ( ... ) {} } return DACC_EINTERNAL; }
+	catch ( ... ) { if ( c ) { try { c->err = "host side failed: unknown exception"; } catch ( ... ) {} } return DACC_EINTERNAL; }
 }
 
 extern "C" {
@@ -519,7 +521,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	if ( hipSetDevice(p->device) != hipSuccess ) return DACC_ENODEV;
 	dacc_ctx * c = new (std::nothrow) dacc_ctx;
 	if ( !c ) return DACC_ENOMEM;
-	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->long_hint = -1; c->handcap = 0; c->handwords = 0; c->handwant = 0; c->nruns = 0;
+	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->nlong[0] = c->nlong[1] = 0; c->handcap = 0; c->handwords = 0; c->handwant = 0; c->nruns = 0;
 	std::memset(&c->timing,0,sizeof(c->timing));
 	// launch geometry of the LDS tiers: set by every batch that uses them; a generic-only batch (DACC_NOFAST, w >= 64, a model table no
 	// tier holds) reads retry_grid in its scratch retry and must not find an indeterminate value there
@@ -634,6 +636,9 @@ static int runDevice(dacc_ctx * c)
 		// second use of this context: now the hand-over buffer pays (dacc_submit_piles); an optimisation only -- if the device
 		// cannot spare it, halve it, and in the end do without
 		uint64_t cap = c->handwant;
+		//  never more than half of what the device has free right now: the buffer is an optimisation and must not be what
+		// makes a later, larger batch of this context (or of another worker on the same device) fail its mandatory buffers
+		{ size_t fr = 0, tot = 0; if ( hipMemGetInfo(&fr,&tot) == hipSuccess ) { uint64_t const lim = (static_cast<uint64_t>(fr)/2) / (static_cast<uint64_t>(c->handwords)*8ull); if ( cap > lim ) cap = lim; } else (void)hipGetLastError(); }
 		while ( cap && c->d_hand.ensure(static_cast<size_t>(cap)*c->handwords) != hipSuccess ) { (void)hipGetLastError(); cap = cap > 65536 ? cap/2 : 0; }
 		c->handcap = static_cast<uint32_t>(cap); c->handwant = cap;
 	}
@@ -682,17 +687,29 @@ static int runDevice(dacc_ctx * c)
 			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0; FL.gslab = 0; FL.gstride = 0; FL.tab32 = c->d_tab32.p; FL.hand = 0; FL.handctr = 0; FL.handcap = 0; FL.handwords = 0;
 			if ( !c->tierL_ok ) FL.F.ldsbytes = 0;
 			// a launch the device refuses (the LDS of a whole CU) falls back to the generic engine alone, for good
-			auto const launchLong = [&](uint32_t const * const lst)
+			// (round 5) The length of a list is fetched before its launch (one 4 byte copy and a stream synchronisation: the host has
+			// nothing else to queue at these two points) and the grid follows it: an empty list -- the rule at the default window -- is
+			// not launched at all, a list of three windows asks for three CUs' worth of LDS instead of 256.  Rounds 1-4 queued the full
+			// grid twice per pass; its workgroups need the LDS of a whole CU each and sat in the queue until the tier in front retired
+			// (939 ms of "duration" for one window in the round-4 kernel table).
+			auto const launchLong = [&](uint32_t const * const lst, uint32_t & nlist) -> int
 			{
+				nlist = 0;
+				HIPCHK(hipMemcpyAsync(&nlist,lst,sizeof(uint32_t),hipMemcpyDeviceToHost,s));
+				HIPCHK(hipStreamSynchronize(s));
+				if ( !nlist ) return DACC_OK;
+				uint32_t const grid = nlist < c->early_grid ? nlist : c->early_grid;
 				(void)hipGetLastError();
-				hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,lst);
+				hipLaunchKernelGGL(k_window_long,dim3(grid),dim3(64),FL.F.ldsbytes,c->stream2,FL,c->d_err.p,lst);
 				if ( FL.F.ldsbytes && hipGetLastError() != hipSuccess )
 				{
 					c->tierL_ok = 0; FL.F.ldsbytes = 0;
-					hipLaunchKernelGGL(k_window_long,dim3(c->early_grid),dim3(64),0,c->stream2,FL,c->d_err.p,lst);
+					hipLaunchKernelGGL(k_window_long,dim3(grid),dim3(64),0,c->stream2,FL,c->d_err.p,lst);
 				}
+				return DACC_OK;
 			};
-			launchLong(static_cast<uint32_t const *>(c->d_pregenlist.p));
+			c->nlong[0] = c->nlong[1] = 0;
+			{ int const rc = launchLong(static_cast<uint32_t const *>(c->d_pregenlist.p),c->nlong[0]); if ( rc ) return rc; }
 			WB.pregen = c->d_pregen.p;
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
@@ -736,7 +753,7 @@ static int runDevice(dacc_ctx * c)
 						early = true;
 						HIPCHK(hipEventRecord(c->evFirstTier,s));
 						HIPCHK(hipStreamWaitEvent(c->stream2,c->evFirstTier,0));
-						launchLong(static_cast<uint32_t const *>(c->d_gearly.p));
+						{ int const rc = launchLong(static_cast<uint32_t const *>(c->d_gearly.p),c->nlong[1]); if ( rc ) return rc; }
 						HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
 					}
 				}
@@ -797,10 +814,9 @@ static int runDevice(dacc_ctx * c)
 	c->timing.tier0_in = 0; c->timing.tier0_out = 0;
 	if ( c->usefast && BP.nwindows && (c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2]) )
 	{
-		// length of the two lists of the second stream (pre-scan, first tier's generic-only windows): grid of the next pass
-		uint32_t n1 = 0, n2 = 0;
-		HIPCHK(hipMemcpy(&n1,c->d_pregenlist.p,sizeof(uint32_t),hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&n2,c->d_gearly.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
-		c->long_hint = std::max(n1,n2); c->timing.long_windows = n1 + n2;
+		// length of the two lists of the second stream (pre-scan, first tier's generic-only windows), fetched before their launches
+		uint32_t const n1 = c->nlong[0], n2 = c->nlong[1];
+		c->timing.long_windows = n1 + n2;
 		if ( c->tier0_ran )
 		{
 			// size classes: the pre-pass sent nsmall windows to tier 0 and nwindows - nsmall - n1 to the big list, which tier 0's
@@ -1155,7 +1171,45 @@ int dacc_debug_windows(dacc_ctx * c, dacc_window_result * out, uint64_t cap, uin
 // guarded entry points (bodies: the *_body functions above)
 int dacc_set_error_profile(dacc_ctx * c, double p_i, double p_d, double est_cor) { return guarded(c,[&]() { return dacc_set_error_profile_body(c,p_i,p_d,est_cor); }); }
 int dacc_load_db(dacc_ctx * c, uint8_t const * bps, uint64_t bps_bytes, uint64_t const * boff, uint32_t const * rlen, uint64_t nreads) { return guarded(c,[&]() { return dacc_load_db_body(c,bps,bps_bytes,boff,rlen,nreads); }); }
-int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes) { return guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); }); }
-int dacc_rerun_resident(dacc_ctx * c) { return guarded(c,[&]() { return dacc_rerun_resident_body(c); }); }
+// Measurement hook, host only (no device, no context): the planner of dacc_submit_piles (BatchPlan::plan: device records, window schedule,
+// active ranges, offsets -- everything a batch needs before its first byte is uploaded) on the caller's thread + the planner's own.  With
+// it the front end can time the whole host side of a run (loader + selection + plan) on a box without a GPU: `daccord_hip --loaderonly`.
+int dacc_plan_only(dacc_params const * par, uint32_t const * rlen, uint64_t nreads, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl,
+	void const * trace, uint64_t ntrace, int trace_bytes, uint64_t * nwindows, uint64_t * nblocks)
+{
+	if ( !par || !rlen || (!piles && npiles) ) return DACC_EINVAL;
+	try
+	{
+		BatchPlan BP; std::string err;
+		int const rc = BP.plan(*par,piles,npiles,ovl,novl,trace,ntrace,trace_bytes,rlen,nreads,err);
+		if ( nwindows ) *nwindows = BP.nwindows;
+		if ( nblocks ) *nblocks = BP.nblocks;
+		return rc;
+	}
+	catch ( std::bad_alloc const & ) { return DACC_ENOMEM; }
+	catch ( ... ) { return DACC_EINTERNAL; }
+}
+
+//  a HIP failure while the optional hand-over buffer is held (up to 16 GB) may be an allocation it starved: give the buffer
+// back and run the call once more without it
+static bool dacc_drop_hand(dacc_ctx * c)
+{
+	if ( !c || !c->d_hand.p ) return false;
+	(void)hipGetLastError(); hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipGetLastError();
+	c->d_hand.release(); c->handcap = 0; c->handwant = 0;
+	return true;
+}
+int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes)
+{
+	int rc = guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); });
+	if ( (rc == DACC_EHIP || rc == DACC_ENOMEM) && dacc_drop_hand(c) ) rc = guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); });
+	return rc;
+}
+int dacc_rerun_resident(dacc_ctx * c)
+{
+	int rc = guarded(c,[&]() { return dacc_rerun_resident_body(c); });
+	if ( (rc == DACC_EHIP || rc == DACC_ENOMEM) && dacc_drop_hand(c) ) rc = guarded(c,[&]() { return dacc_rerun_resident_body(c); });
+	return rc;
+}
 
 }

@@ -47,7 +47,7 @@ struct Options
 	uint32_t w = 40, a = 10, m = 3; uint64_t d = UINT64_MAX, e = UINT64_MAX, l = 0, D = 5000, vard = 0;
 	bool f = false; int V = 1; bool haveI = false, haveJ = false; std::string Itext, Jtext; int64_t Ilo = 0, Ihi = 0, Jc = 0, Jd = 1;
 	std::string E, eprof; uint32_t klow = 8, khigh = 8; int32_t minff = 0, maxff = 2;
-	bool eprofonly = false, keepeprof = false, deepprofileonly = false, binaryeprof = false; int device = 0; int gpus = 1; uint64_t batch = 2000;
+	bool eprofonly = false, keepeprof = false, deepprofileonly = false, binaryeprof = false, loaderonly = false; int device = 0; int gpus = 1; uint64_t batch = 2000;
 	std::vector<std::string> pos;
 };
 
@@ -97,6 +97,7 @@ Options parse(int argc, char ** argv)
 			else if ( val("gpus",v) ) { o.gpus = static_cast<int>(num("--gpus",v)); if ( o.gpus < 1 || o.gpus > 64 ) die("--gpus needs a number between 1 and 64"); }
 			else if ( val("batch",v) ) { o.batch = num("--batch",v); if ( !o.batch ) die("--batch needs a positive number of A reads"); }
 			else if ( val("deepprofileonly",v) ) o.deepprofileonly = v.empty() || v != "0";
+			else if ( val("loaderonly",v) ) o.loaderonly = v.empty() || v != "0";
 			else die("unknown option " + a);
 			continue;
 		}
@@ -134,7 +135,8 @@ Options parse(int argc, char ** argv)
 			"  --eprof<p_i,p_d,est_cor> | -E<file> error profile (default: <las>.eprof, estimated if missing)  --eprofonly  --keepeprof  --deepprofileonly\n"
 			"  --binaryeprof             write an estimated profile in the reference's binary form (read in either form)\n"
 			"  --device<0> first HIP device  --gpus<1> devices used by this process (batches are dealt to them, output stays ordered)\n"
-			"  --batch<2000> A reads per GPU batch  (or one process per GPU like the reference: -J<g,G> --device<g>)\n");
+			"  --batch<2000> A reads per GPU batch  (or one process per GPU like the reference: -J<g,G> --device<g>)\n"
+			"  --loaderonly  measure the host side alone (loader + selection + planner, --gpus planner threads), no device\n");
 		std::exit(EXIT_FAILURE);
 	}
 	// what dacc_create would refuse, said before any file is read and in the option's own words.  The reference compiles k = 3 ... 12 and
@@ -394,6 +396,82 @@ int main(int argc, char ** argv)
 	dacc_params p; std::memset(&p,0,sizeof(p));
 	p.w = o.w; p.a = o.a; p.klow = o.klow; p.khigh = o.khigh; p.minfilterfreq = o.minff; p.maxfilterfreq = o.maxff; p.minwindowcov = o.m;
 	p.maxalign = o.d; p.eminrate = o.e; p.minlen = o.l; p.producefull = o.f ? 1 : 0; p.tspace = tspace; p.device = o.device; p.verbose = o.V;
+	if ( o.loaderonly )
+	{
+		// Measurement without a device (round 5, VERDICT r04 task 5): the host side of a run alone.  One loader thread reads and selects
+		// the batches exactly as below; --gpus N consumer threads stand in for the device workers and run only what dacc_submit_piles
+		// does on the host before its first upload (the planner, dacc_plan_only).  Reports what the loader sustains (piles/s, A-read
+		// Mbase/s) and what the planners do, so that "can one loader feed N GPUs" has a number.
+		int const nwork = o.gpus;
+		int64_t const batch = static_cast<int64_t>(o.batch);
+		std::mutex mu; std::condition_variable cv; std::deque<Batch *> loaded, freeb; std::vector<Batch> bslots(2*nwork);
+		for ( size_t i = 0; i < bslots.size(); ++i ) freeb.push_back(&bslots[i]);
+		double load_s = 0, wait_s = 0, plan_s = 0; uint64_t npl = 0, nov = 0, abases = 0, nwin = 0, nbat = 0; std::string fatal;
+		auto const t0 = std::chrono::steady_clock::now();
+		std::thread loader([&]() {
+			uint64_t seq = 0;
+			for ( int64_t b0 = minaread; ; b0 += batch )
+			{
+				Batch * B;
+				auto const tw = std::chrono::steady_clock::now();
+				{ std::unique_lock<std::mutex> lk(mu); cv.wait(lk,[&]{ return !freeb.empty(); }); B = freeb.front(); freeb.pop_front(); }
+				auto const tl = std::chrono::steady_clock::now();
+				B->end = !(b0 < toparead); B->seq = seq++;
+				if ( !B->end ) loadBatch(b0,std::min(toparead,b0+batch),false,*B);
+				auto const te = std::chrono::steady_clock::now();
+				bool const stop = B->end || !B->err.empty();
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					wait_s += std::chrono::duration<double>(tl-tw).count(); load_s += std::chrono::duration<double>(te-tl).count();
+					if ( !B->end ) { npl += B->spiles.size(); nov += B->sel.size(); for ( size_t i = 0; i < B->spiles.size(); ++i ) abases += prlen[B->spiles[i].aread]; }
+					loaded.push_back(B);
+				}
+				cv.notify_all();
+				if ( stop ) break;
+			}
+		});
+		bool stopall = false;
+		auto const consumer = [&]()
+		{
+			while ( true )
+			{
+				Batch * B = 0;
+				{
+					std::unique_lock<std::mutex> lk(mu);
+					cv.wait(lk,[&]{ return stopall || !loaded.empty(); });
+					if ( stopall && loaded.empty() ) return;
+					B = loaded.front(); loaded.pop_front();
+					if ( B->end || !B->err.empty() ) { stopall = true; if ( !B->err.empty() && fatal.empty() ) fatal = B->err; }
+				}
+				cv.notify_all();
+				if ( !B->end && B->err.empty() && !B->spiles.empty() )
+				{
+					auto const tp = std::chrono::steady_clock::now();
+					uint64_t w = 0, nb = 0;
+					int const rc = dacc_plan_only(&p,prlen,nreads,B->spiles.data(),B->spiles.size(),B->sel.data(),B->sel.size(),B->trace.data(),B->ntrace,tbytes,&w,&nb);
+					double const dt = std::chrono::duration<double>(std::chrono::steady_clock::now()-tp).count();
+					std::lock_guard<std::mutex> lk(mu);
+					if ( rc && fatal.empty() ) fatal = "planner failed (" + std::to_string(rc) + ")";
+					plan_s += dt; nwin += w; ++nbat;
+				}
+				{ std::lock_guard<std::mutex> lk(mu); freeb.push_back(B); }
+				cv.notify_all();
+			}
+		};
+		std::vector<std::thread> cons; for ( int g = 0; g < nwork; ++g ) cons.emplace_back(consumer);
+		loader.join(); for ( size_t g = 0; g < cons.size(); ++g ) cons[g].join();
+		double const tot = std::chrono::duration<double>(std::chrono::steady_clock::now()-t0).count();
+		if ( !fatal.empty() ) die(fatal);
+		std::fprintf(stderr,"[L] host side only: %llu piles (%llu selected overlaps, %llu A-read bases, %llu windows) in %llu batches of %llu A reads, %.3f s wall\n"
+			"[L] loader thread: %.3f s reading + selecting = %.0f piles/s = %.1f Mbase/s of A reads; %.3f s waiting for a free batch slot\n"
+			"[L] %d planner thread(s) standing in for the device workers: %.3f s in dacc_plan_only in total = %.0f piles/s per worker\n",
+			static_cast<unsigned long long>(npl),static_cast<unsigned long long>(nov),static_cast<unsigned long long>(abases),static_cast<unsigned long long>(nwin),
+			static_cast<unsigned long long>(nbat),static_cast<unsigned long long>(o.batch),tot,
+			load_s,load_s > 0 ? npl/load_s : 0.0,load_s > 0 ? abases/load_s/1e6 : 0.0,wait_s,
+			nwork,plan_s,plan_s > 0 ? npl/plan_s : 0.0);
+		return EXIT_SUCCESS;
+	}
+
 	// One context per device worker.  --gpus N uses the devices device, device+1, ...; when there are fewer devices the workers
 	// wrap around (a legal, oversubscribed configuration: two contexts on one GPU overlap one batch's host plan with the other's
 	// kernels; it is also how the mode is tested on a box with one GPU).  Piles are independent, so the batches are simply dealt to whichever worker is free; the writer

@@ -14,7 +14,7 @@ from ._structs import (DaccParams, DaccOverlap, DaccPile, DaccFragment, DaccTimi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("DACC_LIB") or os.path.join(_HERE, "libdaccord_hip.so")
 
-ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP", -6: "ENOTSUP"}
+ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP", -6: "ENOTSUP", -7: "EINTERNAL"}
 
 
 class DaccError(RuntimeError):

@@ -38,6 +38,7 @@ extern "C" {
 #define DACC_ESTATE     -4   /* call order violated (e.g. submit before load_db) */
 #define DACC_EHIP       -5   /* HIP runtime error, see dacc_last_error */
 #define DACC_ENOTSUP    -6   /* input outside the kernel's capacity (depth / tspace / k) */
+#define DACC_EINTERNAL  -7   /* an exception of the host side that is not an allocation failure (a planner thread, a container): see dacc_last_error */
 
 /* Run parameters: the daccord command line options that shape the path
  * (src/daccord.cpp:101-169 defaults, :1282-1305 parsing). */
@@ -191,6 +192,13 @@ int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
  * most 64), valid until the next call on this context. */
 int  dacc_pile_status(dacc_ctx *ctx, int32_t *status, uint64_t cap, uint64_t *n);
 const char *dacc_pile_errors(dacc_ctx *ctx);
+
+/* Host-only measurement hook (no device, no context): the planner that dacc_submit_piles runs before its uploads, on the same
+ * inputs; nwindows / nblocks (optional) receive the batch's window and trace block counts.  `daccord_hip --loaderonly` times the
+ * host side of a run with it on a box without a GPU (reference: the input side of the OpenMP loop, src/daccord.cpp:2107-2160). */
+int  dacc_plan_only(const dacc_params *par, const uint32_t *rlen, uint64_t nreads, const dacc_pile *piles, uint64_t npiles,
+                    const dacc_overlap *ovl, uint64_t novl, const void *trace, uint64_t ntrace, int trace_bytes,
+                    uint64_t *nwindows, uint64_t *nblocks);
 
 /* Re-run only the device part of the last submitted batch (inputs already resident
  * in HBM); used by bench.py so the timed region excludes H2D. */

@@ -88,6 +88,28 @@ def test_plan_reproduces_the_committed_digests(threads):
     assert G["narrow_k8_pile_out_of_range"][1] != 0 and G["narrow_k8_malformed"][1] == 0 and G["narrow_k8"][0] != G["narrow_k8_malformed"][0]
 
 
+def test_plan_with_sixteen_threads_that_really_run():
+    """ the committed cases have 120-400 piles = at most a dozen chunks of 32, and the planner starts one thread per 64 piles, so
+    `threads=16` above runs 3-7 of them.  Here a batch is tiled to 2400+ piles (the tiles share the overlap records, which the planner only
+    reads) and the piles-per-thread floor is lowered: 16 threads over 75+ chunks against the serial planner, byte for byte."""
+    name, kw, d, ovl, piles, trace = [c for c in _cases() if c[0] == "deep"][0]
+    reps = (2400 + len(piles) - 1) // len(piles)
+    big = np.concatenate([piles] * reps)
+    assert len(big) >= 2400
+    os.environ["DACC_PLAN_THREADS"] = "1"
+    try:
+        serial = _digest(kw, d, ovl, big, trace)
+        os.environ["DACC_PLAN_THREADS"] = "16"; os.environ["DACC_PLAN_PILES_PER_THREAD"] = "8"
+        par16 = _digest(kw, d, ovl, big, trace)
+        os.environ["DACC_PLAN_THREADS"] = "-5"      # not a count: treated as unset (hardware concurrency, at most 16)
+        unset = _digest(kw, d, ovl, big, trace)
+        os.environ["DACC_PLAN_THREADS"] = "100000"      # clamped to 64
+        many = _digest(kw, d, ovl, big, trace)
+    finally:
+        os.environ.pop("DACC_PLAN_THREADS", None); os.environ.pop("DACC_PLAN_PILES_PER_THREAD", None)
+    assert serial == par16 == unset == many and serial[1] == 0, (serial, par16, unset, many)
+
+
 def test_plan_has_no_data_race(tmp_path):
     """the planner's threads under ThreadSanitizer (tests/emul/plan_tsan.cpp): no report, one digest for 1 / 8 / 3 / 16 threads;
     an exception in a worker is rethrown in the caller after the join"""
