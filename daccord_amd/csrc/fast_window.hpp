@@ -2294,51 +2294,111 @@ struct FastEngine
 		return found;
 	}
 	// one candidate offered to the candidate heap CDH (:5049-5092, including the shrink quirk); false: stop (error)
+	//
+	// Round 5: a candidate enters the heap as its pair of pool ids (forward path | reverse path << 16, flag UNMAT) and its stretch
+	// sequence is written to a slot only if the candidate is still in the heap when its pools are about to be reused (materializeKept,
+	// one lane per candidate, at the end of a batch of forward trees; materializeSerial after a pair on its exact stretch set).  The
+	// duplicate test (:5077-5088: same string as the previous candidate kept of this pair <=> same stretch sequence) needs the two
+	// sequences only when their stretch counts AND consensus lengths agree, both of which follow from the ids with four loads.
+	// Rounds 1-4 walked the two parent chains of EVERY offered candidate on lane 0 (33 walks of 2 300 cycles per window of config 2,
+	// 5.6 % of its time: site 6 of profiles/r05b_sites_cfg2_256piles_first_ledger.log) and copied the sequence twice.
+	enum : uint32_t { UNMAT = 0x80000000u };
+	uint32_t pvpath, pvrp, pvcl, pvnf;      // lane 0: the previous candidate kept of the current pair (pool ids, consensus length, stretches of its forward part); its stretch count is `pn`
+	// Do (forward entry pa with na stretches, reverse entry ra) and (pb with nb, rb) spell the same stretch sequence, given equal
+	// totals and na != nb?  The pool entries of an enumeration are the nodes of a tree (one entry per (parent, stretch)), so two
+	// entries of one enumeration are equal sequences iff they are the same entry.  With na < nb = na + d the sequences are equal iff
+	// pa is the d-th ancestor of pb, rb is the d-th ancestor of ra, and the d stretches in between agree: d steps along two parent
+	// chains (d = distance of the two junctions, mostly 1) instead of both full chains.  Half of the offered candidates of config 2
+	// are such duplicates -- the same chain met at a neighbouring junction k-mer.
+	DEV bool seqEqual(uint32_t pa, uint32_t ra, uint32_t na, uint32_t pb, uint32_t rb, uint32_t nb)
+	{
+		if ( na > nb ) { uint32_t t = pa; pa = pb; pb = t; t = ra; ra = rb; rb = t; t = na; na = nb; nb = t; }
+		uint32_t const d = nb - na;
+		if ( static_cast<uint32_t>(L.rc_len()[ra]) < d ) return false;      // (equal totals: ra has d stretches more than rb)
+		LDSQ sid_t * mid = L.cseq() + 16*FSEQCAP;      // the first d stretches of ra in candidate order
+		uint32_t qr = ra;
+		for ( uint32_t t = 0; t < d; ++t ) { mid[t] = L.rc_stretch()[qr]; qr = L.rc_parent()[qr]; }
+		if ( qr != rb ) return false;
+		uint32_t qf = pb;
+		for ( uint32_t t = 0; t < d; ++t )
+		{
+			if ( L.f_stretch()[qf] != mid[d-1-t] ) return false;
+			qf = L.f_parent()[qf];
+		}
+		return qf == pa;
+	}
 	DEV bool offerCandidate(uint64_t const weight, uint32_t const path, uint32_t const rp, uint32_t & pn)
 	{
-		LDSQ sid_t * cur = L.cseq() + 16*FSEQCAP; LDSQ sid_t * prev = L.cseq() + 17*FSEQCAP;
 		FSTAT_ADD(18,1);
 		SITE_T0
-		if ( ncdh == 16 ) { cfree |= 1u << L.cdh()[0].o; spop<FCC,true>(L.cdh(),ncdh); SITE(5) }   // weight > top here
-		uint32_t conslen = 0;
-		uint64_t const tbs_ = pclock();
-		uint32_t const n = buildSeq(path,rp,cur,conslen);
-		pcount(24,pclock()-tbs_);      // profiling builds: cycles of the sequence walks (lane 0)
-		SITE(6)      // offerCandidate: sequence walk of the two parent chains
-		if ( n == ~0u ) return false;
-		// sequences are compared and copied as 64 bit words (a slot is FSEQCAP ids, 8 byte aligned; ids behind a sequence's
-		// length are never looked at): one round of loads instead of one per stretch
-		enum : uint32_t { SW = FSEQCAP*sizeof(sid_t)/8u, IPW = 8u/sizeof(sid_t) };      // words per slot, ids per word
-		static_assert((FSEQCAP*sizeof(sid_t)) % 8 == 0 && (FastLds<CT>::o_cseq & 7) == 0,"candidate sequences are moved as 64 bit words");
-		LDSQ uint64_t const * cur8 = reinterpret_cast<LDSQ uint64_t const *>(cur);
-		LDSQ uint64_t * prev8 = reinterpret_cast<LDSQ uint64_t *>(prev);
-		uint64_t cw[SW];
-		#pragma unroll
-		for ( uint32_t q = 0; q < SW; ++q ) cw[q] = cur8[q];
-		if ( n == pn )
+		if ( ncdh == 16 ) { uint32_t const to = L.cdh()[0].o, tl = L.cdh()[0].l; if ( !(tl & UNMAT) ) cfree |= 1u << to; spop<FCC,true>(L.cdh(),ncdh); SITE(5) }   // weight > top here
+		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[rp];
+		uint32_t const conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[rp];
+		if ( nf + nr > FSEQCAP || conslen > MAXCONS ) { over(4096); return false; }      // (the checks of buildSeq, in its order)
+		uint32_t const n = nf+nr;
+		SITE(6)      // offerCandidate: stretch count and consensus length of the candidate
+		// Within a pair both candidates come from one forward tree and one reverse enumeration, whose pool entries are the nodes of
+		// a tree each: two entries of the same enumeration are different stretch sequences.  So equal strings need equal stretch counts
+		// and consensus lengths, a different forward entry AND a different reverse entry, and forward parts of different lengths (the
+		// same chain cut at another junction); half of the offers of config 2 pass the first two tests, hardly any all of them.
+		if ( n == pn && conslen == pvcl && path != pvpath && rp != pvrp && nf != pvnf )
 		{
-			// ids [0,n) equal <=> the xor of every word, cut to the ids below n, is zero
-			uint64_t diff = 0;
-			#pragma unroll
-			for ( uint32_t q = 0; q < SW; ++q )
-			{
-				uint64_t const pq = prev8[q];
-				uint64_t const m = n >= IPW*q+IPW ? ~0ull : ( n > IPW*q ? ((1ull << (8u*sizeof(sid_t)*(n-IPW*q)))-1ull) : 0ull );
-				diff |= (cw[q]^pq) & m;
-			}
-			if ( diff == 0 ) { SITE(7) return true; }
+			bool const same = seqEqual(path,rp,nf,pvpath,pvrp,pvnf);
+			SITE(7)      // offerCandidate: comparison with the previous kept candidate (the stretches between the two junctions)
+			if ( same ) return true;
 		}
-		SITE(7)      // offerCandidate: sequence words loaded, compared with the previous kept candidate
-		uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
-		LDSQ uint64_t * dst8 = reinterpret_cast<LDSQ uint64_t *>(L.cseq() + FSEQCAP*slot);
-		#pragma unroll
-		for ( uint32_t q = 0; q < SW; ++q ) { prev8[q] = cw[q]; dst8[q] = cw[q]; }
-		pn = n;
-		FCC cc; cc.w = weight; cc.o = slot; cc.l = n | (conslen<<8);
+		pn = n; pvpath = path; pvrp = rp; pvcl = conslen; pvnf = nf;
+		FCC cc; cc.w = weight; cc.o = path | (rp << 16); cc.l = n | (conslen<<8) | UNMAT;
 		FSTAT_ADD(19,1);
 		spush<FCC,true>(L.cdh(),ncdh,cc);
-		SITE(8)      // offerCandidate: slot copy + push
+		SITE(8)      // offerCandidate: push
 		return true;
+	}
+	// all lanes: the kept candidates that are still pool ids get a sequence slot each and their sequences, one lane per candidate
+	DEV void materializeKept()
+	{
+		wv_sync();
+		uint32_t const n = wv_bcast(ncdh,0);
+		if ( !n ) return;
+		uint32_t const cf = wv_bcast(cfree,0);
+		uint32_t taken = 0, done = 0;
+		for ( uint32_t c0 = 0; c0 < n; c0 += WSZ )
+		{
+			uint32_t const c = c0 + lane;
+			FCC e; e.w = 0; e.o = 0; e.l = 0;
+			if ( c < n ) e = ldget(L.cdh()+c);
+			bool const um = c < n && (e.l & UNMAT) != 0;
+			uint32_t tot; uint32_t const rank = done + wv_scan_flag(um,tot);
+			done += tot;
+			if ( um )
+			{
+				uint32_t m = cf; for ( uint32_t i = 0; i < rank; ++i ) m &= m-1;      // the rank-th free slot
+				uint32_t const slot = __builtin_ctz(m);
+				uint32_t cl;
+				buildSeq(e.o & 0xFFFFu,e.o >> 16,L.cseq() + FSEQCAP*slot,cl);
+				e.o = slot; e.l &= ~static_cast<uint32_t>(UNMAT); ldput(L.cdh()+c,e);
+				taken |= 1u << slot;
+			}
+		}
+		taken = wv_or(taken);
+		if ( lane == 0 ) cfree &= ~taken;
+		wv_sync();
+	}
+	// lane 0: the same for the candidates that name pool entries from slot f0 (forward) / r0 (reverse) on -- the enumerations of a
+	// pair on its exact stretch set, whose pool space the next such pair reuses
+	DEV void materializeSerial(uint32_t const f0, uint32_t const r0)
+	{
+		for ( uint32_t c = 0; c < ncdh; ++c )
+		{
+			uint32_t const l = L.cdh()[c].l;
+			if ( !(l & UNMAT) ) continue;
+			uint32_t const o = L.cdh()[c].o, pa = o & 0xFFFFu, ra = o >> 16;
+			if ( pa < f0 && ra < r0 ) continue;
+			uint32_t const slot = __builtin_ctz(cfree); cfree &= cfree-1;
+			uint32_t cl;
+			buildSeq(pa,ra,L.cseq() + FSEQCAP*slot,cl);
+			L.cdh()[c].o = slot; L.cdh()[c].l = l & ~static_cast<uint32_t>(UNMAT);
+		}
 	}
 	// serial form (lane 0): score intervals in the shared heap L.siq, candidates offered as they are popped
 	// skip: that many pops have been offered already (recorded sequence of the lane form), pn: sequence length of the last
@@ -2347,6 +2407,7 @@ struct FastEngine
 		uint32_t const skip = 0, uint32_t pn = ~0u)
 	{
 		nsiq = 0;
+		if ( !skip ) { pvpath = pvrp = pvnf = 0; pvcl = ~0u; }      // a pair of its own: no previous candidate
 		for ( uint32_t pi = 0; pi < nfpop; ++pi )
 		{
 			uint32_t const o = clSlot<FCH>(FC,pi);
@@ -2466,7 +2527,7 @@ struct FastEngine
 	// returns true if the sequence was used up (false: ended at an entry that cannot enter the full heap, or error)
 	DEV bool replayPair(ChunkList<FNW> const & FC, uint32_t const sbase, LDSQ id_t const * out, uint32_t const cnt, uint32_t & pn)
 	{
-		pn = ~0u;
+		pn = ~0u; pvpath = pvrp = pvnf = 0; pvcl = ~0u;      // (dead between pairs: the compiler must not keep them alive across the enumerations)
 		FSTAT_ADD(16,1); FSTAT_ADD(17,cnt);
 		SITE_T0
 		for ( uint32_t e = 0; e < cnt; ++e )
@@ -2838,6 +2899,7 @@ struct FastEngine
 			}
 			else { forwardTreeLoad(FC,fi); nfp = L.fnp()[fi]; ffmx = L.ffm()[fi]; }
 			if ( rfm & ffmx ) combinePair(FC,nfp,sbase,nacc2,rfm,lmin,lmax,16);   // else: no junction k-mer in common
+			if ( !flags && (!rcached || !fcached) ) materializeSerial(fcached ? ~0u : fsave*FCH,rcached ? ~0u : rsave*RCH);      // candidates that name this pair's own enumerations
 			L.ctr()[0] = rsave; L.ctr()[1] = fsave;
 			SITE(10)      // replayRound: a pair on its exact stretch set (enumerations + serial combine)
 			if ( flags ) return 0;
@@ -2848,7 +2910,7 @@ struct FastEngine
 	DEV bool traverse(int64_t const lmin, int64_t const lmax)
 	{
 		PROF_T0
-		cfree = 0xFFFFu; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; nsiq = 0;
+		cfree = 0xFFFFu; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; nsiq = 0; pvpath = pvrp = pvnf = 0; pvcl = ~0u;
 		computeBaseStretches();
 		flags = wv_or(flags); if ( flags ) return false;
 		PROF(*this,8)
@@ -2927,6 +2989,7 @@ struct FastEngine
 		uint32_t fstart = 0, bw = WSZ, pskip = 0;
 		while ( fstart < nF )
 		{
+			materializeKept();      // the trees of the batch before are about to be overwritten
 			if ( lane == 0 ) L.ctr()[1] = 0;
 			wv_sync();
 			uint32_t const fi = fstart + lane;
@@ -3029,6 +3092,7 @@ struct FastEngine
 			if ( restart ) continue;
 			fstart += nb; pskip = 0;
 		}
+		{ SITE_T0 materializeKept(); SITE(34) }      // the pools give way to the build-phase arrays
 		{ SITE_T0 restoreS(); SITE(25) }
 		PROF(*this,12)
 		// CDH -> CH -> ACC (:5099-5136) leaves the kept candidates in descending weight order.  With pairwise distinct
@@ -3331,7 +3395,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 #endif
 	if ( B.pregen && ((B.pregen[widx>>5] >> (widx&31)) & 1) ) return FW_DONE;      // the generic engine has this window (a string longer than 64 bases)
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
-	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.nmid = 0; E.midbase = 0;
+	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pvpath = E.pvrp = E.pvnf = 0; E.pvcl = 0; E.nmid = 0; E.midbase = 0;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.gslab = 0; E.gtab = FB.tab32; E.sfresh = true; E.sdirty = false;
 	if ( CT::gw )

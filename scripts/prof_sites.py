@@ -12,13 +12,13 @@ PH = ["gather+strings", "peq+elength", "instances(sort)", "nodes", "successors",
       "stretches", "cand+tab+stretchfeas", "F trees (lanes)", "R blocks (lanes)", "tail", "cand-errors", "align+emit"]
 SITES = {1: "combineLane: intervals of a pair (scoreInterval per forward pop + heap)", 2: "combineLane: one pop (sift, next lighter, push, record)",
          3: "replayRound: per live pair up to dispatch", 4: "replayPair: entry -> weight, compare with lightest kept", 5: "offerCandidate: pop of the full candidate heap",
-         6: "offerCandidate: sequence walk (buildSeq)", 7: "offerCandidate: load words + duplicate compare", 8: "offerCandidate: slot copy + push",
+         6: "offerCandidate: stretch count + consensus length (r05b: sequence walk)", 7: "offerCandidate: rare full duplicate comparison (r05b: load words + compare)", 8: "offerCandidate: push (r05b: slot copy + push)",
          9: "replayRound: serial combinePair", 10: "replayRound: exact pair", 11: "F tree: root extensions", 12: "F tree: bucket membership scan (per 64 entries)",
          13: "F tree: bucket heap fill (per 64 entries)", 14: "F tree: pop (ipop + fields)", 15: "F tree: popped path's record (slab load)",
          16: "F tree: one successor stretch (iterator, slab load, extendPath)", 17: "R enum: pop (ipop + fields)", 18: "R enum: accepted-paths check",
          19: "R enum: root extensions", 20: "R enum: one predecessor stretch (iterator, linkOk, slab load, push)", 21: "R blocks: copy + sort + rank",
          22: "F tree finish", 23: "reachability prune", 24: "spillS", 25: "restoreS", 26: "pair-gen: classifyPair", 27: "restoreInstances", 28: "buildInstances",
-         29: "saveInstances", 30: "loadHand", 31: "buildInstances: generation", 32: "buildInstances: sort of the last k-mers", 33: "buildInstances: sort of the instances"}
+         29: "saveInstances", 30: "loadHand", 31: "buildInstances: generation", 32: "buildInstances: sort of the last k-mers", 33: "buildInstances: sort of the instances", 34: "materializeKept before restoreS"}
 npiles = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 cov = float(sys.argv[3]) if len(sys.argv) > 3 else 20.0
