@@ -2448,6 +2448,9 @@ struct FastEngine
 	// record area serve 64 pairs per round instead of 32: a window has 96 pairs on average, its lanes are the pairs; 0.24 % of the
 	// pairs have more than 10 matching intervals and are combined serially, a pair with more than 8 pops continues serially)
 	enum { PSIQ = 10, POUTE = 8 };
+	static constexpr id_t PSENT = static_cast<id_t>(~static_cast<id_t>(0));      // forward pop index no path has (8 bit ids: fewer than 255 pops per tree)
+	static_assert(sizeof(id_t) > 1 || 8u*FNW*FCH < 255u,"the end mark of a lane's interval heap must not be a forward pop index");
+	bool lscrdirty;      // lane 0: the lane scratch of the current round has been overwritten (an exact pair's enumerations, a serial combine)
 	DEV uint64_t psiW(PSI const & e, ChunkList<FNW> const & FC, uint32_t const sbase) const { return L.fp_adj()[clSlot<FCH>(FC,e.path)] + L.rc_w()[L.rc_ord()[sbase+e.current]]; }
 	DEV uint32_t combineLane(ChunkList<FNW> const & FC, uint32_t const nfpop, uint32_t const sbase, uint32_t const nacc2, uint64_t const rfm, int64_t const lmin, int64_t const lmax,
 		uint32_t const maxfullpath, LDSQ PSI * H, LDSQ id_t * out, bool const prune, uint64_t const T0)
@@ -2484,9 +2487,10 @@ struct FastEngine
 			PSI const top = H[0];
 			// the candidate heap was full with lightest weight T0 when the round began: as long as that still holds when
 			// the pair is offered, nothing from here on can enter (replayRound checks it and continues serially otherwise)
-			if ( prune && psiW(top,FC,sbase) <= T0 ) return cnt | 0x20;
+			// (round 5: a cut pair leaves its heap behind -- the entry behind the last one marked -- and is continued from it, continueLane)
+			if ( prune && psiW(top,FC,sbase) <= T0 ) { if ( n < PSIQ ) H[n].path = PSENT; return cnt | 0x20; }
 			// the record of a pair holds POUTE pops: the rest of this pair's sequence is produced serially at its place in the pair order
-			if ( cnt == POUTE ) return cnt | 0x10;
+			if ( cnt == POUTE ) { if ( n < PSIQ ) H[n].path = PSENT; return cnt | 0x10; }
 			// pop
 			{
 				--n; PSI const last = H[n]; H[0] = last;
@@ -2542,6 +2546,53 @@ struct FastEngine
 			SITE_RESET
 		}
 		return true;
+	}
+
+	// lane 0: a pair whose recorded sequence was cut (record full, or pruned at a weight that no longer prunes) goes on from the heap
+	// its lane left behind in the lane scratch -- the state combinePair would reach by building every interval again and popping `cnt`
+	// times (same heap mechanics: FiniteSizeHeap push / pop on the same weights).  Rounds 1-4 did exactly that: 43 k cycles per
+	// continued pair, 0.7 of them per window of config 2 (site 9 of the ledger).
+	DEV void continueLane(ChunkList<FNW> const & FC, uint32_t const sbase, LDSQ PSI * H, uint32_t const cnt, uint32_t pn)
+	{
+		uint32_t n = 0;
+		while ( n < PSIQ && H[n].path != PSENT ) ++n;
+		for ( uint32_t numfullpath = cnt; n && numfullpath < 16; ++numfullpath )
+		{
+			PSI const top = H[0];
+			uint64_t const wtop = psiW(top,FC,sbase);
+			if ( ncdh == 16 && wtop <= L.cdh()[0].w ) break;
+			{
+				--n; PSI const last = H[n]; H[0] = last;
+				uint32_t i = 0, r;
+				while ( (r = 2*i+2) < n )
+				{
+					uint32_t const m = psiW(H[r-1],FC,sbase) > psiW(H[r],FC,sbase) ? (r-1) : r;
+					PSI const em = H[m], ei = H[i];
+					if ( psiW(ei,FC,sbase) > psiW(em,FC,sbase) ) break;
+					H[i] = em; H[m] = ei; i = m;
+				}
+				if ( r >= n )
+				{
+					uint32_t const l = 2*i+1;
+					if ( l < n ) { PSI const el = H[l], ei = H[i]; if ( !(psiW(ei,FC,sbase) > psiW(el,FC,sbase)) ) { H[i] = el; H[l] = ei; } }
+				}
+			}
+			uint32_t bi;
+			if ( scoreNext(sbase,top.left,top.right,top.current,bi) )
+			{
+				PSI e = top; e.current = bi;
+				uint32_t i = n++; H[i] = e;
+				uint64_t const we = psiW(e,FC,sbase);
+				while ( i )
+				{
+					uint32_t const p = (i-1)>>1;
+					PSI const ep = H[p];
+					if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
+					else break;
+				}
+			}
+			if ( !offerCandidate(wtop,L.fp_id()[clSlot<FCH>(FC,top.path)],L.rc_ord()[sbase+top.current],pn) ) return;
+		}
 	}
 
 	// text: 8 byte aligned, readable up to the next multiple of 8 behind n (a row of consL).  The pattern masks and the
@@ -2834,16 +2885,18 @@ struct FastEngine
 					if ( used && ( (mode & 0x10) || ((mode & 0x20) && !(ncdh == 16 && L.cdh()[0].w >= roundT0)) ) )
 					{
 						pcount(21,1);
-						combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16,cnt,pn);
-						SITE(9)      // replayRound: serial continuation of a cut sequence (combinePair with skip)
+						if ( !lscrdirty ) continueLane(FC,L.rbase()[li],reinterpret_cast<LDSQ PSI *>(L.lscr()) + PSIQ*q,cnt,pn);
+						else combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16,cnt,pn);
+						SITE(9)      // replayRound: continuation of a cut sequence (from the lane's heap; combinePair with skip if the scratch is gone)
 					}
 				}
-				else { pcount(23,1); combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16); SITE(9) }
+				else { pcount(23,1); lscrdirty = true; combinePair(FC,L.fnp()[fi],L.rbase()[li],L.rn()[li],L.rfmask()[li],lmin,lmax,16); SITE(9) }
 				if ( flags ) return 0;
 				continue;
 			}
 			// exact stretch set of the pair (split at first, then at last)
 			pcount(22,1);
+			lscrdirty = true;      // (its enumerations and its serial combine use the lane scratch)
 			bool const rcached = mode & 1, fcached = mode & 2, same = mode & 4;
 			uint32_t const sf = L.parF()[fi], sl = L.parL()[li];
 			int32_t const firstnode = L.fnode()[fi] == 0xFFFF ? -1 : L.fnode()[fi];
@@ -3073,7 +3126,7 @@ struct FastEngine
 				while ( true )
 				{
 					uint32_t req = 0;
-					if ( lane == 0 ) req = replayRound(q,nround,p0,fstart,lmin,lmax,nb == 1,live);
+					if ( lane == 0 ) { lscrdirty = false; req = replayRound(q,nround,p0,fstart,lmin,lmax,nb == 1,live); }
 					wv_sync();
 					flags = wv_bcast(flags,0); if ( flags ) return false;
 					req = wv_bcast(req,0);
