@@ -672,17 +672,15 @@ struct FastEngine
 		PROFX_T0
 		// k-mer instances of all strings at once, lane = instance.  String j (lane j%64 of round j/64) has nk k-mers, its first
 		// output slot is the exclusive prefix sum off, and among the strings with k-mers it is number rk.  (Round 5: an instance finds
-		// its string in two LDS round trips in the tiers of deep piles -- a byte per output slot marks where a string begins, so the number of marks up to
+		// its string in two LDS round trips -- a byte per output slot marks where a string begins, so the number of marks up to
 		// slot t, counted with a ballot per 64 slots, names the string of slot t in a compact list (string, first slot).  Rounds 1-4
 		// compared t against the offsets of all strings, broadcast one by one: 64 x strings scalar steps per 64 instances, 3 % of a
 		// window of config 2 and a quarter of one at 54x, profiles/r05c_sites_*.log.)
 		enum { NCH = (CT::maxs+WSZ-1)/WSZ };
-#if defined(DACC_GEN_MARKS_ALL)
-		enum : bool { GENMARKS = true };
-#elif defined(DACC_GEN_MARKS_NONE)
-		enum : bool { GENMARKS = false };
+#if defined(DACC_GEN_MARKS_NONE)
+		enum : bool { GENMARKS = false };      // (A/B builds: the broadcast loop of rounds 1-4)
 #else
-		enum : bool { GENMARKS = (CT::maxs > 40) };      // the tiers of deep piles (96 strings)
+		enum : bool { GENMARKS = true };
 #endif
 		static_assert(4u*CT::maxs <= CT::precap && CT::maxs <= 256 && CT::precap <= (1u<<24),"compact string list: string | first slot << 8, in the bytes of irpos");
 		LDSQ uint8_t * const marks = L.ipos();                                             // free until buildNodes writes the positions
@@ -726,9 +724,9 @@ struct FastEngine
 			}
 			else
 			{
-				// shallow tiers: t against the offsets of all strings, broadcast one by one (pure VALU / scalar work, which the other
-				// wavefront of the SIMD hides; the two dependent LDS round trips of the marks measured 2.6 % SLOWER on config 2,
-				// profiles/r05d_ab_generation.log)
+				// rounds 1-4: t against the offsets of all strings, broadcast one by one (kept for A/B builds; the first measurement of
+				// the marks on the shallow tiers, profiles/r05d_ab_generation.log, was 2.6 % slower only because that build also capped
+				// the registers with amdgpu_waves_per_eu -- without the cap the marks are 1.9 % faster there, profiles/r05n_*)
 				#pragma unroll
 				for ( int c = 0; c < NCH; ++c )
 					for ( uint32_t jj = 0; jj < WSZ && c*WSZ + jj < mao; ++jj )
