@@ -1502,7 +1502,15 @@ struct FastEngine
 					uint32_t const pp = P+j;
 					uint32_t const pc = pp < nrows ? pp : nrows;
 					uint64_t U = tabR(ip_a*stride + pc);
-					for ( uint32_t q = 1; q < f_a; ++q ) U += tabR(static_cast<uint32_t>(IP[i0_a+q])*stride + pc);
+					// (round 5) the other instances of the node four at a time: their position bytes, then their table words, are in
+					// flight together -- one instance per step was two dependent round trips (LDS byte, table word in L1 / L2) each
+					for ( uint32_t q = 1; q < f_a; q += 4 )
+					{
+						uint32_t const m = f_a - q;
+						uint32_t const b0 = IP[i0_a+q], b1 = IP[i0_a+q+(m > 1 ? 1u : 0u)], b2 = IP[i0_a+q+(m > 2 ? 2u : 0u)], b3 = IP[i0_a+q+(m > 3 ? 3u : 0u)];
+						uint32_t const t0 = tabR(b0*stride + pc), t1 = tabR(b1*stride + pc), t2 = tabR(b2*stride + pc), t3 = tabR(b3*stride + pc);
+						U += t0; U += m > 1 ? t1 : 0u; U += m > 2 ? t2 : 0u; U += m > 3 ? t3 : 0u;
+					}
 					if ( U < FW_THRES_FEAS ) { ok = false; FEAS_ITERS(t,len,j+1) break; }
 					sum += U;
 					if ( j == 0 ) f1 = U;
