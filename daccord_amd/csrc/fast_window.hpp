@@ -2020,6 +2020,65 @@ struct FastEngine
 		}
 		else arpIns(first,last,lk);
 	}
+	// The same sort on (id, key) pairs: key = front k-mer << 8 | base length, so that key order is arpLess order and a comparison is two
+	// independent loads instead of two chains of four (path -> stretch -> first node -> k-mer).  Same comparisons with the same
+	// outcomes in the same order, hence the same permutation.  I / K: ids and keys of the block, indexed from its start.
+	DEV static void arpSwapK(LDSQ id_t * I, LDSQ uint64_t * K, int32_t const a, int32_t const b) { id_t const t = I[a]; I[a] = I[b]; I[b] = t; uint64_t const u = K[a]; K[a] = K[b]; K[b] = u; }
+	DEV static void arpULIK(LDSQ id_t * I, LDSQ uint64_t * K, int32_t last) { id_t const vi = I[last]; uint64_t const vk = K[last]; int32_t next = last-1; while ( vk < K[next] ) { I[last] = I[next]; K[last] = K[next]; last = next; --next; } I[last] = vi; K[last] = vk; }
+	DEV static void arpInsK(LDSQ id_t * I, LDSQ uint64_t * K, int32_t const first, int32_t const last)
+	{
+		if ( first == last ) return;
+		for ( int32_t i = first+1; i != last; ++i )
+		{
+			if ( K[i] < K[first] ) { id_t const vi = I[i]; uint64_t const vk = K[i]; for ( int32_t q = i; q != first; --q ) { I[q] = I[q-1]; K[q] = K[q-1]; } I[first] = vi; K[first] = vk; }
+			else arpULIK(I,K,i);
+		}
+	}
+	DEV void arpSortK(LDSQ id_t * I, LDSQ uint64_t * K, int32_t const n)
+	{
+		if ( n == 0 ) return;
+		if ( n > 16 )
+		{
+			int depth = 0; { int32_t t = n; while ( t > 1 ) { t >>= 1; ++depth; } depth *= 2; }
+			LDSQ uint16_t * stF = L.sstack(); LDSQ uint16_t * stL = stF+24; LDSQ uint16_t * stD = stF+48; int sp = 0;
+			stF[0] = 0; stL[0] = n; stD[0] = depth; sp = 1;
+			while ( sp )
+			{
+				--sp;
+				int32_t f = stF[sp], l = stL[sp]; int d = stD[sp];
+				while ( l-f > 16 )
+				{
+					if ( d == 0 ) { over(1024); return; }
+					--d;
+					int32_t const mid = f + (l-f)/2, a = f+1, b = mid, c = l-1;
+					if ( K[a] < K[b] )
+					{
+						if ( K[b] < K[c] ) arpSwapK(I,K,f,b);
+						else if ( K[a] < K[c] ) arpSwapK(I,K,f,c);
+						else arpSwapK(I,K,f,a);
+					}
+					else if ( K[a] < K[c] ) arpSwapK(I,K,f,a);
+					else if ( K[b] < K[c] ) arpSwapK(I,K,f,c);
+					else arpSwapK(I,K,f,b);
+					int32_t lo = f+1, hi = l;
+					while ( true )
+					{
+						while ( K[lo] < K[f] ) ++lo;
+						--hi;
+						while ( K[f] < K[hi] ) --hi;
+						if ( !(lo < hi) ) break;
+						arpSwapK(I,K,lo,hi);
+						++lo;
+					}
+					if ( sp < 24 ) { stF[sp] = lo; stL[sp] = l; stD[sp] = d; ++sp; } else { over(1024); return; }
+					l = lo;
+				}
+			}
+			arpInsK(I,K,0,16);
+			for ( int32_t i = 16; i != n; ++i ) arpULIK(I,K,i);
+		}
+		else arpInsK(I,K,0,n);
+	}
 	// copy the accepted list to its block (acceptance order)
 	DEV void reverseBlockCopy(REnum const & R, uint32_t const sbase)
 	{
@@ -2038,8 +2097,15 @@ struct FastEngine
 		LDSQ uint64_t * const WT = L.f_w() + sbase;
 		uint64_t rmaxw = 0, rfm = 0;
 		for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const w = W[L.rc_ord()[sbase+i]]; rmaxw = w > rmaxw ? w : rmaxw; }
-		arpSort(L.rc_ord()+sbase,L.rc_ord()+sbase+narp,R.lastk);
-		if constexpr ( TMP ) for ( uint32_t i = 0; i < narp; ++i ) WT[i] = W[L.rc_ord()[sbase+i]];
+		if constexpr ( TMP )
+		{
+			// keys of the block in acceptance order, then the sort on (id, key); WT holds the keys until the ranks need it for the weights
+			for ( uint32_t i = 0; i < narp; ++i ) { uint32_t const rp = L.rc_ord()[sbase+i]; WT[i] = (static_cast<uint64_t>(rpFront(rp,R.lastk)) << 8) | L.rc_baselen()[rp]; }
+			arpSortK(L.rc_ord()+sbase,WT,static_cast<int32_t>(narp));
+			for ( uint32_t i = 0; i < narp; ++i ) { uint64_t const key = WT[i]; L.rc_front()[sbase+i] = static_cast<uint32_t>(key >> 8); L.rc_sbl()[sbase+i] = static_cast<uint8_t>(key & 0xFF); }
+			for ( uint32_t i = 0; i < narp; ++i ) WT[i] = W[L.rc_ord()[sbase+i]];
+		}
+		else arpSort(L.rc_ord()+sbase,L.rc_ord()+sbase+narp,R.lastk);
 		// rank of every entry by (weight, sorted position); one bit per scan target (node id mod 64) of the enumeration
 		uint64_t tm = lastnode >= 0 ? (1ull << (lastnode & 63)) : 0ull;
 		for ( uint32_t i = 0; i < narp; ++i )
@@ -2065,8 +2131,9 @@ struct FastEngine
 				if ( wj < wi || (wj == wi && j < i) ) ++r;
 			}
 			L.rc_arw()[sbase+i] = r;
-			uint32_t const fr = rpFront(rp,R.lastk);
-			L.rc_front()[sbase+i] = fr; L.rc_sbl()[sbase+i] = L.rc_baselen()[rp];
+			uint32_t fr;
+			if constexpr ( TMP ) fr = L.rc_front()[sbase+i];      // (written from the sort keys above)
+			else { fr = rpFront(rp,R.lastk); L.rc_front()[sbase+i] = fr; L.rc_sbl()[sbase+i] = L.rc_baselen()[rp]; }
 			rfm |= 1ull << (fr & 63);
 			if ( L.rc_len()[rp] && static_cast<int64_t>(L.rc_baselen()[rp]) < (lmax+1)/2 ) tm |= 1ull << (L.sfirst()[L.rc_stretch()[rp]] & 63);
 		}
