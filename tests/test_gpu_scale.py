@@ -63,3 +63,30 @@ def test_scale_case_matches_oracle_digests(name):
         E.rerun(); f2, b2 = E.collect()
         assert hashlib.sha256(engine.fasta(f2, b2).encode()).hexdigest() == run["fasta_sha256"], ("second pass", run["params"])
         E.close()
+
+
+def test_rest_of_headline_batch_matches_oracle_digests():
+    """Round 5: the piles of BASELINE config 2 outside the five strata above, in the parts the oracle digested in the build container
+    (tests/golden/scale_cfg2wNN.json, tests/scale_cases.py::_complement_cases): with them every pile of the batch bench.py times is compared."""
+    from scale_cases import CFG2W
+    have = [n for n in CFG2W if os.path.exists(os.path.join(HERE, "golden", "scale_%s.json" % n))]
+    if not have:
+        pytest.skip("no cfg2w fixture")
+    d, ovl, piles, _ = make_case(CASES[have[0]], engine.pile_select)
+    p = default_params(k=14)
+    E = engine.Engine(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+    npiles = 0
+    for name in have:
+        G = _golden(name); case = CASES[name]
+        assert G["spec"]["pile_ranges"] == json.loads(json.dumps(case["pile_ranges"]))
+        sel = np.concatenate([piles[a:b] for a, b in case["pile_ranges"]])
+        run = G["runs"][0]
+        fx, bx = E(sel, ovl, d.trace)
+        pd = pile_digests(fx, bx, sel, engine.fasta)
+        badp = [i for i, (a, b) in enumerate(zip(pd, run["pile_sha256"])) if a != b]
+        assert badp == [], (name, "piles whose FASTA differs from the oracle's", len(badp), badp[:10])
+        assert len(bx) == run["nbases"] and len(fx) == run["nfragments"]
+        assert hashlib.sha256(engine.fasta(fx, bx).encode()).hexdigest() == run["fasta_sha256"], name
+        npiles += len(sel)
+    print("%d parts, %d piles of the headline batch equal to the oracle" % (len(have), npiles))
+    E.close()
