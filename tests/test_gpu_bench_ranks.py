@@ -14,9 +14,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, reads, scaling):
+def _run(n, reads, scaling, extra=()):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    common = ["--reads", str(reads), "--readlen", "5000", "--steps", "1", "--warmup", "0", "--no-cpu", "--scaling", scaling]
+    common = ["--reads", str(reads), "--readlen", "5000", "--steps", "1", "--warmup", "0", "--no-cpu", "--scaling", scaling] + list(extra)
     env = dict(os.environ, DACC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if n == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + common
@@ -46,7 +46,11 @@ def test_eight_ranks_on_one_device_weak():
     eight ranks, -J g,8 sharding of one data set, gather in rank order, rank 0's digests and accuracy block; equals the N = 1 run over
     the same 8 x 40 reads and reports which gather ran and how long rank 0 worked behind the timed loop"""
     one = _run(1, 320, "weak")
-    eight = _run(8, 40, "weak")
+    eight = _run(8, 40, "weak", extra=["--live-parity", "4"])
+    # round 5: a line the committed digests do not cover compares a sample of rank 0's own shard with the oracle and the reference build
+    live = eight["parity"]["live"]
+    assert live["identical"] is True and live["oracle"]["identical"] is True and live["oracle"]["piles"] == 4, live
+    assert live["reference_build"].get("identical", True) is True, live
     assert eight["n_gpus"] == 8 and eight["ranks"] == 8 and eight["gather"] == "p2p" and one["gather"] is None
     assert eight["parity"]["gpu_fasta_sha256_all"] == one["parity"]["gpu_fasta_sha256_all"]
     assert eight["config"]["corrected_bases_total"] == one["config"]["corrected_bases_total"] and eight["config"]["piles_rank0"] == 40
