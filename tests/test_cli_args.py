@@ -98,3 +98,28 @@ def test_reference_binary_profile_is_written_and_read(files, tmp_path):
     assert cli.run(["--eprofonly", "-E" + bad, "--keepeprof", las, db]).returncode != 0
     open(bad, "wb").write(raw[:40])
     assert cli.run(["--eprofonly", "-E" + bad, "--keepeprof", las, db]).returncode != 0
+
+
+def test_loaderonly_measures_the_host_side_without_a_device(files):
+    """--loaderonly (round 5): loader thread + planner threads, no HIP context; reports piles, windows and rates on stderr and writes no FASTA.
+    The window count is the planner's (dacc_plan_only) = what dacc_submit_piles would schedule: one window per step of -a over every A read
+    (HandleContext.hpp:390-408) up to the pile's largest aepos, here checked against the closed form."""
+    d, las, db = files
+    r = cli.run(["--eprof0.12,0.02,0.85", "-k10", "--loaderonly", "--gpus3", "--batch25", las, db])
+    assert r.returncode == 0 and r.stdout == b"", r.stderr.decode()
+    err = r.stderr.decode()
+    m = re.search(r"\[L\] host side only: (\d+) piles \((\d+) selected overlaps, (\d+) A-read bases, (\d+) windows\) in (\d+) batches of 25 A reads", err)
+    assert m, err
+    npiles, novl, abases, nwin, nbat = (int(x) for x in m.groups())
+    areads = np.unique(d.ovl["aread"])
+    assert npiles == len(areads) and abases == int(d.rlen[areads].sum()) and nbat >= npiles // 25
+    w, a = 40, 10
+
+    def windows_n(l):      # Windows::computeN (HandleContext.hpp:390-408) over [0, l), l = the largest aepos of the pile (HandleContext.hpp:1760-1778)
+        npre = (l + a - w) // a if l + a >= w else 0
+        if npre:
+            return npre if (npre - 1) * a + w == l else npre + 1
+        return 1 if l >= w else 0
+    expect = sum(windows_n(int(d.ovl["aepos"][d.ovl["aread"] == r].max())) for r in areads)
+    assert nwin == expect, (nwin, expect)
+    assert "[L] loader thread:" in err and "3 planner thread(s)" in err
