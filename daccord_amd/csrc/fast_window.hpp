@@ -2572,8 +2572,14 @@ struct FastEngine
 			}
 		}
 		FSTAT_ADD(25,1); FSTAT_ADD(26,n > 8 ? 1u : 0u); FSTAT_ADD(27,n > 10 ? 1u : 0u); FSTAT_ADD(28,n > 12 ? 1u : 0u); FSTAT_ADD(29,n > 16 ? 1u : 0u); FSTAT_MX(30,n);
-		uint32_t cnt = 0;
 		SITE(1)      // combineLane: the intervals of the pair (one scoreInterval per forward pop) and their heap
+		return combineLanePops(FC,sbase,n,maxfullpath,H,out,prune,T0);
+	}
+	// the pops of the lane form on a heap of n intervals (second half of combineLane)
+	DEV uint32_t combineLanePops(ChunkList<FNW> const & FC, uint32_t const sbase, uint32_t n, uint32_t const maxfullpath, LDSQ PSI * H, LDSQ id_t * out, bool const prune, uint64_t const T0)
+	{
+		SITE_T0
+		uint32_t cnt = 0;
 		for ( uint32_t numfullpath = 0; n && numfullpath < maxfullpath; ++numfullpath )
 		{
 			PSI const top = H[0];
@@ -2618,6 +2624,61 @@ struct FastEngine
 			SITE(2)      // combineLane: one pop (sift down, next lighter entry, push, record)
 		}
 		return cnt;
+	}
+	// Round 5: the interval construction of a round of pairs as a flat task list.  The lane form above walks a pair's forward pops and runs
+	// scoreInterval for every pop whose junction k-mer (mod 64) the reverse block knows -- 64 lanes with different trees, different match
+	// patterns and data dependent scan lengths, so the wavefront pays, iteration by iteration, for its slowest lane (site 1 of the ledger:
+	// 6 % of a window).  Here a pair only LISTS its matching pops (matchPops: two loads per pop), the (pair, pop) matches of the whole
+	// round become tasks dealt 64 at a time to the lanes (intervalTask: every lane runs one scoreInterval), and the pair then pushes its
+	// valid intervals in pop order (heapOfList) -- the same pushes in the same order as before, hence the same heap.  A pair with more
+	// than PSIQ matches, or a round with more tasks than the task list holds, takes the lane form as before.
+	DEV uint32_t matchPops(ChunkList<FNW> const & FC, uint32_t const nfpop, uint64_t const rfm, LDSQ PSI * H) const
+	{
+		uint32_t nm = 0;
+		for ( uint32_t pi = 0; pi < nfpop; ++pi )
+		{
+			uint32_t const front = L.fp_front()[clSlot<FCH>(FC,pi)];
+			if ( !((rfm >> (front & 63)) & 1) ) continue;
+			if ( nm < PSIQ ) H[nm].path = static_cast<id_t>(pi);
+			++nm;
+		}
+		return nm;
+	}
+	// one (pair, matching pop) task: the pop's interval in the pair's reverse block, written over the list entry; false: the interval does
+	// not fit an 8 bit id (the pair is combined serially, as in the lane form)
+	DEV bool intervalTask(ChunkList<FNW> const & FC, uint32_t const sbase, uint32_t const nacc2, int64_t const lmin, int64_t const lmax, LDSQ PSI * e) const
+	{
+		uint32_t const pi = e->path;
+		uint32_t const o = clSlot<FCH>(FC,pi);
+		uint32_t sub, sup, mi;
+		if ( scoreInterval(sbase,nacc2,L.fp_front()[o],static_cast<int64_t>(L.fp_cl()[o]) + k,lmin,lmax,sub,sup,mi) )
+		{
+			if ( sup > 255 && sizeof(id_t) == 1 ) return false;
+			PSI v; v.path = static_cast<id_t>(pi); v.current = static_cast<id_t>(mi); v.left = static_cast<id_t>(sub); v.right = static_cast<id_t>(sup);
+			*e = v;
+		}
+		else e->path = PSENT;
+		return true;
+	}
+	// the valid entries of a pair's list, pushed in list (= pop) order: FiniteSizeHeap pushes as in combineLane; returns the heap's size
+	DEV uint32_t heapOfList(ChunkList<FNW> const & FC, uint32_t const sbase, LDSQ PSI * H, uint32_t const nm) const
+	{
+		uint32_t n = 0;
+		for ( uint32_t j = 0; j < nm; ++j )
+		{
+			PSI const e = H[j];
+			if ( e.path == PSENT ) continue;
+			uint32_t i = n++; H[i] = e;
+			uint64_t const we = psiW(e,FC,sbase);
+			while ( i )
+			{
+				uint32_t const p = (i-1)>>1;
+				PSI const ep = H[p];
+				if ( we > psiW(ep,FC,sbase) ) { H[i] = ep; H[p] = e; i = p; }
+				else break;
+			}
+		}
+		return n;
 	}
 	// offers the recorded sequence of a pair to the candidate heap, exactly as combinePair would have
 	// returns true if the sequence was used up (false: ended at an entry that cannot enter the full heap, or error)
@@ -2895,7 +2956,7 @@ struct FastEngine
 	// pair into recorded (path, entry) sequences, and lane 0 offers those to the candidate heap in the reference's pair
 	// order.  A pair whose cached enumerations may be touched by the other k-mer's split (rare) is enumerated on its
 	// exact stretch set by lane 0 at its place in that order.
-	enum { NPL = 64, RPSTL = 32, PM_SKIP = 0xF0, PM_SERIAL = 0xF1, PM_EXACT = 0xE0 };
+	enum { NPL = 64, RPSTL = 32, PM_SKIP = 0xF0, PM_SERIAL = 0xF1, PM_EXACT = 0xE0, PM_PEND = 0x80 };      // (PM_PEND | matches: between the phases of a round only)
 	static_assert(sizeof(PSI)*PSIQ*NPL <= FastLds<CT>::lscrbytes && 2u*POUTE*NPL <= 32u*32u,"score interval heaps and pop records of a round of pairs");
 	enum : uint32_t { MIDCAP = 8 };
 	uint32_t nmid, midbase;              // middle pieces of this activation state: pool ids midbase .. midbase+nmid-1
@@ -3190,24 +3251,86 @@ struct FastEngine
 				roundT0 = cfull ? L.cdh()[0].w : 0ull;
 				uint64_t live = 0;
 				static_assert(NPL <= 64,"one bit per pair of a round");
+				// phase A: classification; a pair that combines cached enumerations lists its matching pops (mode PM_PEND | number of matches)
+				LDSQ PSI * const HH = reinterpret_cast<LDSQ PSI *>(L.lscr());
+				uint32_t ntask = 0;
+				for ( uint32_t t0 = 0; t0 < nround; t0 += WSZ )
+				{
+					uint32_t const t = t0 + lane;
+					uint32_t mode = PM_SKIP;
+					if ( t < nround )
+					{
+						uint32_t const p = p0 + t;
+						uint32_t const pfi = fstart + p/nL, pli = p%nL;
+						SITE_T0
+						uint32_t const cl = classifyPair(pfi,pli,lmax);
+						SITE(26)      // pair generation: classification of a pair (cached enumerations valid?)
+						if ( cl != 3 ) mode = PM_EXACT | cl;
+						else if ( (L.rfmask()[pli] & L.ffm()[pfi]) == 0 ) mode = PM_SKIP;     // the forward tree and the reverse block share no junction k-mer
+						else
+						{
+							ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
+							uint32_t const nm = matchPops(FC,L.fnp()[pfi],L.rfmask()[pli],HH + PSIQ*t);
+							if ( nm == 0 ) mode = PM_SKIP;
+							else mode = PM_PEND | (nm <= PSIQ ? nm : 15u);      // 15: more matches than the list holds -- the lane form, in phase B (its records share the task list's bytes)
+						}
+						L.poutn()[t] = mode;
+					}
+					uint32_t tot; wv_scan_excl(((mode & 0xF0u) == PM_PEND && (mode & 0x0Fu) != 15u) ? (mode & 0x0Fu) : 0u,tot);
+					ntask += tot;
+				}
+				wv_sync();
+				// the task list borrows the pairs' record area (written in phase B): 16 bit entries pair | match << 6
+				LDSQ uint16_t * const TL = reinterpret_cast<LDSQ uint16_t *>(L.pout());
+				enum : uint32_t { TLCAP = 32u*32u*static_cast<uint32_t>(sizeof(id_t))/2u };
+				bool const flat = ntask != 0 && ntask <= TLCAP;
+				if ( flat )
+				{
+					uint32_t tb = 0;
+					for ( uint32_t t0 = 0; t0 < nround; t0 += WSZ )
+					{
+						uint32_t const t = t0 + lane;
+						uint32_t const mode = t < nround ? L.poutn()[t] : static_cast<uint32_t>(PM_SKIP);
+						uint32_t const nm = ((mode & 0xF0u) == PM_PEND && (mode & 0x0Fu) != 15u) ? (mode & 0x0Fu) : 0u;
+						uint32_t tot; uint32_t const pre = tb + wv_scan_excl(nm,tot);
+						for ( uint32_t j = 0; j < nm; ++j ) TL[pre+j] = static_cast<uint16_t>(t | (j << 6));
+						tb += tot;
+					}
+					wv_sync();
+					// phase T: one scoreInterval per lane and step
+					for ( uint32_t q0 = 0; q0 < ntask; q0 += WSZ )
+					{
+						uint32_t const q = q0 + lane;
+						if ( q < ntask )
+						{
+							uint32_t const en = TL[q], t = en & 63u, j = en >> 6;
+							uint32_t const p = p0 + t;
+							uint32_t const pfi = fstart + p/nL, pli = p%nL;
+							ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
+							if ( !intervalTask(FC,L.rbase()[pli],L.rn()[pli],lmin,lmax,HH + PSIQ*t + j) ) L.poutn()[t] = PM_SERIAL;
+						}
+					}
+					wv_sync();
+				}
+				// phase B: heap of the valid intervals and the pops of the lane form (pairs still pending; without the task list: the lane form)
 				for ( uint32_t t = lane; t < nround; t += WSZ )
 				{
-					uint32_t const p = p0 + t;
-					uint32_t const pfi = fstart + p/nL, pli = p%nL;
-					SITE_T0
-					uint32_t const cl = classifyPair(pfi,pli,lmax);
-					SITE(26)      // pair generation: classification of a pair (cached enumerations valid?)
-					uint32_t mode;
-					if ( cl != 3 ) mode = PM_EXACT | cl;
-					else if ( (L.rfmask()[pli] & L.ffm()[pfi]) == 0 ) mode = PM_SKIP;     // the forward tree and the reverse block share no junction k-mer
-					else
+					uint32_t mode = L.poutn()[t];
+					if ( (mode & 0xF0u) == PM_PEND )
 					{
+						uint32_t const p = p0 + t;
+						uint32_t const pfi = fstart + p/nL, pli = p%nL;
 						ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
-						uint32_t const cnt = combineLane(FC,L.fnp()[pfi],L.rbase()[pli],L.rn()[pli],L.rfmask()[pli],lmin,lmax,16,
-							reinterpret_cast<LDSQ PSI *>(L.lscr()) + PSIQ*t,L.pout() + 2*POUTE*t,cfull,roundT0);
+						uint32_t cnt;
+						if ( flat && (mode & 0x0Fu) != 15u )
+						{
+							uint32_t const n = heapOfList(FC,L.rbase()[pli],HH + PSIQ*t,mode & 0x0Fu);
+							cnt = combineLanePops(FC,L.rbase()[pli],n,16,HH + PSIQ*t,L.pout() + 2*POUTE*t,cfull,roundT0);
+						}
+						else cnt = combineLane(FC,L.fnp()[pfi],L.rbase()[pli],L.rn()[pli],L.rfmask()[pli],lmin,lmax,16,HH + PSIQ*t,L.pout() + 2*POUTE*t,cfull,roundT0);
 						mode = cnt == 0xFF ? static_cast<uint32_t>(PM_SERIAL) : (cnt ? cnt : static_cast<uint32_t>(PM_SKIP));
+						L.poutn()[t] = mode;
 					}
-					L.poutn()[t] = mode;
 					if ( mode != PM_SKIP ) live |= 1ull << t;
 				}
 				live = wv_or64(live);
