@@ -73,39 +73,39 @@ template<int TIER> struct FastTier;
 // while the enumerations run): layout FastLds<CT,true>.  Round 3 measured that a second wavefront per SIMD hides the LDS
 // round trips of the first almost completely (profiles/r03a_occupancy_experiment.md), so LDS bytes per window decide the
 // throughput: tier 1 is 26.3 KB = 6 wavefronts per CU with (almost) the capacities it had at 53.8 KB = 3 per CU.
-template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
-template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 640, ncap = 416, scap = 88, lcap = 512, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96 }; };
-enum : uint32_t { T0INST_DEFAULT = 488 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
+template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 512, ncap = 476, scap = 88, lcap = 512, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+enum : uint32_t { T0INST_DEFAULT = 500 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 // (round 4: 76 KB = 2 wavefronts per CU instead of 46.5 KB = 3, with tier 3's node capacity: at 54x more than half of what the deep tier
 // hands on has more than 1024 nodes at filter frequency 1 and used to go through this tier only to be handed on again to tier 3, which
 // runs one wavefront per CU)
-template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 2048, scap = 232, lcap = 2304, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 2048, scap = 232, lcap = 2304, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 // tier 6 (second slot of SHALLOW batches since round 3, gw layout, 36 KB = 4 wavefronts per CU): what tier 1 hands on at 20x
 // are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
 // tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep
 // tier 2 (64 strings, 2048 instances) behind the deep tier.
-template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 900, scap = 192, lcap = 1024, wcap = 1536, rccap = 192, fcap = 256, siqcap = 96, blcap = 96 }; };
+template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 900, scap = 192, lcap = 1024, wcap = 1536, rccap = 192, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
 // gw layout and 16 bit STRETCH ids since round 3: what the legacy tier 3 handed to the generic engine at 54x were windows with
 // more than 250 stretches (13 of 19 per 60 000 windows) or more than 2112 feasible weights (5 of 19), and each of them cost the
 // generic engine seconds (685 such windows were 92 % of a 2000-pile 54x batch, profiles/r03c_bench_54x_2000piles.log)
-template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
 // small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
 // has about a hundred nodes, while the 55 strings of a window carry 1500 k-mer instances.
-template<> struct FastTier<4> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 608, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96 }; };
+template<> struct FastTier<4> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 608, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 // tier 5 (one wavefront per CU, only for the windows the pre-scan found): B strings of up to 128 bases (string stride 128,
 // two words per pattern mask); everything else as tier 3 with 64 strings.  Window strings of more than 64 bases are rare
 // at the default window (a few per ten million windows of config 2) but each of them costs the generic engine seconds.
-template<> struct FastTier<5> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128 }; };
+template<> struct FastTier<5> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -207,15 +207,15 @@ struct FastLds<CT,false>
 	FLD(bestL,uint8_t,MAXCONS,e_pieL)      // best consensus so far (survives the tries)
 	FLD(cdh,FCC,16,e_bestL)
 	static_assert(uA <= o_cdh,"the model table copy (from o_cdh on) is loaded for gap filling while the instance array is live");
-	FLD(cseq,uint8_t,18*FSEQCAP,e_cdh)      // stretch sequences of the kept candidates (16 slots) + current + previous
+	FLD(cseq,uint8_t,18*CT::seqcap,e_cdh)      // stretch sequences of the kept candidates (16 slots) + current + previous
 	// dead until the kept candidates are decoded: shared with the lane scratch of the enumerations (lscr: per lane a
 	// heap of 32 path ids / of 12 path ids / of PSIQ score intervals; all of it for an enumeration on lane 0 alone)
 	FLD(ch,FCC,16,e_cseq)
 	FLD(acc,FCC,16,e_ch)
 	FLD(accerr,uint32_t,16,e_acc)
 	FLD(canderr,uint8_t,16*CT::maxs,e_accerr)
-	FLD(consL,uint8_t,16*MAXCONS,e_canderr)   // decoded candidates
-	static constexpr uint32_t lscrbytes = 2560u*static_cast<uint32_t>(sizeof(typename CT::id_t));
+	FLD(consL,uint8_t,16*CT::consrow,e_canderr)   // decoded candidates
+	static constexpr uint32_t lscrbytes = static_cast<uint32_t>(CT::lscrids)*static_cast<uint32_t>(sizeof(typename CT::id_t));
 	FLD(lscr,uint8_t,lscrbytes,e_cseq)
 	FLD(siq,FSI,CT::siqcap,e_cseq)          // score intervals of a pair combined on lane 0
 	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
@@ -438,13 +438,13 @@ struct FastLds<CT,true>
 	FLD(pieL,sid_t,CT::fnc,e_pieF)
 	static constexpr uint32_t xbase = (e_pieL + 15u) & ~15u;
 	FLD(cdh,FCC,16,xbase)
-	FLD(cseq,sid_t,18*FSEQCAP,e_cdh)
+	FLD(cseq,sid_t,18*CT::seqcap,e_cdh)
 	FLD(ch,FCC,16,e_cseq)
 	FLD(acc,FCC,16,e_ch)
 	FLD(accerr,uint32_t,16,e_acc)
 	FLD(canderr,uint8_t,16*CT::maxs,e_accerr)
-	FLD(consL,uint8_t,16*MAXCONS,e_canderr)
-	static constexpr uint32_t lscrbytes = 2560u*static_cast<uint32_t>(sizeof(typename CT::id_t));
+	FLD(consL,uint8_t,16*CT::consrow,e_canderr)
+	static constexpr uint32_t lscrbytes = static_cast<uint32_t>(CT::lscrids)*static_cast<uint32_t>(sizeof(typename CT::id_t));
 	FLD(lscr,uint8_t,lscrbytes,e_cseq)
 	FLD(siq,FSI,CT::siqcap,e_cseq)
 	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
@@ -2315,6 +2315,9 @@ struct FastEngine
 	}
 
 	// ================= combining a forward tree with a reverse block (score intervals) =================
+	// capacities of this tier that rounds 1-4 had as globals (tier 0 trades them for nodes, round 5): stretches of a candidate, bytes of a decoded candidate's row
+	enum : uint32_t { FSEQCAP = CT::seqcap, CONSROW = CT::consrow };
+	static_assert(CONSROW <= MAXCONS && (CONSROW & 7u) == 0,"rows of the decoded candidates: read as 64 bit words");
 	uint32_t cfree;   // free candidate sequence slots
 	// A candidate is kept as its sequence of view stretches (forward chain, then reverse chain).  Within one view two
 	// candidates spell the same string iff their sequences are equal (nodes are distinct k-mers and every edge lies on
@@ -2325,7 +2328,7 @@ struct FastEngine
 		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[rp];
 		if ( nf + nr > FSEQCAP ) { over(4096); return ~0u; }
 		conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[rp];
-		if ( conslen > MAXCONS ) { over(4096); return ~0u; }
+		if ( conslen > CONSROW ) { over(4096); return ~0u; }
 		// the two parent chains are walked in one loop, so that their dependent loads are in flight together (rc_len drops
 		// by one per step and is zero at the root: the reverse chain has nr steps)
 		uint32_t qf = path, qr = rp;
@@ -2426,7 +2429,7 @@ struct FastEngine
 		if ( ncdh == 16 ) { uint32_t const to = L.cdh()[0].o, tl = L.cdh()[0].l; if ( !(tl & UNMAT) ) cfree |= 1u << to; spop<FCC,true>(L.cdh(),ncdh); SITE(5) }   // weight > top here
 		uint32_t const nf = L.f_len()[path], nr = L.rc_len()[rp];
 		uint32_t const conslen = static_cast<uint32_t>(L.f_pos()[path]) + k + L.rc_pos()[rp];
-		if ( nf + nr > FSEQCAP || conslen > MAXCONS ) { over(4096); return false; }      // (the checks of buildSeq, in its order)
+		if ( nf + nr > FSEQCAP || conslen > CONSROW ) { over(4096); return false; }      // (the checks of buildSeq, in its order)
 		uint32_t const n = nf+nr;
 		SITE(6)      // offerCandidate: stretch count and consensus length of the candidate
 		// Within a pair both candidates come from one forward tree and one reverse enumeration, whose pool entries are the nodes of
@@ -2539,7 +2542,7 @@ struct FastEngine
 	// (round 4: 10 intervals per lane and 8 recorded pops per pair instead of 20 / 16, so that the same lane scratch and the same
 	// record area serve 64 pairs per round instead of 32: a window has 96 pairs on average, its lanes are the pairs; 0.24 % of the
 	// pairs have more than 10 matching intervals and are combined serially, a pair with more than 8 pops continues serially)
-	enum { PSIQ = 10, POUTE = 8 };
+	enum { PSIQ = CT::psiq, POUTE = 8 };
 	static constexpr id_t PSENT = static_cast<id_t>(~static_cast<id_t>(0));      // forward pop index no path has (8 bit ids: fewer than 255 pops per tree)
 	static_assert(sizeof(id_t) > 1 || 8u*FNW*FCH < 255u,"the end mark of a lane's interval heap must not be a forward pop index");
 	bool lscrdirty;      // lane 0: the lane scratch of the current round has been overwritten (an exact pair's enumerations, a serial combine)
@@ -3398,8 +3401,8 @@ struct FastEngine
 		for ( uint32_t c = lane; c < nc; c += WSZ )
 		{
 			uint32_t const slot = L.acc()[c].o, n = L.acc()[c].l & 0xFF;
-			uint32_t const len = decodeSeq(L.cseq()+FSEQCAP*slot,n,L.consL()+c*MAXCONS);
-			L.acc()[c].o = c*MAXCONS; L.acc()[c].l = len;
+			uint32_t const len = decodeSeq(L.cseq()+FSEQCAP*slot,n,L.consL()+c*CONSROW);
+			L.acc()[c].o = c*CONSROW; L.acc()[c].l = len;
 		}
 		wv_sync();
 		for ( uint32_t t = lane; t < nc*mao; t += WSZ )
