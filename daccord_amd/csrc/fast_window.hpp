@@ -73,7 +73,7 @@ template<int TIER> struct FastTier;
 // while the enumerations run): layout FastLds<CT,true>.  Round 3 measured that a second wavefront per SIMD hides the LDS
 // round trips of the first almost completely (profiles/r03a_occupancy_experiment.md), so LDS bytes per window decide the
 // throughput: tier 1 is 26.3 KB = 6 wavefronts per CU with (almost) the capacities it had at 53.8 KB = 3 per CU.
-template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 608, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 684, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
 template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 512, ncap = 476, scap = 88, lcap = 512, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
@@ -448,8 +448,8 @@ struct FastLds<CT,true>
 	FLD(lscr,uint8_t,lscrbytes,e_cseq)
 	FLD(siq,FSI,CT::siqcap,e_cseq)
 	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
-	// (the scratch tables of the stretch construction need 6 bytes per node: the region is at least that long)
-	static constexpr uint32_t uB = fcmax(fcmax(fcmax(e_consL,e_lscr),xbase + 6u*CT::ncap + 16u),xbase + (2u*CT::scap+2u)*2u + 8u + 8u*CT::scap + 16u);
+	// (the scratch tables of the stretch construction need 3 bytes per node: the region is at least that long)
+	static constexpr uint32_t uB = fcmax(fcmax(fcmax(e_consL,e_lscr),xbase + 3u*CT::ncap + 16u),xbase + (2u*CT::scap+2u)*2u + 8u + 8u*CT::scap + 16u);
 	static constexpr uint32_t xbytes = uB - xbase;
 	// raw stretches: over the pattern masks and weight offsets, which the feasibility writes later
 	FLD(tfirst,uint16_t,CT::scap,o_maskF)
@@ -467,10 +467,10 @@ struct FastLds<CT,true>
 	FLD(toff,uint16_t,2*CT::scap+2,xbase)
 	FLD(urec,uint32_t,2*CT::scap,e_toff)      // unit at position q of the processing order: lo | unit << 7
 	static_assert(e_urec <= uB,"feasibility tasks");
-	static_assert(6u*CT::ncap + 16u <= xbytes,"predecessor counts and walking table must fit the scratch");
+	static_assert(3u*CT::ncap + 16u <= xbytes,"predecessor counts (a byte per node) and walking table must fit the scratch");
 	static_assert(3u*CT::ncap + 16u <= xbytes && 2u*CT::ncap + CT::scap + 8u <= xbytes,"interior node table / reachability scratch");
 	HDEV LDSQ uint32_t * xcnt32() const { return reinterpret_cast<LDSQ uint32_t *>(base + xbase); }
-	HDEV LDSQ uint16_t * xstep() const { return reinterpret_cast<LDSQ uint16_t *>(base + xbase + 4u*CT::ncap + 8u); }
+	HDEV LDSQ uint16_t * xstep() const { return reinterpret_cast<LDSQ uint16_t *>(base + xbase + ((CT::ncap + 3u) & ~3u) + 8u); }
 	HDEV LDSQ uint16_t * xsid() const { return reinterpret_cast<LDSQ uint16_t *>(base + xbase); }
 	HDEV LDSQ uint8_t * xspos() const { return reinterpret_cast<LDSQ uint8_t *>(base + xbase + 2u*CT::ncap + 8u); }
 	HDEV LDSQ uint8_t * xreach() const { return reinterpret_cast<LDSQ uint8_t *>(base + xbase); }
@@ -1011,21 +1011,23 @@ struct FastEngine
 	DEV LDSQ uint16_t * stepTable() const { return L.xstep(); }
 	DEV void computePredCounts()
 	{
+		// (round 5: four 8 bit counters per word -- a node has at most four predecessors --, so that the scratch is 3 bytes per node
+		// instead of 6 and stops being what binds the tiers' last region when their node tables grow)
 		LDSQ uint32_t * const cnt32 = L.xcnt32();
 		LDSQ uint16_t * const stepT = stepTable();
-		for ( uint32_t z = lane; z < nn; z += WSZ ) cnt32[z] = 0;
+		for ( uint32_t z = lane; 4u*z < nn; z += WSZ ) cnt32[z] = 0;
 		wv_sync();
 		for ( uint32_t u = lane; u < nn; u += WSZ )
 		{
 			uint32_t const na = nsuccact(u);
 			uint32_t first = 0xFFFF;
-			for ( uint32_t i = 0; i < na; ++i ) { int32_t const v = succNode(u,i); wv_atomic_add(cnt32+v,1u); if ( i == 0 ) first = v; }
+			for ( uint32_t i = 0; i < na; ++i ) { int32_t const v = succNode(u,i); wv_atomic_add(cnt32+(static_cast<uint32_t>(v)>>2),1u << (8u*(static_cast<uint32_t>(v)&3u))); if ( i == 0 ) first = v; }
 			stepT[u] = (na == 1) ? first : 0xFFFF;
 		}
 		wv_sync();
 		for ( uint32_t z = lane; z < nn; z += WSZ )
 		{
-			uint32_t const c = cnt32[z];
+			uint32_t const c = (cnt32[z>>2] >> (8u*(z&3u))) & 0xFFu;
 			L.npred()[z] = c;
 			if ( c != 1 ) stepT[z] = 0xFFFF;
 		}
