@@ -73,11 +73,11 @@ template<int TIER> struct FastTier;
 // while the enumerations run): layout FastLds<CT,true>.  Round 3 measured that a second wavefront per SIMD hides the LDS
 // round trips of the first almost completely (profiles/r03a_occupancy_experiment.md), so LDS bytes per window decide the
 // throughput: tier 1 is 26.3 KB = 6 wavefronts per CU with (almost) the capacities it had at 53.8 KB = 3 per CU.
-template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 684, scap = 112, lcap = 768, wcap = 1024, rccap = 128, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 776, scap = 112, lcap = 960, wcap = 1024, rccap = 144, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
-template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 512, ncap = 476, scap = 88, lcap = 512, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
-enum : uint32_t { T0INST_DEFAULT = 500 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
+template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+enum : uint32_t { T0INST_DEFAULT = 560 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 // (round 4: 76 KB = 2 wavefronts per CU instead of 46.5 KB = 3, with tier 3's node capacity: at 54x more than half of what the deep tier
@@ -354,8 +354,9 @@ struct FastLds<CT,true>
 	FLD(bestL,uint8_t,MAXCONS,e_npred)
 	static constexpr uint32_t sbase = (e_bestL + 15u) & ~15u;
 	// ---- S (spilled while the pools are live) ----
-	FLD(str,uint8_t,CT::maxs*CT::lstr,sbase)
-	FLD(peq,uint64_t,CT::maxs*4*pw,e_str)
+	// (round 5: no string array -- the pattern masks ARE the strings: symbol c at position p of string j <=> bit p of peq[4*j+c]; they are
+	// built by ballots while the bases are gathered and the k-mers are cut from them; the 64 bytes per string went into the node tables)
+	FLD(peq,uint64_t,CT::maxs*4*pw,sbase)
 	FLD(ipos,uint8_t,CT::precap,e_peq)
 	FLD(irpos,uint8_t,CT::precap,e_ipos)
 	FLD(nps,uint16_t,CT::ncap+1,e_irpos)
@@ -738,10 +739,22 @@ struct FastEngine
 			if ( t < npre )
 			{
 				uint32_t const i = t - oj;
-				LDSQ uint8_t const * sp = L.str() + j*CT::lstr + i;
 				uint32_t v = 0;
-				#pragma unroll
-				for ( uint32_t q = 0; q < 16; ++q ) { uint32_t const c = sp[q]; v = q < k ? ((v<<2) | c) : v; }
+				if constexpr ( GW )
+				{
+					// symbols i ... i+k-1 from the pattern masks: low / high bit planes, reversed (symbol i is the most significant) and interleaved
+					LDSQ uint64_t const * PEQ = L.peq() + 4*j;
+					uint64_t const e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
+					uint32_t const km = (1u << k) - 1u;
+					uint32_t const lo = static_cast<uint32_t>((e1|e3) >> i) & km, hi = static_cast<uint32_t>((e2|e3) >> i) & km;
+					v = dacc_spread16(dacc_rev32(lo) >> (32u-k)) | (dacc_spread16(dacc_rev32(hi) >> (32u-k)) << 1);
+				}
+				else
+				{
+					LDSQ uint8_t const * sp = L.str() + j*CT::lstr + i;
+					#pragma unroll
+					for ( uint32_t q = 0; q < 16; ++q ) { uint32_t const c = sp[q]; v = q < k ? ((v<<2) | c) : v; }
+				}
 				uint64_t const word = (static_cast<uint64_t>(v)<<32) | (static_cast<uint64_t>(i)<<16) | j;
 				L.pre()[t] = word;
 				if ( i + k == L.slen()[j] ) L.lastk()[lo-1] = word;
@@ -2837,6 +2850,8 @@ struct FastEngine
 	}
 	DEV void buildPeq()
 	{
+		if constexpr ( GW ) return;      // the gather built them
+		else
 		for ( uint32_t j = lane; j < mao; j += WSZ )
 		{
 			uint32_t const m = L.slen()[j];
@@ -3781,10 +3796,24 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				if ( a2 ) DACC_LB(2)
 				if ( a3 ) DACC_LB(3)
 				#undef DACC_LB
+				if constexpr ( CT::gw != 0 )
+				{
+					// pattern masks by ballot: bit p of word c of string j <=> symbol c at position p (positions behind the string: no bit)
+					static_assert(CT::gw == 0 || CT::lstr == 64,"one 64 bit word per pattern mask");
+					uint32_t const sh = p - static_cast<uint32_t>(lane);      // (a 64-lane wavefront: 0; the 1-lane test build walks p)
+					#define DACC_PM(u) if ( j0+u < mao ) { \
+						uint64_t const b0 = wv_ballot(a##u && v##u == 0) << sh, b1 = wv_ballot(a##u && v##u == 1) << sh, b2 = wv_ballot(a##u && v##u == 2) << sh, b3 = wv_ballot(a##u && v##u == 3) << sh; \
+						if ( lane == 0 ) { LDSQ uint64_t * const q = L.peq() + 4*(j0+u); if ( sh == 0 ) { q[0] = b0; q[1] = b1; q[2] = b2; q[3] = b3; } else { q[0] |= b0; q[1] |= b1; q[2] |= b2; q[3] |= b3; } } }
+					DACC_PM(0) DACC_PM(1) DACC_PM(2) DACC_PM(3)
+					#undef DACC_PM
+				}
+				else
+				{
 				if ( a0 ) L.str()[(j0+0)*CT::lstr+p] = v0;
 				if ( a1 ) L.str()[(j0+1)*CT::lstr+p] = v1;
 				if ( a2 ) L.str()[(j0+2)*CT::lstr+p] = v2;
 				if ( a3 ) L.str()[(j0+3)*CT::lstr+p] = v3;
+				}
 			}
 	}
 	wv_sync();

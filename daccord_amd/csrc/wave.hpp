@@ -340,6 +340,22 @@ DEV void wv_sort_keys(PT A, uint32_t const n)
 	wv_bitonic_sort_n(A,n);
 }
 
+// bits of a 32 bit word in reverse order; the low 16 bits of a word spread to the even bit positions
+HDEV uint32_t dacc_rev32(uint32_t x)
+{
+#if defined(__clang__)
+	return __builtin_bitreverse32(x);
+#else
+	x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+	x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4); x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+	return (x >> 16) | (x << 16);
+#endif
+}
+HDEV uint32_t dacc_spread16(uint32_t x)
+{
+	x &= 0xFFFFu; x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+	return x;
+}
 HDEV uint32_t next_pow2(uint32_t v)
 {
 	uint32_t p = 1;
