@@ -266,7 +266,8 @@ def main():
         # workload AND on the very kernels this build runs -- never stale counters.  "The very kernels": the device sources are the
         # same (csrc_hash), or the machine code of the kernel is (kernel_isa: instruction-stream hash per kernel, build.kernel_isa_hashes;
         # a change to the generic engine leaves the code of the LDS tiers as it was).  Per-kernel numbers are quoted for unchanged kernels only.
-        roof.update(pmc_lookup(dom, args.reads, args.readlen, args.coverage, args.k))
+        # (the size classes' entry is two kernels; its counters are those of k_window_fast<0>, the pre-pass is 1 ms of it)
+        roof.update(pmc_lookup("k_window_fast<0>" if dom == "k_classify+k_window_fast<0>" else dom, args.reads, args.readlen, args.coverage, args.k))
         res = {
             "metric": "corrected Mbase/s (whole node), synthetic 20x PacBio piles",
             "value": round(value, 3), "unit": "Mbase/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1), "backend": (backend if world > 1 else None),
