@@ -526,7 +526,7 @@ def main():
             else:
                 cb["note_kind"] = "oracle/_ref is not available here: the top-level entry is the oracle port"
         res["post_loop_s"] = round(time.perf_counter() - t_post, 2)
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)      # out before any teardown (stdout is block-buffered when it is a file)
     if world > 1:
         dist.destroy_process_group()
 

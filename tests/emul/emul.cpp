@@ -11,6 +11,7 @@
 #include <string>
 #include <cstring>
 #include <cstdlib>
+#include <shared_mutex>
 #include "../../daccord_amd/csrc/batch_plan.hpp"
 #include "../../daccord_amd/csrc/host_tables.hpp"
 #include "../../daccord_amd/csrc/window_main.hpp"
@@ -34,6 +35,14 @@ struct EmulCtx
 	std::vector<uint64_t> glist;   // windows that went to the generic engine: index, flags of the last tier
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
+
+// arena.hpp's guard sink (arenaGuardSink) is ONE pointer per process, and every arena_carve pushes its field offsets into whatever it
+// points to.  Contexts that run on several threads (bench.py's like-for-like leg: one context per thread, all reaching their sizing
+// carve within microseconds of each other) would push into each other's `guards` vector -- a race on a std::vector that ends in
+// "double free or corruption" once in some dozen runs (round 5, found by -fsanitize=thread).  Sizing carves (sink set) are
+// exclusive; the carve at the head of every generic-engine window (window_main.hpp, sink must read 0) shares.
+static std::shared_mutex g_carve_mx;
+#define GENERIC_WINDOW(wdx) { std::shared_lock<std::shared_mutex> carve_(g_carve_mx); wave_run([&]() { processWindow(WB,(wdx),arena.data()); }); }
 
 // (diagnostics: the window and tier being emulated, for a debugger or a signal handler)
 extern "C" { volatile uint64_t dacc_emul_curwin = 0; volatile int dacc_emul_curtier = -1; }
@@ -190,7 +199,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		Arena A; ArenaCaps caps = BP.caps;
 		// guard gaps behind every arena field (arena.hpp): their offsets, and a check that they still hold the fill pattern
 		std::vector<uint64_t> guards;
-		arenaGuardSink() = &guards; caps.bytes = arena_carve(A,0,caps,P.w); arenaGuardSink() = 0;
+		{ std::unique_lock<std::shared_mutex> carve_(g_carve_mx); arenaGuardSink() = &guards; caps.bytes = arena_carve(A,0,caps,P.w); arenaGuardSink() = 0; }
 		std::vector<uint8_t> arena(caps.bytes+64,arenafill);
 		uint64_t guardbad = 0;
 		auto checkGuards = [&](uint64_t const wdx)
@@ -353,14 +362,14 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				wave_run([&]() { int const r = processWindowFast< FastTier<5> >(FBL,earlysnap[i],ldsL.data(),false); if ( wv_lane() == 0 ) rc = r; });
 			}
 			if ( rc == FW_DONE ) { ++c->nlong; continue; }
-			++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); wave_run([&]() { processWindow(WB,earlysnap[i],arena.data()); }); checkGuards(earlysnap[i]);
+			++c->nretry; c->glist.push_back(earlysnap[i]); c->glist.push_back(wout[earlysnap[i]].flags); GENERIC_WINDOW(earlysnap[i]) checkGuards(earlysnap[i]);
 		}
 		{
 			uint64_t const n = haveList ? cur.size() : BP.nwindows;
 			for ( uint64_t i = 0; i < n; ++i )
 			{
 				uint64_t const wdx = haveList ? cur[i] : i;
-				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); wave_run([&]() { processWindow(WB,wdx,arena.data()); }); checkGuards(wdx);
+				++c->nretry; c->glist.push_back(wdx); c->glist.push_back(wout[wdx].flags); GENERIC_WINDOW(wdx) checkGuards(wdx);
 			}
 		}
 		for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_RETRY ) { c->err = "internal error: a window was handed on between engines and never processed"; return DACC_EHIP; }
@@ -372,10 +381,10 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			if ( !any ) break;
 			if ( getenv("DACC_EMUL_VERBOSE") ) { uint64_t n = 0; uint32_t fl = 0; for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) { ++n; fl |= wout[wdx].flags; } std::fprintf(stderr,"[emul] scratch retry %d: %llu windows, flags 0x%x\n",attempt,static_cast<unsigned long long>(n),fl); }
 			growArenaCaps(caps,P.w);
-			guards.clear(); arenaGuardSink() = &guards; caps.bytes = arena_carve(A,0,caps,P.w); arenaGuardSink() = 0;
+			guards.clear(); { std::unique_lock<std::shared_mutex> carve_(g_carve_mx); arenaGuardSink() = &guards; caps.bytes = arena_carve(A,0,caps,P.w); arenaGuardSink() = 0; }
 			arena.assign(caps.bytes+64,arenafill);
 			WB.C = caps; WB.arena = arena.data();
-			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) { wave_run([&]() { processWindow(WB,wdx,arena.data()); }); checkGuards(wdx); }
+			for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx ) if ( wout[wdx].status == WS_OVERFLOW ) { GENERIC_WINDOW(wdx) checkGuards(wdx); }
 		}
 		if ( guardbad ) { c->err = "a window wrote behind the capacity of an arena field (guard gap overwritten)"; return DACC_EHIP; }
 	}

@@ -319,3 +319,24 @@ def test_wide_window_tables_bit_identical():
         for prof in ((0.12, 0.02, 0.85), (0.03, 0.01, 0.95)):
             O.set_error_profile(*prof); E.set_error_profile(*prof)
             assert (O.tables(200) == E.tables(200)).all()
+
+
+def test_contexts_on_concurrent_threads(small_data):
+    """bench.py's like-for-like leg: one context per thread, all started together.  The arena guard sink of the emulation build is
+    one pointer per process; contexts that reach their sizing carve together used to push into each other's guard list (a double free
+    once in some dozen bench runs, round 5) -- tests/emul/emul.cpp now makes the sizing carve exclusive.  Same output as one thread."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    d, ovl, piles = small_data
+    p = default_params(k=8)
+    def work(sel):
+        E = emul_lib.Emul(p); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+        fe, be = E.run(piles[sel], ovl, d.trace)
+        return hashlib.sha256(pyoracle.fasta(fe, be).encode()).hexdigest()
+    emul_lib.lib(1)
+    sels = [slice(i % 3, i % 3 + 1) for i in range(12)]
+    want = [work(s) for s in sels[:3]]
+    for _ in range(3):
+        with ThreadPoolExecutor(12) as ex:
+            got = list(ex.map(work, sels))
+        assert got == [want[i % 3] for i in range(12)]

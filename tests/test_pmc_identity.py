@@ -42,3 +42,13 @@ def test_bench_quotes_counters_only_for_kernels_it_runs():
         assert "traffic" not in r and r["pmc_source"].startswith("none for this build")
     # a workload nobody measured has no counters
     assert "traffic" not in bench.pmc_lookup(dom, 123, 456, 7.0, 9)
+
+
+def test_fused_tier0_line_reads_tier0_counters():
+    """the bench names the first slot `k_classify+k_window_fast<0>` (one event pair around both launches); the summaries are keyed by
+    kernel names: the lookup of that line must go to tier 0's counters (round 5: the line of the final build carried traffic null)"""
+    import bench
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"k_window_fast<0>" if dom == "k_classify+k_window_fast<0>" else dom' in src
+    a = bench.pmc_lookup("k_window_fast<0>", 10000, 10000, 20.0, 14)
+    assert "pmc_source" in a and not a["pmc_source"].startswith("error")
