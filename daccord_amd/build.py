@@ -50,19 +50,21 @@ def kernel_isa_hashes(lib=None):
         co = [os.path.join(d, f) for f in os.listdir(d) if "gfx950" in f]
         if not co:
             return {}
-        syms = [l.split()[-1] for l in subprocess.run([objdump, "-t", co[0]], check=True, capture_output=True, text=True).stdout.splitlines() if " F .text" in l]
         out = {}
-        for sym in syms:
-            dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", "--disassemble-symbols=" + sym, co[0]], check=True, capture_output=True, text=True).stdout
-            ins = [m.group(1) for m in (re.match(r"^\s+(\S.*?)\s*//\s*[0-9A-Fa-f]+:.*$", l) for l in dis.splitlines()) if m]
-            # _Z<len><name>[ILi<N>EE...]: the kernels are plain functions or templates over one int (no tool needed to read that)
-            m = re.match(r"^_Z(\d+)", sym); name = sym
-            if m:
-                n = int(m.group(1)); rest = sym[m.end():]; name = rest[:n]
-                t = re.match(r"^ILi(\d+)EE", rest[n:])
-                if t:
-                    name += "<%s>" % t.group(1)
-            out[name] = hashlib.sha256("\n".join(ins).encode()).hexdigest()[:16]
+        # one code object per translation unit that holds kernels (csrc/window_kernels.hpp: a unit per window kernel)
+        for cobj in sorted(co):
+            syms = [l.split()[-1] for l in subprocess.run([objdump, "-t", cobj], check=True, capture_output=True, text=True).stdout.splitlines() if " F .text" in l]
+            for sym in syms:
+                dis = subprocess.run([objdump, "-d", "--no-show-raw-insn", "--disassemble-symbols=" + sym, cobj], check=True, capture_output=True, text=True).stdout
+                ins = [m.group(1) for m in (re.match(r"^\s+(\S.*?)\s*//\s*[0-9A-Fa-f]+:.*$", l) for l in dis.splitlines()) if m]
+                # _Z<len><name>[ILi<N>EE...]: the kernels are plain functions or templates over one int (no tool needed to read that)
+                m = re.match(r"^_Z(\d+)", sym); name = sym
+                if m:
+                    n = int(m.group(1)); rest = sym[m.end():]; name = rest[:n]
+                    t = re.match(r"^ILi(\d+)EE", rest[n:])
+                    if t:
+                        name += "<%s>" % t.group(1)
+                out[name] = hashlib.sha256("\n".join(ins).encode()).hexdigest()[:16]
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -72,30 +74,72 @@ def _newer(target, srcs):
     return (not os.path.exists(target)) or os.path.getmtime(target) < max(os.path.getmtime(s) for s in srcs)
 
 
-def build_hip(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "daccord_hip.h"))
-    if force or _newer(LIB, srcs):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB, os.path.join(CSRC, "capi.hip"), os.path.join(CSRC, "host_tables.cpp"),
-                                       os.path.join(CSRC, "host_piles.cpp"), os.path.join(CSRC, "host_io.cpp"),
-                                       os.path.join(CSRC, "host_eprof.cpp")]
+HIP_UNITS = ["capi.hip", "k_generic.hip", "k_fast_0.hip", "k_fast_1.hip", "k_fast_6.hip", "k_fast_2.hip", "k_fast_3.hip", "k_fast_4.hip"]
+HOST_UNITS = ["host_tables.cpp", "host_piles.cpp", "host_io.cpp", "host_eprof.cpp"]
+
+
+def _deps_newer(obj, dep):
+    """True if `obj` is missing or older than any file its depfile (-MD) names."""
+    if not os.path.exists(obj) or not os.path.exists(dep):
+        return True
+    t = os.path.getmtime(obj)
+    txt = open(dep).read().replace("\\\n", " ")
+    for f in txt.split(":", 1)[1].split():
+        try:
+            if os.path.getmtime(f) > t:
+                return True
+        except OSError:
+            return True
+    return False
+
+
+def _build_objects(out, extra_flags, tag, force=False, verbose=False):
+    """The library as one object per translation unit, compiled side by side: the window kernels are 150-260 KB of gfx950 code each
+    (one k_window_fast<tier> per unit, csrc/window_kernels.hpp) and took 25 minutes one after the other in a single unit.  Objects and
+    their dependency files live in daccord_amd/_obj/<tag>/ (git- and gpurun-ignored); a unit is recompiled when a file it includes
+    changed.  Same flags and the same device code as the single-unit build (kernel_isa_hashes)."""
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    odir = os.path.join(_HERE, "_obj", tag)
+    os.makedirs(odir, exist_ok=True)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    stamp = os.path.join(odir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(cflags):
+        force = True
+    jobs = []
+    for u in HIP_UNITS + HOST_UNITS:
+        obj = os.path.join(odir, u + ".o"); dep = os.path.join(odir, u + ".d")
+        if force or _deps_newer(obj, dep):
+            jobs.append([hipcc] + cflags + ["-c", "-MD", "-MF", dep, "-o", obj, os.path.join(CSRC, u)])
+    def run(cmd):
         if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-    return LIB
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed:\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+    if jobs:
+        nw = int(os.environ.get("DACC_BUILD_JOBS", "0")) or min(len(jobs), max(1, (os.cpu_count() or 1)))
+        with ThreadPoolExecutor(nw) as ex:
+            list(ex.map(run, jobs))
+        open(stamp, "w").write(" ".join(cflags))
+    objs = [os.path.join(odir, u + ".o") for u in HIP_UNITS + HOST_UNITS]
+    if jobs or _newer(out, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs)
+    return out
+
+
+def build_hip(force=False, verbose=False):
+    return _build_objects(LIB, [], "product", force, verbose)
 
 
 def build_prof(force=False):
     """Profiling build of the same library (-DDACC_PROFILE: per-phase shader-cycle counters, scripts/prof_phases.py)."""
-    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".cpp"))]
-    out = os.path.join(_HERE, "libdaccord_hip_prof.so")
-    if force or _newer(out, srcs):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc] + HIPCC_FLAGS + ["-DDACC_PROFILE", "-o", out, os.path.join(CSRC, "capi.hip"),
-                               os.path.join(CSRC, "host_tables.cpp"), os.path.join(CSRC, "host_piles.cpp"),
-                               os.path.join(CSRC, "host_io.cpp"), os.path.join(CSRC, "host_eprof.cpp")])
-    return out
+    return _build_objects(os.path.join(_HERE, "libdaccord_hip_prof.so"), ["-DDACC_PROFILE"], "prof", force)
+
+
+def build_variant(name, flags, units=None, force=False):
+    """Experiment variant daccord_amd/libvar_<name>.so (selected with DACC_LIB=<path>): the product's flags plus `flags`."""
+    return _build_objects(os.path.join(_HERE, "libvar_%s.so" % name), list(flags), "var_" + name, force)
 
 
 def build_io(force=False):

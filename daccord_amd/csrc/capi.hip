@@ -13,8 +13,7 @@
 #include "../../include/daccord_hip.h"
 #include "batch_plan.hpp"
 #include "host_tables.hpp"
-#include "window_main.hpp"
-#include "fast_window.hpp"
+#include "window_kernels.hpp"
 #include "trace_kernel.hpp"
 #include "vote_kernel.hpp"
 
@@ -66,83 +65,6 @@ __global__ void __launch_bounds__(64) k_trace_wide(TraceBatch B, uint32_t const 
 	if ( threadIdx.x < nl )
 		for ( uint64_t task = static_cast<uint64_t>(blockIdx.x)*nl + threadIdx.x; task < B.nblocks; task += static_cast<uint64_t>(gridDim.x)*nl )
 			traceBlockWide<NW>(B,task,st);
-}
-
-// Work distribution of the window kernels.  Windows differ in cost by orders of magnitude, so workgroups pull indices
-// from counters; workgroup b runs on XCD b%8 (observed placement), and the windows of one pile share its overlaps and
-// reads, so every XCD first drains its own contiguous eighth of the index range (its L2 keeps the pile's data) and
-// then steals from the other XCDs.  work[0..7] = per-XCD counters.  Returns false when nothing is left.
-__device__ __forceinline__ bool next_window(uint32_t * work, uint64_t const n, uint32_t & state, uint32_t & idx)
-{
-	uint32_t const home = blockIdx.x & 7;
-	while ( state < 8 )
-	{
-		uint32_t const q = (home + state) & 7;
-		uint64_t const lo = (n*q)>>3, hi = (n*(q+1))>>3;
-		uint32_t i = 0;
-		if ( threadIdx.x == 0 ) i = atomicAdd(work+q,1u);
-		i = __builtin_amdgcn_readfirstlane(i);
-		if ( lo + i < hi ) { idx = static_cast<uint32_t>(lo+i); return true; }
-		++state;
-	}
-	return false;
-}
-
-// one wavefront per workgroup, grid-stride over windows.  Workgroup b lands on XCD b%8 (observed
-// placement, used for L2 affinity only): give every XCD a contiguous run of windows so that the
-// windows of one pile (which share the pile's overlaps and reads) hit one L2.
-// generic engine: all windows (list == 0) or the windows the LDS fast path handed back (list[0] = count)
-// Windows differ in cost by orders of magnitude, so the workgroups pull window indices from a counter (*work).
-__global__ void __launch_bounds__(64) k_window(WindowBatch B, uint32_t * errflag, uint32_t const * list, uint32_t * work)
-{
-	uint8_t * arena = B.arena + static_cast<uint64_t>(blockIdx.x)*B.C.bytes;
-	if ( B.prof ) B.prof += DACC_PROFW*(blockIdx.x & 4095);
-	uint64_t const n = list ? list[0] : B.nwindows;
-	uint32_t it = 0;
-	while ( true )
-	{
-		uint32_t i = 0;
-		if ( work )
-		{
-			if ( threadIdx.x == 0 ) i = atomicAdd(work,1u);
-			i = __builtin_amdgcn_readfirstlane(i);
-		}
-		else { i = it*gridDim.x + blockIdx.x; ++it; }
-		if ( i >= n ) break;
-		uint64_t const w = list ? list[1+i] : i;
-		processWindow(B,w,arena);
-		if ( threadIdx.x == 0 && B.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
-	}
-}
-
-// Second stream: the windows the pre-scan (a B string of more than 64 bases) or the first tier (no LDS tier can run the
-// shape) set aside.  One wavefront per workgroup tries tier 5 (FastTier<5>: strings of up to 128 bases, LDS of a whole CU)
-// and runs the generic engine right here for what tier 5 cannot hold.  FB.F.ldsbytes == 0: tier 5 is not usable with this
-// model table (then this is the generic engine alone).  Static striding over the list, like the generic launch it replaces.
-__global__ void __launch_bounds__(64) k_window_long(FastBatch FB, uint32_t * errflag, uint32_t const * list)
-{
-	typedef FastTier<5> CT;
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
-	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
-	bool const tier = FB.F.ldsbytes != 0;
-	if ( tier ) { FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
-	uint8_t * arena = FB.W.arena + static_cast<uint64_t>(blockIdx.x)*FB.W.C.bytes;
-	uint64_t const n = list[0];
-	for ( uint32_t it = 0; ; ++it )
-	{
-		uint64_t const i = static_cast<uint64_t>(it)*gridDim.x + blockIdx.x;
-		if ( i >= n ) break;
-		uint64_t const w = list[1+i];
-		int rc = FW_NEXT;
-		if ( tier ) rc = processWindowFast<CT>(FB,w,lds,false);
-		__syncthreads();
-		if ( rc != FW_DONE )
-		{
-			processWindow(FB.W,w,arena);
-			if ( threadIdx.x == 0 && FB.W.wout[w].status == WS_OVERFLOW ) atomicOr(errflag,1u);
-		}
-		__syncthreads();
-	}
 }
 
 // The generic engine's per-wavefront arena grows with the deepest pile of the batch (7 MB at depth 32, 200 MB at 1000,
@@ -198,51 +120,6 @@ __global__ void k_collect_overflow(WindowOut const * wout, uint64_t n, uint32_t 
 {
 	uint64_t const i = static_cast<uint64_t>(blockIdx.x)*blockDim.x + threadIdx.x;
 	if ( i < n && wout[i].status == WS_OVERFLOW ) { uint32_t const q = atomicAdd(list,1u); list[1+q] = static_cast<uint32_t>(i); }
-}
-
-// LDS fast path: one wavefront per workgroup, working state in the workgroup's dynamic LDS slice.
-// list == 0: all windows; else the windows a smaller capacity tier handed over.  Windows that do not fit go to FB.retry.
-// (tiers 0 and 1 hold 8 and 6 windows per CU in LDS: two wavefronts per SIMD need their kernels within 256 registers; the register
-// allocator lands within a few registers of that bound either way, amdgpu_waves_per_eu(2) would make it a requirement (-DDACC_WPE_CAP: 248 / 253 registers, no scratch) but changes the
-// scheduler's targets with it: 5 % SLOWER on config 2, profiles/r05e_ab_register_cap.log -- so the bound is kept by hand)
-#if defined(DACC_WPE_CAP)
-#define DACC_WPE(T) __attribute__((amdgpu_waves_per_eu((T) <= 1 ? 2 : 1)))
-#elif defined(DACC_NUMVGPR_CAP)
-#define DACC_WPE(T) __attribute__((amdgpu_num_vgpr((T) <= 1 ? 256 : 512)))
-#else
-#define DACC_WPE(T)
-#endif
-template<int TIER>
-__global__ void __launch_bounds__(64) DACC_WPE(TIER) k_window_fast(FastBatch FB, uint32_t const * list, uint32_t * work)
-{
-	typedef FastTier<TIER> CT;
-	if ( FB.W.prof ) FB.W.prof += DACC_PROFW*(blockIdx.x & 4095);
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds_generic[];
-	LDSQ uint8_t * lds = (LDSQ uint8_t *)lds_generic;
-	{ FastLds<CT> L; L.base = lds; fast_load_tables(L,FB.F.nrows,FB.F.nsup,FB.W.T,FB.dpsq_vst); }
-#if defined(DACC_PROFILE)
-	uint64_t const t0c = clock64(), t0w = wall_clock64();
-#endif
-	uint64_t const n = list ? list[0] : FB.W.nwindows;
-	uint32_t it = 0, qstate = 0;
-	while ( true )
-	{
-		uint32_t i = 0;
-		if ( work ) { if ( !next_window(work,n,qstate,i) ) break; }
-		else { i = it*gridDim.x + blockIdx.x; ++it; }
-		if ( i >= n ) break;
-		uint64_t const w = list ? list[1+i] : i;
-		int const rc = processWindowFast<CT>(FB,w,lds,list != 0);
-		if ( rc != FW_DONE && threadIdx.x == 0 )
-		{
-			uint32_t * const dst = (rc == FW_GENERIC && FB.gearly) ? FB.gearly : FB.retry;
-			uint32_t const q = atomicAdd(dst,1u); dst[1+q] = static_cast<uint32_t>(w);
-		}
-		__syncthreads();
-	}
-#if defined(DACC_PROFILE)
-	if ( threadIdx.x == 0 && FB.W.prof && !list ) { atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+30),static_cast<unsigned long long>(clock64()-t0c)); atomicAdd(reinterpret_cast<unsigned long long *>(FB.W.prof+31),static_cast<unsigned long long>(wall_clock64()-t0w)); atomicMax(reinterpret_cast<unsigned long long *>(FB.W.prof+29),static_cast<unsigned long long>(wall_clock64()-t0w)); }
-#endif
 }
 
 // exclusive scan of one value per thread over the 256 threads of the workgroup (4 wavefronts): DPP scan inside a
@@ -463,11 +340,11 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
-	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_t0inst;     // debugging knobs, read once in dacc_create
+	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_lds_t0, env_t0inst;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<int32_t> pile_status; std::vector<std::string> pile_errors; std::string pile_errors_joined;
@@ -475,7 +352,7 @@ struct dacc_ctx
 	dacc_timing timing;
 };
 
-#define HIPCHK(call) do { hipError_t const e_ = (call); if ( e_ != hipSuccess ) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return DACC_EHIP; } } while (0)
+#define HIPCHK(call) do { hipError_t const e_ = (call); if ( e_ != hipSuccess ) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); if ( e_ == hipErrorOutOfMemory ) c->oom = true; return DACC_EHIP; } } while (0)
 
 template<typename T>
 static int upload(dacc_ctx * c, DevBuf<T> & b, T const * src, size_t n)
@@ -521,7 +398,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	if ( hipSetDevice(p->device) != hipSuccess ) return DACC_ENODEV;
 	dacc_ctx * c = new (std::nothrow) dacc_ctx;
 	if ( !c ) return DACC_ENOMEM;
-	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->nlong[0] = c->nlong[1] = 0; c->handcap = 0; c->handwords = 0; c->handwant = 0; c->nruns = 0;
+	c->par = *p; c->device = p->device; c->haveprofile = c->havedb = c->havebatch = false; c->est_cor = 0; c->nlong[0] = c->nlong[1] = 0; c->handcap = 0; c->handwords = 0; c->handwant = 0; c->nruns = 0; c->nohand = false; c->oom = false;
 	std::memset(&c->timing,0,sizeof(c->timing));
 	// launch geometry of the LDS tiers: set by every batch that uses them; a generic-only batch (DACC_NOFAST, w >= 64, a model table no
 	// tier holds) reads retry_grid in its scratch retry and must not find an indeterminate value there
@@ -533,6 +410,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 15;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes)
 		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
+		char const * l0 = getenv("DACC_LDS_T0"); c->env_lds_t0 = l0 ? static_cast<uint32_t>(atoi(l0)) : 0u;      // the same for tier 0 (size classes)
 		char const * t0 = getenv("DACC_T0INST"); c->env_t0inst = t0 ? static_cast<uint32_t>(atoi(t0)) : static_cast<uint32_t>(T0INST_DEFAULT);      // size-class threshold (k-mer instances) of tier 0
 		char const * dr = getenv("DACC_DEBUG_RETRY"); c->env_dbgretry = (dr && dr[0] == '1');
 	}
@@ -631,7 +509,7 @@ static int runDevice(dacc_ctx * c)
 	// DACC_DEBUG_SYNC=1: wait for every kernel of the generic-only path and say so on stderr (a device fault then names its kernel)
 	static bool const dbgsync = getenv("DACC_DEBUG_SYNC") && getenv("DACC_DEBUG_SYNC")[0] == '1';
 	auto const mark = [&](char const * what) { if ( dbgsync ) { hipError_t const e = hipStreamSynchronize(s); std::fprintf(stderr,"[dacc] %s: %s\n",what,hipGetErrorString(e)); std::fflush(stderr); } };
-	if ( c->nruns && c->handwant > c->handcap )
+	if ( c->nruns && c->handwant > c->handcap && !c->nohand )
 	{
 		// second use of this context: now the hand-over buffer pays (dacc_submit_piles); an optimisation only -- if the device
 		// cannot spare it, halve it, and in the end do without
@@ -683,20 +561,26 @@ static int runDevice(dacc_ctx * c)
 			if ( BP.ovl.size() )
 				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
 			HIPCHK(hipEventRecord(c->evPrescan,s));
-			HIPCHK(hipStreamWaitEvent(c->stream2,c->evPrescan,0));
 			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0; FL.gslab = 0; FL.gstride = 0; FL.tab32 = c->d_tab32.p; FL.hand = 0; FL.handctr = 0; FL.handcap = 0; FL.handwords = 0;
+#if defined(DACC_LEDGER)
+			FL.ledger = 0;
+#endif
 			if ( !c->tierL_ok ) FL.F.ldsbytes = 0;
 			// a launch the device refuses (the LDS of a whole CU) falls back to the generic engine alone, for good
-			// (round 5) The length of a list is fetched before its launch (one 4 byte copy and a stream synchronisation: the host has
-			// nothing else to queue at these two points) and the grid follows it: an empty list -- the rule at the default window -- is
-			// not launched at all, a list of three windows asks for three CUs' worth of LDS instead of 256.  Rounds 1-4 queued the full
-			// grid twice per pass; its workgroups need the LDS of a whole CU each and sat in the queue until the tier in front retired
+			// (round 5) The length of a list is fetched before its launch and the grid follows it: an empty list -- the rule at the default
+			// window -- is not launched at all, a list of three windows asks for three CUs' worth of LDS instead of 256.  Rounds 1-4 queued
+			// the full grid twice per pass; its workgroups need the LDS of a whole CU each and sat in the queue until the tier in front retired
 			// (939 ms of "duration" for one window in the round-4 kernel table).
-			auto const launchLong = [&](uint32_t const * const lst, uint32_t & nlist) -> int
+			// (round 6) The 4 byte copy and the wait run on the SECOND stream, behind the event of the kernel that fills the
+			// list, and only after every tier and the generic kernel have been queued on the main stream: round 5 synchronised the main
+			// stream in the middle of the chain, which kept the host -- and a second context's batches on the same device -- out of the
+			// queue until the first tier had retired.
+			auto const launchLong = [&](uint32_t const * const lst, uint32_t & nlist, hipEvent_t const filled) -> int
 			{
 				nlist = 0;
-				HIPCHK(hipMemcpyAsync(&nlist,lst,sizeof(uint32_t),hipMemcpyDeviceToHost,s));
-				HIPCHK(hipStreamSynchronize(s));
+				HIPCHK(hipStreamWaitEvent(c->stream2,filled,0));
+				HIPCHK(hipMemcpyAsync(&nlist,lst,sizeof(uint32_t),hipMemcpyDeviceToHost,c->stream2));
+				HIPCHK(hipStreamSynchronize(c->stream2));
 				if ( !nlist ) return DACC_OK;
 				uint32_t const grid = nlist < c->early_grid ? nlist : c->early_grid;
 				(void)hipGetLastError();
@@ -709,7 +593,6 @@ static int runDevice(dacc_ctx * c)
 				return DACC_OK;
 			};
 			c->nlong[0] = c->nlong[1] = 0;
-			{ int const rc = launchLong(static_cast<uint32_t const *>(c->d_pregenlist.p),c->nlong[0]); if ( rc ) return rc; }
 			WB.pregen = c->d_pregen.p;
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
@@ -725,6 +608,9 @@ static int runDevice(dacc_ctx * c)
 					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p;
 					FB.gslab = c->d_gslab.p; FB.gstride = c->gstride[t]; FB.tab32 = c->d_tab32.p;
 					FB.hand = c->handcap ? c->d_hand.p : static_cast<uint64_t *>(0); FB.handctr = c->d_handctr.p; FB.handcap = c->handcap; FB.handwords = c->handwords;
+#if defined(DACC_LEDGER)
+					{ char const * lm = getenv("DACC_LEDGER_MASK"); FB.ledger = lm ? static_cast<uint32_t>(strtoul(lm,0,0)) : 0u; }      // (scripts/ledger.py)
+#endif
 					// only the first tier feeds the early generic list (its kernel reads the list once, right after that tier): a
 					// window that reaches a later tier first (mao beyond the earlier tier) and turns out to be generic-only takes
 					// the ordinary hand-over chain to the generic kernel at the end
@@ -752,9 +638,6 @@ static int runDevice(dacc_ctx * c)
 						// (high priority) stream and arena, while the remaining tiers run
 						early = true;
 						HIPCHK(hipEventRecord(c->evFirstTier,s));
-						HIPCHK(hipStreamWaitEvent(c->stream2,c->evFirstTier,0));
-						{ int const rc = launchLong(static_cast<uint32_t const *>(c->d_gearly.p),c->nlong[1]); if ( rc ) return rc; }
-						HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
 					}
 				}
 				hipEventRecord(c->evtier[t],s);
@@ -770,6 +653,10 @@ static int runDevice(dacc_ctx * c)
 			}
 			// what is left (rare shapes) goes through the generic engine
 			hipLaunchKernelGGL(k_window,dim3(c->retry_grid),dim3(64),0,s,WB,c->d_err.p,list,(c->sched&2) ? c->d_work.p+32 : static_cast<uint32_t *>(0));
+			// the second stream: the pre-scan's list (a string of more than 64 bases) as soon as the pre-scan is done, the first tier's
+			// generic-only windows behind the first tier; the main stream's queue is full by now
+			{ int const rc = launchLong(static_cast<uint32_t const *>(c->d_pregenlist.p),c->nlong[0],c->evPrescan); if ( rc ) return rc; }
+			if ( early ) { int const rc = launchLong(static_cast<uint32_t const *>(c->d_gearly.p),c->nlong[1],c->evFirstTier); if ( rc ) return rc; }
 			// everything the second stream ran (pre-scan list, first tier's generic-only windows) must be done before the vote
 			HIPCHK(hipEventRecord(c->evEarlyGeneric,c->stream2));
 			HIPCHK(hipStreamWaitEvent(s,c->evEarlyGeneric,0));
@@ -816,7 +703,7 @@ static int runDevice(dacc_ctx * c)
 	{
 		// length of the two lists of the second stream (pre-scan, first tier's generic-only windows), fetched before their launches
 		uint32_t const n1 = c->nlong[0], n2 = c->nlong[1];
-		c->timing.long_windows = n1 + n2;
+		c->timing.long_windows = n1 + n2; c->timing.long_first_tier = n2;
 		if ( c->tier0_ran )
 		{
 			// size classes: the pre-pass sent nsmall windows to tier 0 and nwindows - nsmall - n1 to the big list, which tier 0's
@@ -885,7 +772,7 @@ static int runDevice(dacc_ctx * c)
 	hipEventElapsedTime(&ms,c->ev[1],c->ev[2]); c->timing.window_ms = ms;
 	for ( int i = 0; i < 3; ++i ) { c->timing.tier_ms[i] = 0; c->timing.tier_out[i] = c->tier_out[i]; }
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) { hipEventElapsedTime(&ms,i ? c->evtier[i-1] : c->ev[1],c->evtier[i]); c->timing.tier_ms[i] = ms; }
-	c->timing.tier0_ms = 0; c->timing.reserved_ = 0;
+	c->timing.tier0_ms = 0;
 	if ( c->tier0_ran ) { hipEventElapsedTime(&ms,c->ev[1],c->evT0); c->timing.tier0_ms = ms; }
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
@@ -993,6 +880,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 		}
 		{
 			// tier 0 (size classes) in front of tier 1 of a shallow batch: DACC_TIERS bit 3 switches it off
+			if ( c->env_lds_t0 > BP.ftier0.ldsbytes && c->env_lds_t0 <= 160*1024 ) BP.ftier0.ldsbytes = c->env_lds_t0;
 			FastCaps const & F0 = BP.ftier0;
 			c->tier0_ok = !BP.deep && c->tier_ok[0] && ((c->env_tiers>>3)&1) && F0.ldsbytes <= 160*1024;
 			uint64_t percu0 = (160*1024) / (F0.ldsbytes ? F0.ldsbytes : 1); if ( percu0 > 8 ) percu0 = 8; if ( percu0 < 1 ) percu0 = 1;
@@ -1017,6 +905,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			if ( cap > maxcap ) cap = maxcap;
 			if ( he && he[0] == '0' ) cap = 0;
 			if ( c->par.klow != c->par.khigh ) cap = 0;
+			if ( c->nohand ) cap = 0;      // a retry after an allocation failure: no optional buffer (dacc_drop_hand)
 			c->handwant = cap;
 			HIPCHK(c->d_handctr.ensure(4));
 			if ( c->d_hand.cap < static_cast<size_t>(cap)*c->handwords ) c->handcap = static_cast<uint32_t>(c->d_hand.cap / c->handwords);     // what an earlier batch left
@@ -1190,25 +1079,31 @@ int dacc_plan_only(dacc_params const * par, uint32_t const * rlen, uint64_t nrea
 	catch ( ... ) { return DACC_EINTERNAL; }
 }
 
-//  a HIP failure while the optional hand-over buffer is held (up to 16 GB) may be an allocation it starved: give the buffer
-// back and run the call once more without it
+//  a device ALLOCATION failure while the optional hand-over buffer is held (up to 16 GB) may be an allocation it
+// starved: give the buffer back and run the call once more without it -- the context keeps `nohand` set, so neither the planner of the
+// retried call nor runDevice's "second use" allocation brings the buffer back.  Other failures (a device fault, internal error
+// flags, host allocation) are not retried: a second pass would only overwrite the first error's text.
 static bool dacc_drop_hand(dacc_ctx * c)
 {
-	if ( !c || !c->d_hand.p ) return false;
+	if ( !c || !c->oom ) return false;
+	c->oom = false;
+	if ( !c->d_hand.p ) return false;
 	(void)hipGetLastError(); hipSetDevice(c->device); (void)hipDeviceSynchronize(); (void)hipGetLastError();
-	c->d_hand.release(); c->handcap = 0; c->handwant = 0;
+	c->d_hand.release(); c->handcap = 0; c->handwant = 0; c->nohand = true;
 	return true;
 }
 int dacc_submit_piles(dacc_ctx * c, dacc_pile const * piles, uint64_t npiles, dacc_overlap const * ovl, uint64_t novl, void const * trace, uint64_t ntrace, int trace_bytes)
 {
+	if ( c ) c->oom = false;
 	int rc = guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); });
-	if ( (rc == DACC_EHIP || rc == DACC_ENOMEM) && dacc_drop_hand(c) ) rc = guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); });
+	if ( rc == DACC_EHIP && dacc_drop_hand(c) ) rc = guarded(c,[&]() { return dacc_submit_piles_body(c,piles,npiles,ovl,novl,trace,ntrace,trace_bytes); });
 	return rc;
 }
 int dacc_rerun_resident(dacc_ctx * c)
 {
+	if ( c ) c->oom = false;
 	int rc = guarded(c,[&]() { return dacc_rerun_resident_body(c); });
-	if ( (rc == DACC_EHIP || rc == DACC_ENOMEM) && dacc_drop_hand(c) ) rc = guarded(c,[&]() { return dacc_rerun_resident_body(c); });
+	if ( rc == DACC_EHIP && dacc_drop_hand(c) ) rc = guarded(c,[&]() { return dacc_rerun_resident_body(c); });
 	return rc;
 }
 

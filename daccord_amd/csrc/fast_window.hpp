@@ -73,10 +73,16 @@ template<int TIER> struct FastTier;
 // while the enumerations run): layout FastLds<CT,true>.  Round 3 measured that a second wavefront per SIMD hides the LDS
 // round trips of the first almost completely (profiles/r03a_occupancy_experiment.md), so LDS bytes per window decide the
 // throughput: tier 1 is 26.3 KB = 6 wavefronts per CU with (almost) the capacities it had at 53.8 KB = 3 per CU.
-template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 776, scap = 112, lcap = 960, wcap = 1024, rccap = 144, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+// (round 6) reverse pool of tiers 0 and 1 in chunks of TWO paths: a lane takes pool entries a chunk at a time, and with one lane per last
+// k-mer candidate (9 on average, up to 24) most chunks of four were half empty -- the reverse pool had become what sent tier 0's windows on
+// (82 % of its hand-overs, each after the whole build phase and the feasibility; emulation, 8 piles of config 2: 261 of 5251 windows -> 14)
+#if !defined(DACC_RCH01)
+#define DACC_RCH01 2
+#endif
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 776, scap = 112, lcap = 960, wcap = 1024, rccap = 144, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
-template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = 4, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
 enum : uint32_t { T0INST_DEFAULT = 560 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
@@ -519,6 +525,9 @@ struct FastBatch
 	// list in a slot of this buffer (handwords 64 bit words per slot: header {npre, nlast}, instances, last k-mers); the tier that picks
 	// the window up loads them instead of generating and sorting them again.  hand == 0: every hand-over restarts from the strings.
 	uint64_t * hand; uint32_t * handctr; uint32_t handcap, handwords;
+#if defined(DACC_LEDGER)
+	uint32_t ledger;            // instruction ledger build (scripts/ledger.py): bit p set = phase p of every window runs twice
+#endif
 };
 
 // once per workgroup: the support bounds of the model table
@@ -530,6 +539,19 @@ DEV void fast_load_tables(FastLds<CT> const & L, uint32_t const nrows, uint32_t 
 	wv_sync();
 }
 
+// Instruction ledger (round 6, VERDICT r05 task 1b).  PC sampling is refused on this pool and thread trace has no decoder, but the SQ
+// counters are per kernel: a -DDACC_LEDGER build runs the phase whose bit is set in FastBatch::ledger TWICE (every phase listed is
+// idempotent: it rewrites the same bytes from inputs it does not modify), so the difference of SQ_INSTS_VALU / _SALU / _LDS / ... and of
+// SQ_WAVE_CYCLES between a run with the bit and a run without is that phase's own instruction count and wave time, on the product's code
+// generation, at the product's occupancy, with bit-identical output.  What cannot run twice (the lane 0 replay of the pairs, which feeds
+// the candidate heap) is the remainder.  The product build compiles LEDGER_REP to nothing.
+#if defined(DACC_LEDGER)
+#define LEDGER_REP(bit) for ( uint32_t lrep_ = 0, lrn_ = 1u + ((ledger >> (bit)) & 1u); lrep_ < lrn_; ++lrep_ )
+#define LEDGER_REPX(E,bit) for ( uint32_t lrep_ = 0, lrn_ = 1u + (((E).ledger >> (bit)) & 1u); lrep_ < lrn_; ++lrep_ )
+#else
+#define LEDGER_REP(bit)
+#define LEDGER_REPX(E,bit)
+#endif
 #define FW_THRES_FEAS 4294968ull        /* weight >= 1e-3 */
 #define FW_THRES_01   429496730ull      /* weight > 0.1 and weight >= 0.1 (no integer lies between) */
 #define FW_THRES_05   2147483648ull     /* weight >= 0.5 */
@@ -597,6 +619,9 @@ struct FastEngine
 	uint32_t const * gtab;       // gw: padded 32 bit table in global memory
 	struct G4 { uint32_t x, y, z, w; };      // one 16 byte weight record
 	int lane; uint32_t flags;
+#if defined(DACC_LEDGER)
+	uint32_t ledger;
+#endif
 	uint64_t * prof;
 	uint32_t mao, k; uint64_t kmask;
 	uint32_t npre, nlast, nn, nmfirst, nmlast;
@@ -3137,15 +3162,16 @@ struct FastEngine
 	{
 		PROF_T0
 		cfree = 0xFFFFu; ncdh = 0; nacc = 0; nwF = 0; nwR = 0; nsiq = 0; pvpath = pvrp = pvnf = 0; pvcl = ~0u;
-		computeBaseStretches();
+		LEDGER_REP(5) computeBaseStretches();
 		flags = wv_or(flags); if ( flags ) return false;
 		PROF(*this,8)
-		findCandidatesAndPieces();
+		LEDGER_REP(6) findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
 #if !defined(DACC_NO_REACH)
 		{
 			SITE_T0
-			bool const reach = pairReachable();
+			bool reach = false;
+			LEDGER_REP(7) reach = pairReachable();
 			SITE(23)      // traverse: reachability prune
 			if ( !reach ) { FSTAT_ADD(23,1); PROF(*this,16) return false; }
 		}
@@ -3153,12 +3179,14 @@ struct FastEngine
 		PROF(*this,16)
 		loadTab();
 		PROF(*this,17)
-		computeStretchFeasLanes(0,npool);
+		LEDGER_REP(8) { nwF = 0; nwR = 0; computeStretchFeasLanes(0,npool); }
 		flags = wv_or(flags); if ( flags ) return false;
-		{ SITE_T0 spillS(); SITE(24) }      // traverse: build-phase arrays to the slab
+		{ SITE_T0 bool const sf0_ = sfresh, sd0_ = sdirty; LEDGER_REP(9) { sfresh = sf0_; sdirty = sd0_; spillS(); } SITE(24) }      // traverse: build-phase arrays to the slab
 		PROF(*this,9)
 
 		// ---- reverse blocks of all last k-mer candidates, lane = candidate ----
+		LEDGER_REP(10)
+		{
 		if ( lane == 0 ) { L.ctr()[0] = 0; L.ctr()[1] = 0; }
 		wv_sync();
 		{
@@ -3209,6 +3237,7 @@ struct FastEngine
 			rstop = sb;
 		}
 		wv_sync();
+		}
 		PROF(*this,11)
 
 		// ---- batches of forward trees (lane = first k-mer candidate) and their pairs ----
@@ -3216,13 +3245,16 @@ struct FastEngine
 		while ( fstart < nF )
 		{
 			materializeKept();      // the trees of the batch before are about to be overwritten
-			if ( lane == 0 ) L.ctr()[1] = 0;
-			wv_sync();
 			uint32_t const fi = fstart + lane;
 			bool const fact = static_cast<uint32_t>(lane) < bw && fi < nF;
-			FEnum F; clInit(F.C,L.fchb() + 8*FNW*(fi < nF ? fi : static_cast<uint32_t>(FNC))); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
-			int32_t firstnode = -1;
-			uint32_t fover = 0;
+			FEnum F; int32_t firstnode = -1; uint32_t fover = 0;
+			LEDGER_REP(11)
+			{
+			if ( lane == 0 ) L.ctr()[1] = 0;
+			wv_sync();
+			clInit(F.C,L.fchb() + 8*FNW*(fi < nF ? fi : static_cast<uint32_t>(FNC))); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
+			firstnode = -1;
+			fover = 0;
 			if ( fact )
 			{
 				uint32_t const saved = flags; flags = 0;
@@ -3233,6 +3265,10 @@ struct FastEngine
 				else flags |= saved;
 #if defined(DACC_EMUL)
 				{ FILE * f = ftrav_file(); if ( f ) fprintf(f,"T %d %u %u %u\n",int(CT::maxs),F.np,F.nfpop,fover); }
+#endif
+			}
+#if defined(DACC_LEDGER)
+			wv_sync();      // (the second run resets the chunk counter: every lane must have left the first)
 #endif
 			}
 			flags = wv_or(flags); if ( flags ) return false;
@@ -3271,6 +3307,9 @@ struct FastEngine
 				roundT0 = cfull ? L.cdh()[0].w : 0ull;
 				uint64_t live = 0;
 				static_assert(NPL <= 64,"one bit per pair of a round");
+				LEDGER_REP(12)
+				{
+				live = 0;
 				// phase A: classification; a pair that combines cached enumerations lists its matching pops (mode PM_PEND | number of matches)
 				LDSQ PSI * const HH = reinterpret_cast<LDSQ PSI *>(L.lscr());
 				uint32_t ntask = 0;
@@ -3355,6 +3394,7 @@ struct FastEngine
 				}
 				live = wv_or64(live);
 				wv_sync();
+				}
 				PROF(*this,5)
 				if ( lane == 0 ) pcount(27,1);
 				uint32_t q = 0;
@@ -3381,7 +3421,7 @@ struct FastEngine
 			fstart += nb; pskip = 0;
 		}
 		{ SITE_T0 materializeKept(); SITE(34) }      // the pools give way to the build-phase arrays
-		{ SITE_T0 restoreS(); SITE(25) }
+		{ SITE_T0 LEDGER_REP(13) restoreS(); SITE(25) }
 		PROF(*this,12)
 		// CDH -> CH -> ACC (:5099-5136) leaves the kept candidates in descending weight order.  With pairwise distinct
 		// weights that order does not depend on the heaps: one lane per candidate counts the heavier ones and stores its
@@ -3422,6 +3462,7 @@ struct FastEngine
 			L.acc()[c].o = c*CONSROW; L.acc()[c].l = len;
 		}
 		wv_sync();
+		LEDGER_REP(14)
 		for ( uint32_t t = lane; t < nc*mao; t += WSZ )
 		{
 			uint32_t const c = t / mao, j = t - c*mao;
@@ -3695,6 +3736,9 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 #endif
 	}
 	E.lane = wv_lane(); E.flags = 0; E.prof = B.prof;
+#if defined(DACC_LEDGER)
+	E.ledger = FB.ledger;
+#endif
 #if defined(DACC_PROFILE) && !defined(DACC_EMUL)
 	uint64_t * const prof = E.prof;
 #endif
@@ -3736,7 +3780,10 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	if ( B.P.w > 63 ) { FFAIL(1) }
 
 	DevOvl const * ov = B.ovl + pile.first_ovl;
-	uint32_t nact = 0;
+	uint32_t nact = 0, mao = 0, toolong = 0;
+	LEDGER_REPX(E,0)
+	{
+	nact = 0;
 	for ( uint32_t c = 0; c < pile.novl; c += WSZ )
 	{
 		uint32_t const z = c + lane;
@@ -3751,7 +3798,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	for ( uint32_t i = nact + lane; i < ap2; i += WSZ ) L.pre()[i] = ~0ull;
 	wv_sync();
 	wv_sort_keys<CT::precap>(L.pre(),nact);
-	uint32_t mao = 0;
+	mao = 0;
 	if ( nact )
 	{
 		uint64_t const nb = (B.P.maxalign > 0) ? (B.P.maxalign-1) : 0;
@@ -3760,7 +3807,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	if ( mao > CT::maxs ) { FFAIL(3) }
 	E.mao = mao; out.mao = mao;
 
-	uint32_t toolong = 0;
+	toolong = 0;
 	if ( mao )
 	{
 		// string descriptors, one lane per string (a single round of dependent HBM loads for the whole window):
@@ -3817,6 +3864,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 			}
 	}
 	wv_sync();
+	}
 	if ( toolong ) { FFAIL(4) }
 	PROF(E,0)
 
@@ -3824,7 +3872,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	if ( mao )
 	{
 		E.buildPeq();
-		elength = E.estimateLength()+1;
+		LEDGER_REPX(E,1) elength = E.estimateLength()+1;
 	}
 	out.elength = elength;
 	PROF(E,1)
@@ -3850,13 +3898,13 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				{
 					SITE_T0
 					if ( instsaved ) { E.restoreInstances(); SITE(27) }
-					else if ( !(hslot && !handloaded && E.loadHand(FB,hslot)) ) { E.buildInstances(); SITE(28) }      // handed over by the tier before: no second sort
+					else if ( !(hslot && !handloaded && E.loadHand(FB,hslot)) ) { LEDGER_REPX(E,2) E.buildInstances(); SITE(28) }      // handed over by the tier before: no second sort
 					else { SITE(30) }
 					handloaded = true;
 				}
 				if ( E.flags ) { FFAIL(7) }     // uniform: set from wave-uniform values only
 				PROF(E,2)
-				E.buildNodes(ff > 1 ? ff : 1);
+				LEDGER_REPX(E,3) E.buildNodes(ff > 1 ? ff : 1);
 				E.flags = wv_or(E.flags);
 				// the node table does not fit this tier (82 % of tier 1's hand-overs): the instances are sorted and valid, the next tier takes them
 				if ( E.flags ) { if ( handable ) hslot = E.saveHand(FB,hslot); FFAIL(7) }
@@ -3865,9 +3913,9 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				// candidate is a node (every reverse enumeration is empty): its three traversals (:2270-2322) are skipped.  The
 				// traversal structures then never overwrite the instance array, which the next pass takes over.
 				instvalid = false;
-				if ( ff != 0 && E.passIsDead() ) { instvalid = true; continue; }
-				if ( CT::gw != 0 && ff > B.P.minff && !instsaved ) { SITE_T0 E.saveInstances(); instsaved = true; SITE(29) }
-				E.buildSuccessors(mao);
+				{ bool dead_ = false; LEDGER_REPX(E,16) dead_ = (ff != 0 && E.passIsDead()); if ( dead_ ) { instvalid = true; continue; } }
+				if ( CT::gw != 0 && ff > B.P.minff && !instsaved ) { SITE_T0 LEDGER_REPX(E,17) E.saveInstances(); instsaved = true; SITE(29) }
+				LEDGER_REPX(E,4) E.buildSuccessors(mao);
 				PROF(E,4)
 				if ( ff == 0 )
 				{
@@ -3919,11 +3967,15 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 			out.status = WS_OK; out.conslen = bestlen; out.minrate = minrate;
 			PROF_T0
 			uint32_t nops = 0;
+			LEDGER_REPX(E,15)
+			{
+			nops = 0;
 			wv_sync();      // the alignment scratch may lie over the candidate buffers the lanes have just read (gw layout)
 			if ( lane == 0 ) nops = E.alignAndEmit(best,bestlen);
 			wv_sync();
 			nops = wv_bcast(nops,0);
 			E.emitRecord(best,nops,rec);
+			}
 			PROF(E,14)
 		}
 		else out.status = WS_FAILED;

@@ -27,6 +27,46 @@ def shard_piles(piles, g, G):
     return piles[(piles["aread"] >= a) & (piles["aread"] < b)]
 
 
+def preflight(device=None, device_index=None, dst=0):
+    """All ranks call, right after init_process_group and BEFORE anything expensive: one tiny all_gather and one point-to-point round on
+    the real backend -- the two primitives gather_fragments uses -- so that a missing rank, two ranks on one device, or a backend that
+    cannot send fails in seconds and says what it saw, not after minutes of data generation inside the first timed step.  Returns
+    {"ranks": [...], "devices": [...], "backend": ...} on every rank; raises RuntimeError with the ranks / devices seen otherwise."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"ranks": [0], "devices": [device_index], "backend": None}
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    me = torch.tensor([rank, -1 if device_index is None else int(device_index)], dtype=torch.int64, device=device)
+    seen = [torch.full((2,), -7, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(seen, me)
+    seen = torch.stack(seen).cpu().numpy()
+    ranks, devs = [int(x) for x in seen[:, 0]], [int(x) for x in seen[:, 1]]
+    if ranks != list(range(world)):
+        raise RuntimeError("preflight: all_gather over %s returned ranks %r, expected 0..%d" % (dist.get_backend(), ranks, world - 1))
+    if device_index is not None and str(device) != "cpu" and len(set(devs)) != world:
+        raise RuntimeError("preflight: %d ranks share devices %r -- RCCL needs one device per rank" % (world, devs))
+    # every rank sends 8 bytes (its rank, twice) to rank dst with batch_isend_irecv, as the gather does
+    msg = torch.tensor([rank, rank], dtype=torch.int32, device=device)
+    if rank != dst:
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, msg, dst)]):
+            q.wait()
+    else:
+        got = torch.full((world, 2), -1, dtype=torch.int32, device=device)
+        ops = [dist.P2POp(dist.irecv, got[r], r) for r in range(world) if r != dst]
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        got = got.cpu().numpy()
+        bad = [r for r in range(world) if r != dst and (int(got[r][0]) != r or int(got[r][1]) != r)]
+        if bad:
+            raise RuntimeError("preflight: point-to-point messages of ranks %r did not arrive intact at rank %d (got %r)" % (bad, dst, got.tolist()))
+    dist.barrier()
+    return {"ranks": ranks, "devices": devs, "backend": dist.get_backend(), "primitives": ["all_gather", "batch_isend_irecv"]}
+
+
 _pinned = {}
 
 
@@ -59,7 +99,7 @@ def _transport():
     return t
 
 
-def gather_fragments(frags, bases, device=None, dst=0, copy=False):
+def gather_fragments(frags, bases, device=None, dst=0, copy=False, force=False):
     """All ranks call.  Returns (frags, bases) of the whole job on rank `dst` (fragments in rank order, seq_off rebased
     onto the concatenated base buffer) and (None, None) elsewhere.  Without an initialised process group: identity.
 
@@ -70,11 +110,13 @@ def gather_fragments(frags, bases, device=None, dst=0, copy=False):
 
     ALIASING: the gathered `bases` is a memoryview of a module-level host buffer that the NEXT call overwrites; pass
     copy=True to get an owned bytes object when a result must outlive the next call.  Errors of the transport are raised, not
-    swallowed."""
+    swallowed.  `force`: do not short-cut a group of one rank."""
     global last_transport
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    # (force: run the whole path -- counts, message buffers, receive buffers, pinned copy, rebasing -- on a group of ONE rank too; the
+    # GPU suite drives the RCCL / device-buffer branch that way on a box with a single device, tests/test_shard_gloo.py)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         last_transport = "local"
         return frags, bases
     world, rank = dist.get_world_size(), dist.get_rank()

@@ -21,11 +21,11 @@ _SRCS = [os.path.join(_HERE, "emul", "emul.cpp")] + [os.path.join(_ROOT, "daccor
 
 def build(force=False):
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in _SRCS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-shared", "-o", _SO,
+        subprocess.check_call(["g++", "-O2", "-w", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-shared", "-o", _SO,
                                os.path.join(_HERE, "emul", "emul.cpp"),
                                os.path.join(_ROOT, "daccord_amd", "csrc", "host_tables.cpp")])
     if force or not os.path.exists(_SO64) or os.path.getmtime(_SO64) < max(os.path.getmtime(s) for s in _SRCS):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-shared", "-DDACC_EMUL_LANES=64",
+        subprocess.check_call(["g++", "-O2", "-w", "-std=c++17", "-fPIC", "-pthread", "-ffp-contract=off", "-shared", "-DDACC_EMUL_LANES=64",
                                "-DDACC_EMUL_IMPL", "-o", _SO64, os.path.join(_HERE, "emul", "emul.cpp"),
                                os.path.join(_ROOT, "daccord_amd", "csrc", "host_tables.cpp")])
     return _SO

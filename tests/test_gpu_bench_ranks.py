@@ -51,6 +51,9 @@ def test_eight_ranks_on_one_device_weak():
     live = eight["parity"]["live"]
     assert live["identical"] is True and live["oracle"]["identical"] is True and live["oracle"]["piles"] == 4, live
     assert live["reference_build"].get("identical", True) is True, live
+    # round 6: every rank samples ITS OWN shard, rank 0 collects the verdicts
+    assert live["all_ranks"] == {"ranks_reporting": 8, "ranks_identical": 8, "piles_total": 32, "identical_on_every_rank": True}, live
+    assert eight["preflight"]["ranks"] == list(range(8)) and eight["preflight"]["backend"] == "gloo", eight["preflight"]
     assert eight["n_gpus"] == 8 and eight["ranks"] == 8 and eight["gather"] == "p2p" and one["gather"] is None
     assert eight["parity"]["gpu_fasta_sha256_all"] == one["parity"]["gpu_fasta_sha256_all"]
     assert eight["config"]["corrected_bases_total"] == one["config"]["corrected_bases_total"] and eight["config"]["piles_rank0"] == 40

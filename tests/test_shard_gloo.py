@@ -69,6 +69,9 @@ def _worker_edge(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dt = np.dtype(DaccFragment)
+    # the preflight bench.py runs before it generates data: every rank sees every rank, on the backend's own primitives
+    pf = shard.preflight()
+    assert pf["ranks"] == list(range(world)) and pf["backend"] == "gloo", pf
     # rank 1 has nothing to contribute; the others have r+1 fragments of different lengths
     nf = 0 if rank == 1 else rank + 1
     f = np.zeros(nf, dtype=dt); bases = b""
@@ -148,3 +151,56 @@ def test_two_ranks_with_the_hip_engine():
         pr.join(timeout=120)
         assert pr.exitcode == 0
     assert same and n > 0 and 0 < nmine < 12
+
+
+def _worker_rccl1(q):
+    """ONE rank on the one GPU of the test box over the REAL backend (nccl = RCCL): what an 8-GPU node adds to the gloo tests above and no
+    CPU test can execute -- backend initialisation with a device id, device-resident message tensors, the all_gather of the counts on
+    RCCL, the device receive buffers, the copy into the pinned host buffer and the seq_off rebasing (gather_fragments(force=True));
+    the point-to-point sends need a second device and stay untested here."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from daccord_amd import shard
+    from daccord_amd._structs import DaccFragment
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        pf = shard.preflight("cuda", device_index=0)
+        dt = np.dtype(DaccFragment)
+        f = np.zeros(3, dtype=dt); bases = b""
+        for i in range(3):
+            s = bytes([65 + i]) * (100 + 7 * i)
+            f[i]["aread"] = i; f[i]["first"] = i; f[i]["last"] = i + len(s); f[i]["len"] = len(s); f[i]["seq_off"] = len(bases)
+            bases += s
+        F, B = shard.gather_fragments(f, bases, force=True)
+        ok = (shard.last_transport == "p2p" and bytes(B) == bases and F.tobytes() == f.tobytes())
+        F2, B2 = shard.gather_fragments(f[:0], b"", force=True)      # an empty shard
+        ok = ok and len(F2) == 0 and len(B2) == 0
+        q.put((ok, pf))
+        dist.destroy_process_group()
+    except Exception as ex:      # reported, not hung
+        q.put((False, repr(ex)))
+
+
+@pytest.mark.gpu
+def test_rccl_backend_with_device_buffers_on_one_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        pr = ctx.Process(target=_worker_rccl1, args=(q,))
+        pr.start()
+        ok, pf = q.get(timeout=300)
+        pr.join(timeout=120)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert ok, pf
+    assert pf["ranks"] == [0] and pf["devices"] == [0] and pf["backend"] == "nccl"
