@@ -94,7 +94,10 @@ template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 // are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
 // tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep
 // tier 2 (64 strings, 2048 instances) behind the deep tier.
-template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1536, rch = 4, fch = 4, fnw = 4, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 900, scap = 192, lcap = 1024, wcap = 1536, rccap = 192, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+// (round 6: the tier sat at 34 720 B, 6 KB below what four wavefronts per CU allow (40 960 B): the bytes went to what sends its windows on to
+// tier 3 -- ONE wavefront per CU -- on the ONT mix at small k (emulation, 6 piles of config 5 at k = 10 / 12: reverse pool 73 / 130, weights 53 / 1,
+// forward pool 45 / 7 of about 200 hand-overs): reverse pool 192 -> 256 paths in chunks of two, 248 stretches, 2048 weight records)
+template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 2048, rch = 2, fch = 8, fnw = 3, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 1024, scap = 248, lcap = 1280, wcap = 2048, rccap = 256, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)

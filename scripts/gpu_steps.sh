@@ -6,6 +6,7 @@
 #         ab:<reads>:<steps>:<lib>[;<lib>...]   one process per library (DACC_LIB), twice, "default" = the product
 #         pmc:<name>:<reads>:<env or ->:<counter>[,<counter>...]   one rocprofv3 --pmc pass of bench.py (--no-cpu, one step)
 #         counters       list of the counters the box offers
+#         ledger[:reads]  scripts/ledger.py: instruction / wave-time ledger by phase on daccord_amd/libvar_ledger.so
 #         bench[:args]   python bench.py [args with , for spaces]  -> bench_<n>.log
 #         stats          rocprofv3 --kernel-trace --stats of the default bench command
 R=$GRAFT_REPO_ROOT; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
@@ -42,6 +43,9 @@ for step in "$@"; do
       nb=$((nb+1)); a=$(echo "$rest" | tr ',' ' ')
       ( timeout 900 python bench.py $a ) > $O/bench_$nb.log 2>&1; echo "rc=$? args=$a" >> $O/bench_$nb.log
       grep '^{' $O/bench_$nb.log | tail -n 1 | python scripts/bench_brief.py ;;
+    ledger)
+      IFS=: read -r reads extra <<< "$rest"
+      ( timeout 1500 python scripts/ledger.py $O/ledger ${reads:-1500} $(echo $extra | tr ',' ' ') ) > $O/ledger.log 2>&1; echo "rc=$?" >> $O/ledger.log; tail -n 75 $O/ledger.log | cut -c1-230 ;;
     stats)
       ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python $R/bench.py --steps 1 --warmup 0 --no-cpu ) > $O/stats.log 2>&1; echo "rc=$?" >> $O/stats.log
       find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/rocprof_kernel_stats.csv \; ; rm -rf $O/stats; head -8 $O/rocprof_kernel_stats.csv | cut -c1-200 ;;

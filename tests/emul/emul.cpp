@@ -249,6 +249,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			FB[t].W = WB; FB[t].F = BP.ftier[t]; FB[t].dpsq_vst = c->H.dpsq_vst.data(); FB[t].retry = 0; FB[t].gearly = 0;
 			gslab[t].assign(BP.ftier[t].gbytes+64,arenafill); FB[t].gslab = gslab[t].data(); FB[t].gstride = 0; FB[t].tab32 = c->H.tab32.data();
 			FB[t].hand = handon ? hand.data() : 0; FB[t].handctr = &handctr; FB[t].handcap = handon ? static_cast<uint32_t>(BP.nwindows) : 0u; FB[t].handwords = handwords;
+#if defined(DACC_LEDGER)
+			{ char const * lm = getenv("DACC_LEDGER_MASK"); FB[t].ledger = lm ? static_cast<uint32_t>(strtoul(lm,0,0)) : 0u; }      // (ledger build: phases run twice, results must not move)
+#endif
 			lds[t].assign(BP.ftier[t].ldsbytes+64,arenafill);
 			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftier[t].tabcap;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
@@ -262,6 +265,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			FB0.W = WB; FB0.F = BP.ftier0; FB0.dpsq_vst = c->H.dpsq_vst.data(); FB0.retry = 0; FB0.gearly = 0;
 			gslab0.assign(BP.ftier0.gbytes+64,arenafill); FB0.gslab = gslab0.data(); FB0.gstride = 0; FB0.tab32 = c->H.tab32.data();
 			FB0.hand = handon ? hand.data() : 0; FB0.handctr = &handctr; FB0.handcap = handon ? static_cast<uint32_t>(BP.nwindows) : 0u; FB0.handwords = handwords;
+#if defined(DACC_LEDGER)
+			{ char const * lm = getenv("DACC_LEDGER_MASK"); FB0.ledger = lm ? static_cast<uint32_t>(strtoul(lm,0,0)) : 0u; }
+#endif
 			lds0.assign(BP.ftier0.ldsbytes+64,arenafill);
 			wave_run([&]() { FastLds< FastTier<0> > L; L.base = lds0.data(); fast_load_tables(L,BP.ftier0.nrows,BP.ftier0.nsup,T,c->H.dpsq_vst.data()); });
 		}
@@ -347,6 +353,9 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		// the library's launch on the second stream (k_window_long): tier 5 (strings of up to 128 bases) first, the generic
 		// engine for what it cannot hold
 		FastBatch FBL; FBL.W = WB; FBL.W.pregen = 0; FBL.F = BP.ftierL; FBL.dpsq_vst = c->H.dpsq_vst.data(); FBL.retry = 0; FBL.gearly = 0; FBL.gslab = 0; FBL.gstride = 0; FBL.tab32 = c->H.tab32.data(); FBL.hand = 0; FBL.handctr = 0; FBL.handcap = 0; FBL.handwords = 0;
+#if defined(DACC_LEDGER)
+		FBL.ledger = 0;
+#endif
 		std::vector<uint8_t> ldsL(BP.ftierL.ldsbytes+64,arenafill);
 		bool const longok = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap;
 		auto loadTablesL = [&]() { wave_run([&]() { FastLds< FastTier<5> > L; L.base = ldsL.data(); fast_load_tables(L,BP.ftierL.nrows,BP.ftierL.nsup,T,c->H.dpsq_vst.data()); }); };
