@@ -83,7 +83,7 @@ template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
 template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
-enum : uint32_t { T0INST_DEFAULT = 560 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
+enum : uint32_t { T0INST_DEFAULT = 576 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 // (round 4: 76 KB = 2 wavefronts per CU instead of 46.5 KB = 3, with tier 3's node capacity: at 54x more than half of what the deep tier
@@ -1126,6 +1126,7 @@ struct FastEngine
 		// walk every stretch once: the nodes go to a scratch slot of WSLOT entries per stretch in the (not yet used) weight
 		// arrays and are compacted into `links` below; a stretch without a slot or longer than it is walked a second time
 		enum { WSLOT = 64 };
+		// (round 6, measured and dropped: walking every stretch twice instead of sending its nodes through the slab: 0.4 % slower, profiles/r06f)
 		uint32_t const nslot = FastLds<CT>::xnslot;     // legacy: the walking table sits behind the slots; gw: slots in the global slab
 		for ( uint32_t q = lane; q < ns; q += WSZ )
 		{
@@ -2243,6 +2244,8 @@ struct FastEngine
 		}
 		LDSQ uint64_t const * W = L.f_w();
 		SITE(11)      // forward tree: the root's extensions
+		// (round 6, measured and dropped: starting a bucket's scan behind the leading entries whose base lengths are already drained -- three
+		// more registers and a compare per group of four made the window kernels 0.6 % slower, profiles/r06d)
 		while ( F.m0 | F.m1 )
 		{
 			uint32_t const zz = F.m0 ? static_cast<uint32_t>(__builtin_ctzll(F.m0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(F.m1));
@@ -3008,6 +3011,22 @@ struct FastEngine
 	static_assert(sizeof(PSI)*PSIQ*NPL <= FastLds<CT>::lscrbytes && 2u*POUTE*NPL <= 32u*32u,"score interval heaps and pop records of a round of pairs");
 	enum : uint32_t { MIDCAP = 8 };
 	uint32_t nmid, midbase;              // middle pieces of this activation state: pool ids midbase .. midbase+nmid-1
+	// pair p of a batch -> (first k-mer candidate p / nL, last k-mer candidate p % nL): one multiplication by ceil(2^32 / nL) (exact while
+	// p * nL < 2^32) instead of a 32 bit division -- some 25 VALU instructions -- per pair and phase, and per live pair on lane 0
+	uint32_t nLmagic;
+	DEV void pairFL(uint32_t const p, uint32_t & f, uint32_t & l) const
+	{
+		if ( nL <= 1 ) { f = p; l = 0; }
+		else
+		{
+#if defined(DACC_EMUL)
+			f = static_cast<uint32_t>((static_cast<uint64_t>(p) * nLmagic) >> 32);
+#else
+			f = __umulhi(p,nLmagic);
+#endif
+			l = p - f*nL;
+		}
+	}
 	uint32_t rstop;                      // sorted reverse entries used by the cached blocks
 	uint64_t roundT0;                    // lightest weight of the (full) candidate heap when the current round of pairs began
 	uint32_t nsiq, ncdh, nacc;
@@ -3068,7 +3087,7 @@ struct FastEngine
 			FSTAT_ADD(13,1);
 			if ( mode == PM_SKIP ) { FSTAT_ADD(14,1); continue; }
 			uint32_t const p = p0+q;
-			uint32_t const fi = fstart + p/nL, li = p%nL;
+			uint32_t fi, li; pairFL(p,fi,li); fi += fstart;
 			if ( mode < 0x40 || mode == PM_SERIAL )
 			{
 				// no candidate of this pair can beat the lightest kept candidate: score <= path weight + reverse weight
@@ -3170,6 +3189,7 @@ struct FastEngine
 		PROF(*this,8)
 		LEDGER_REP(6) findCandidatesAndPieces();
 		flags = wv_or(flags); if ( flags ) return false;
+		nLmagic = nL > 1 ? static_cast<uint32_t>(((1ull<<32) + nL - 1u) / nL) : 0u;
 #if !defined(DACC_NO_REACH)
 		{
 			SITE_T0
@@ -3323,7 +3343,7 @@ struct FastEngine
 					if ( t < nround )
 					{
 						uint32_t const p = p0 + t;
-						uint32_t const pfi = fstart + p/nL, pli = p%nL;
+						uint32_t pfi, pli; pairFL(p,pfi,pli); pfi += fstart;
 						SITE_T0
 						uint32_t const cl = classifyPair(pfi,pli,lmax);
 						SITE(26)      // pair generation: classification of a pair (cached enumerations valid?)
@@ -3367,7 +3387,7 @@ struct FastEngine
 						{
 							uint32_t const en = TL[q], t = en & 63u, j = en >> 6;
 							uint32_t const p = p0 + t;
-							uint32_t const pfi = fstart + p/nL, pli = p%nL;
+							uint32_t pfi, pli; pairFL(p,pfi,pli); pfi += fstart;
 							ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
 							if ( !intervalTask(FC,L.rbase()[pli],L.rn()[pli],lmin,lmax,HH + PSIQ*t + j) ) L.poutn()[t] = PM_SERIAL;
 						}
@@ -3381,7 +3401,7 @@ struct FastEngine
 					if ( (mode & 0xF0u) == PM_PEND )
 					{
 						uint32_t const p = p0 + t;
-						uint32_t const pfi = fstart + p/nL, pli = p%nL;
+						uint32_t pfi, pli; pairFL(p,pfi,pli); pfi += fstart;
 						ChunkList<FNW> FC; forwardTreeLoad(FC,pfi);
 						uint32_t cnt;
 						if ( flat && (mode & 0x0Fu) != 15u )
@@ -3404,6 +3424,13 @@ struct FastEngine
 				while ( true )
 				{
 					uint32_t req = 0;
+					// (round 6, measured and dropped: the replay with every lane in uniform control flow, the candidate heap cached in registers --
+					// entry i in lane i, v_readlane in the sift chains -- and a pair's recorded entries fetched by one lane each.  Bit-identical
+					// on the 64-lane emulation and on tiers 0 / 1 / 6 of the device, 0.45 % faster there (725.3 -> 722.0 ms at 3000 reads,
+					// profiles/r06e): the regular replay is 5 % of a window, not the 13 % the probe-inflated site ledger of round 5 showed.  And
+					// WRONG in the deep tiers: a register that holds a different value in every lane and is read with v_readlane does not survive
+					// the allocator's spill / reload or live-range copies inside a divergent region (they move the ACTIVE lanes only), and
+					// k_window_fast<4|2|3> spill -- test_deep_batch_starts_in_the_deep_tier failed on the device while the emulation passed.)
 					if ( lane == 0 ) { lscrdirty = false; req = replayRound(q,nround,p0,fstart,lmin,lmax,nb == 1,live); }
 					wv_sync();
 					flags = wv_bcast(flags,0); if ( flags ) return false;
@@ -3696,6 +3723,7 @@ enum { FW_DONE = 0, FW_NEXT = 1, FW_GENERIC = 2 };
 // window may keep fewer, `maxalign`), so a window classed small can still overflow tier 0 and is then handed on like any other.
 DEV uint32_t classifyWindow(WindowBatch const & B, uint64_t const widx, uint32_t const t0inst)
 {
+	// (round 6, measured and dropped: the pile index from a table filled by a pre-pass instead of this search -- no difference, profiles/r06d)
 	uint32_t lo = 0, hi = B.npiles;
 	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
 	DevPile const pile = B.piles[lo];
@@ -3727,7 +3755,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 #endif
 	if ( B.pregen && ((B.pregen[widx>>5] >> (widx&31)) & 1) ) return FW_DONE;      // the generic engine has this window (a string longer than 64 bases)
 	E.mao = 0; E.k = 0; E.kmask = 0; E.npre = E.nlast = E.nn = E.nmfirst = E.nmlast = 0; E.n0 = E.npool = E.nlinks = E.nwF = E.nwR = 0; E.nF = E.nL = 0;
-	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pvpath = E.pvrp = E.pvnf = 0; E.pvcl = 0; E.nmid = 0; E.midbase = 0;
+	E.nsiq = E.ncdh = E.nacc = 0; E.rstop = 0; E.roundT0 = 0; E.cfree = 0; E.pvpath = E.pvrp = E.pvnf = 0; E.pvcl = 0; E.nmid = 0; E.midbase = 0; E.nLmagic = 0;
 	E.T = B.T; E.P = B.P; E.nrows = FB.F.nrows; E.nsup = FB.F.nsup; E.vst = FB.dpsq_vst;
 	E.gslab = 0; E.gtab = FB.tab32; E.sfresh = true; E.sdirty = false;
 	if ( CT::gw )
@@ -3770,6 +3798,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	int32_t const startff = curff;
 	#define FFAIL(code) { if ( lane == 0 ) { B.wout[widx].status = WS_RETRY; B.wout[widx].flags = ((code)<<24) | (E.flags & 0xFFFFFF); B.wout[widx].filterfreq = curff; B.wout[widx].minrate = hslot; } return ((code) == 1 || (code) == 4) ? FW_GENERIC : FW_NEXT; }
 
+	// (round 6, measured and dropped: the pile index from a table filled by a pre-pass instead of this search -- no difference, profiles/r06d)
 	uint32_t lo = 0, hi = B.npiles;
 	while ( hi-lo > 1 ) { uint32_t const mid = (lo+hi)>>1; if ( B.piles[mid].winbase <= widx ) lo = mid; else hi = mid; }
 	DevPile const pile = B.piles[lo];
