@@ -35,7 +35,8 @@ class DaccTiming(C.Structure):
                 ("d2h_ms", C.c_float), ("total_ms", C.c_float), ("nwindows", C.c_uint64), ("nblocks", C.c_uint64),
                 ("algo_bytes", C.c_uint64), ("tier_ms", C.c_float * 3), ("tier_out", C.c_uint32 * 3),
                 ("first_tier", C.c_uint32), ("long_windows", C.c_uint32), ("tier0_ms", C.c_float), ("tier0_in", C.c_uint32),
-                ("tier0_out", C.c_uint32), ("long_first_tier", C.c_uint32)]
+                ("tier0_out", C.c_uint32), ("tier7_ms", C.c_float), ("tier7_in", C.c_uint32), ("tier7_out", C.c_uint32), ("pad_", C.c_uint32),
+                ("long_first_tier", C.c_uint32)]
 
 
 class DaccWindowResult(C.Structure):

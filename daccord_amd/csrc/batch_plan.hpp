@@ -60,6 +60,7 @@ struct BatchPlan
 	enum { NTIER = 3 };
 	FastCaps ftier[NTIER];    // LDS fast path capacity tiers: 3, 2, 1 wavefronts per CU
 	FastCaps ftier0;          // tier 0: small windows of shallow batches (size classes), runs in the first slot in front of tier 1
+	FastCaps ftier7;          // tier 7: the middle size class (7 wavefronts per CU), between tier 0 and tier 1
 	FastCaps ftierL;          // tier 5: windows with a string of 65..128 bases (second stream, before the generic engine)
 	uint64_t ndeepwin;        // windows with more strings / k-mer instances than the first tier of shallow batches holds
 	bool deep;                // most windows are deep: the first tier is FastTier<4> (many strings, small graph) instead of FastTier<1>
@@ -321,6 +322,7 @@ struct BatchPlan
 		ftier[0] = deep ? fastCapsOf< FastTier<4> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
 		ftier[1] = deep ? fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<6> >(tab_nrows,tab_nsup);
 		ftier0 = fastCapsOf< FastTier<0> >(tab_nrows,tab_nsup);
+		ftier7 = fastCapsOf< FastTier<7> >(tab_nrows,tab_nsup);
 		ftierL = fastCapsOf< FastTier<5> >(tab_nrows,tab_nsup);
 		ftier[2] = fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;

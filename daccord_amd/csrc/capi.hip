@@ -147,27 +147,31 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t const v, uint32_t *
 	return MAXOP ? (excl > base ? excl : base) : (base + excl);
 }
 
-// Size classes (shallow batches): one thread per window decides from the window tables whether the window starts in tier 0
-// (small list) or in tier 1 (big list = the list tier 0 appends its hand-overs to); windows the pre-scan set aside are in neither.
-// Blocks reserve their range of a list with one atomic each, so a list keeps the window order inside a block.
-__global__ void __launch_bounds__(256) k_classify(WindowBatch B, uint32_t * small, uint32_t * big, uint32_t const t0inst)
+// Size classes (shallow batches): one thread per window decides from the window tables whether the window starts in tier 0 (small list),
+// in tier 7 (middle list = the list tier 0 appends its hand-overs to; round 6) or in tier 1 (big list = the list tier 7 appends its
+// hand-overs to); windows the pre-scan set aside are in none.  Blocks reserve their range of a list with one atomic each, so a list keeps
+// the window order inside a block.  t7inst == 0: no middle class.
+__global__ void __launch_bounds__(256) k_classify(WindowBatch B, uint32_t * small, uint32_t * mid, uint32_t * big, uint32_t const t0inst, uint32_t const t7inst)
 {
-	__shared__ uint32_t part4[4]; __shared__ uint32_t base2[2];
+	__shared__ uint32_t part4[4]; __shared__ uint32_t base3[3];
 	uint64_t const w = static_cast<uint64_t>(blockIdx.x)*256 + threadIdx.x;
-	uint32_t cls = 2;
+	uint32_t cls = 3;
 	if ( w < B.nwindows && !(B.pregen && ((B.pregen[w>>5] >> (w&31)) & 1)) )
 	{
-		cls = classifyWindow(B,w,t0inst);
+		cls = classifyWindow(B,w,t0inst,t7inst);
 		B.wout[w].status = WS_INSUFFICIENT;      // never WS_RETRY from an earlier batch: the tiers resume from a hand-over record
 	}
-	uint32_t tot0, tot1;
+	uint32_t tot0, tot1, tot2;
 	uint32_t const p0 = block_scan_excl<false>(cls == 0 ? 1u : 0u,part4,tot0);
 	__syncthreads();
 	uint32_t const p1 = block_scan_excl<false>(cls == 1 ? 1u : 0u,part4,tot1);
-	if ( threadIdx.x == 0 ) { base2[0] = tot0 ? atomicAdd(small,tot0) : 0u; base2[1] = tot1 ? atomicAdd(big,tot1) : 0u; }
 	__syncthreads();
-	if ( cls == 0 ) small[1+base2[0]+p0] = static_cast<uint32_t>(w);
-	if ( cls == 1 ) big[1+base2[1]+p1] = static_cast<uint32_t>(w);
+	uint32_t const p2 = block_scan_excl<false>(cls == 2 ? 1u : 0u,part4,tot2);
+	if ( threadIdx.x == 0 ) { base3[0] = tot0 ? atomicAdd(small,tot0) : 0u; base3[1] = tot1 ? atomicAdd(big,tot1) : 0u; base3[2] = tot2 ? atomicAdd(mid,tot2) : 0u; }
+	__syncthreads();
+	if ( cls == 0 ) small[1+base3[0]+p0] = static_cast<uint32_t>(w);
+	if ( cls == 1 ) big[1+base3[1]+p1] = static_cast<uint32_t>(w);
+	if ( cls == 2 ) mid[1+base3[2]+p2] = static_cast<uint32_t>(w);
 }
 
 
@@ -340,11 +344,11 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
-	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_lds_t0, env_t0inst;     // debugging knobs, read once in dacc_create
+	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_lds_t0, env_t0inst, env_t7inst;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<int32_t> pile_status; std::vector<std::string> pile_errors; std::string pile_errors_joined;
@@ -402,13 +406,14 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	std::memset(&c->timing,0,sizeof(c->timing));
 	// launch geometry of the LDS tiers: set by every batch that uses them; a generic-only batch (DACC_NOFAST, w >= 64, a model table no
 	// tier holds) reads retry_grid in its scratch retry and must not find an indeterminate value there
-	c->retry_grid = c->early_grid = c->win_grid = 0; c->tier0_grid = 0; c->tier0_ok = false; c->tier0_ran = false; c->tierL_ok = 0; c->usefast = 0; c->sched = 0;
+	c->retry_grid = c->early_grid = c->win_grid = 0; c->tier0_grid = 0; c->tier0_ok = false; c->tier0_ran = false; c->tier7_grid = 0; c->tier7_ok = false; c->tier7_ran = false; c->gstride7 = 0; c->tierL_ok = 0; c->usefast = 0; c->sched = 0;
 	for ( int i = 0; i < 3; ++i ) { c->tier_grid[i] = 0; c->tier_ok[i] = 0; c->tier_out[i] = 0; c->gstride[i] = 0; }
 	c->gstride0 = 0; c->tr_grid = c->tr_lds = c->tr_words = c->tr_lanes = c->trace_bytes = 0;
 	{
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
-		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 15;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes)
+		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 31;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes), bit 4 tier 7 (the middle class; needs tier 0)
+		char const * t7 = getenv("DACC_T7INST"); c->env_t7inst = t7 ? static_cast<uint32_t>(atoi(t7)) : static_cast<uint32_t>(T7INST_DEFAULT);      // size-class threshold of tier 7
 		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
 		char const * l0 = getenv("DACC_LDS_T0"); c->env_lds_t0 = l0 ? static_cast<uint32_t>(atoi(l0)) : 0u;      // the same for tier 0 (size classes)
 		char const * t0 = getenv("DACC_T0INST"); c->env_t0inst = t0 ? static_cast<uint32_t>(atoi(t0)) : static_cast<uint32_t>(T0INST_DEFAULT);      // size-class threshold (k-mer instances) of tier 0
@@ -419,7 +424,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming); hipEventCreateWithFlags(&c->evPrescan,hipEventDisableTiming);
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
 	for ( int i = 0; i < 3; ++i ) hipEventCreate(&c->evtier[i]);
-	hipEventCreate(&c->evT0); c->tier0_ran = false;
+	hipEventCreate(&c->evT0); c->tier0_ran = false; hipEventCreate(&c->evT7);
 	*out = c;
 	return DACC_OK;
 }
@@ -433,10 +438,10 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release(); c->d_hand.release(); c->d_handctr.release();
+	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release(); c->d_mid.release(); c->d_hand.release(); c->d_handctr.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
-	hipEventDestroy(c->evT0);
+	hipEventDestroy(c->evT0); hipEventDestroy(c->evT7);
 	delete c;
 }
 
@@ -551,7 +556,7 @@ static int runDevice(dacc_ctx * c)
 		// no LDS tier usable (DACC_TIERS=0 or a model table no tier's overlay holds): everything runs in the generic engine on
 		// the main stream; the pre-scan / second stream would hand the same windows to two kernels
 		bool const anytier = c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2];
-		c->tier0_ran = false;
+		c->tier0_ran = false; c->tier7_ran = false;
 		if ( c->usefast && anytier )
 		{
 			// windows only the generic engine can run (a string longer than 64 bases): found by a scan of the window tables and
@@ -619,12 +624,23 @@ static int runDevice(dacc_ctx * c)
 					if ( t == 0 && BP.deep ) hipLaunchKernelGGL(k_window_fast<4>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 0 && c->tier0_ok )
 					{
-						// size classes: the small windows run in tier 0 (8 wavefronts per CU), its hand-overs and all other windows in tier 1
+						// size classes: the small windows run in tier 0 (8 wavefronts per CU), the middle class and tier 0's hand-overs in tier 7
+						// (7 per CU), tier 7's hand-overs and all other windows in tier 1 (6 per CU)
 						HIPCHK(hipMemsetAsync(c->d_small.p,0,sizeof(uint32_t),s)); HIPCHK(hipMemsetAsync(c->d_big.p,0,sizeof(uint32_t),s));
-						hipLaunchKernelGGL(k_classify,dim3((BP.nwindows+255)/256),dim3(256),0,s,WB,c->d_small.p,c->d_big.p,c->env_t0inst);
-						FastBatch F0 = FB; F0.F = BP.ftier0; F0.retry = c->d_big.p; F0.gstride = c->gstride0;
+						if ( c->tier7_ok ) HIPCHK(hipMemsetAsync(c->d_mid.p,0,sizeof(uint32_t),s));
+						uint32_t * const midlist = c->tier7_ok ? c->d_mid.p : c->d_big.p;
+						hipLaunchKernelGGL(k_classify,dim3((BP.nwindows+255)/256),dim3(256),0,s,WB,c->d_small.p,midlist,c->d_big.p,c->env_t0inst,c->tier7_ok ? c->env_t7inst : 0u);
+						// (what the pre-pass itself put on the middle and the big list, before the tiers' hand-overs join them: for the counters of dacc_timing)
+						if ( c->tier7_ok ) { HIPCHK(hipMemcpyAsync(c->d_work.p+56,c->d_mid.p,sizeof(uint32_t),hipMemcpyDeviceToDevice,s)); HIPCHK(hipMemcpyAsync(c->d_work.p+57,c->d_big.p,sizeof(uint32_t),hipMemcpyDeviceToDevice,s)); }
+						FastBatch F0 = FB; F0.F = BP.ftier0; F0.retry = midlist; F0.gstride = c->gstride0;
 						hipLaunchKernelGGL(k_window_fast<0>,dim3(c->tier0_grid),dim3(64),F0.F.ldsbytes,s,F0,static_cast<uint32_t const *>(c->d_small.p),(c->sched&1) ? c->d_work.p+40 : static_cast<uint32_t *>(0));
 						HIPCHK(hipEventRecord(c->evT0,s)); c->tier0_ran = true;
+						if ( c->tier7_ok )
+						{
+							FastBatch F7 = FB; F7.F = BP.ftier7; F7.retry = c->d_big.p; F7.gstride = c->gstride7;
+							hipLaunchKernelGGL(k_window_fast<7>,dim3(c->tier7_grid),dim3(64),F7.F.ldsbytes,s,F7,static_cast<uint32_t const *>(c->d_mid.p),(c->sched&1) ? c->d_work.p+48 : static_cast<uint32_t *>(0));
+							HIPCHK(hipEventRecord(c->evT7,s)); c->tier7_ran = true;
+						}
 						hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,static_cast<uint32_t const *>(c->d_big.p),work);
 					}
 					else if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
@@ -698,20 +714,35 @@ static int runDevice(dacc_ctx * c)
 	{ int const rc = voteAndFetch(); if ( rc ) return rc; }
 	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpy(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost));
-	c->timing.tier0_in = 0; c->timing.tier0_out = 0;
+	c->timing.tier0_in = 0; c->timing.tier0_out = 0; c->timing.tier7_in = 0; c->timing.tier7_out = 0;
 	if ( c->usefast && BP.nwindows && (c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2]) )
 	{
 		// length of the two lists of the second stream (pre-scan, first tier's generic-only windows), fetched before their launches
 		uint32_t const n1 = c->nlong[0], n2 = c->nlong[1];
 		c->timing.long_windows = n1 + n2; c->timing.long_first_tier = n2;
+		c->timing.tier7_in = 0; c->timing.tier7_out = 0;
 		if ( c->tier0_ran )
 		{
-			// size classes: the pre-pass sent nsmall windows to tier 0 and nwindows - nsmall - n1 to the big list, which tier 0's
-			// hand-overs have joined since
-			uint32_t nsmall = 0, nbig = 0;
+			// size classes: the pre-pass sent nsmall windows to tier 0, nmid0 to the middle list and nwindows - nsmall - nmid0 - n1 to the big
+			// list; tier 0's hand-overs have joined the middle list since (the big list without tier 7), tier 7's the big list
+			uint32_t nsmall = 0, nbig = 0, nmid = 0;
 			HIPCHK(hipMemcpy(&nsmall,c->d_small.p,sizeof(uint32_t),hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(&nbig,c->d_big.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
-			uint64_t const big0 = BP.nwindows - std::min<uint64_t>(BP.nwindows,static_cast<uint64_t>(nsmall) + n1);
-			c->timing.tier0_in = nsmall; c->timing.tier0_out = nbig > big0 ? static_cast<uint32_t>(nbig - big0) : 0u;
+			if ( c->tier7_ran ) HIPCHK(hipMemcpy(&nmid,c->d_mid.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+			c->timing.tier0_in = nsmall;
+			if ( !c->tier7_ran )
+			{
+				uint64_t const big0 = BP.nwindows - std::min<uint64_t>(BP.nwindows,static_cast<uint64_t>(nsmall) + n1);
+				c->timing.tier0_out = nbig > big0 ? static_cast<uint32_t>(nbig - big0) : 0u;
+			}
+			else
+			{
+				// nmid = what the pre-pass put on the middle list + tier 0's hand-overs, nbig = the pre-pass's big windows + tier 7's hand-overs
+				uint32_t pre[2] = {0,0};
+				HIPCHK(hipMemcpy(pre,c->d_work.p+56,2*sizeof(uint32_t),hipMemcpyDeviceToHost));
+				uint32_t const t7out = nbig > pre[1] ? nbig - pre[1] : 0u;
+				c->timing.tier0_out = nmid > pre[0] ? nmid - pre[0] : 0u;
+				c->timing.tier7_in = nmid; c->timing.tier7_out = t7out;
+			}
 		}
 	}
 	// a window the generic engine could not hold (dense graph at small k): grow its scratch capacities and run those
@@ -774,6 +805,8 @@ static int runDevice(dacc_ctx * c)
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) { hipEventElapsedTime(&ms,i ? c->evtier[i-1] : c->ev[1],c->evtier[i]); c->timing.tier_ms[i] = ms; }
 	c->timing.tier0_ms = 0;
 	if ( c->tier0_ran ) { hipEventElapsedTime(&ms,c->ev[1],c->evT0); c->timing.tier0_ms = ms; }
+	c->timing.tier7_ms = 0; c->timing.pad_ = 0;
+	if ( c->tier7_ran ) { hipEventElapsedTime(&ms,c->evT0,c->evT7); c->timing.tier7_ms = ms; }
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
@@ -891,6 +924,17 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 				HIPCHK(c->d_small.ensure(BP.nwindows+2)); HIPCHK(c->d_big.ensure(BP.nwindows+2));
 				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg0)*F0.gbytes + 256));
 			}
+			// tier 7 (the middle size class, 7 wavefronts per CU) between them: DACC_TIERS bit 4 switches it off
+			FastCaps const & F7 = BP.ftier7;
+			c->tier7_ok = c->tier0_ok && ((c->env_tiers>>4)&1) && F7.ldsbytes <= 160*1024 && c->env_t7inst > c->env_t0inst;
+			uint64_t percu7 = (160*1024) / (F7.ldsbytes ? F7.ldsbytes : 1); if ( percu7 > 8 ) percu7 = 8; if ( percu7 < 1 ) percu7 = 1;
+			uint64_t fg7 = ((BP.nwindows+7)/8)*8; if ( fg7 > 256*percu7 ) fg7 = 256*percu7; if ( fg7 < 8 ) fg7 = 8;
+			c->tier7_grid = static_cast<uint32_t>(fg7); c->gstride7 = F7.gbytes;
+			if ( c->tier7_ok )
+			{
+				HIPCHK(c->d_mid.ensure(BP.nwindows+2));
+				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg7)*F7.gbytes + 256));
+			}
 		}
 		{
 			// hand-over slots (sorted instances of a window that overflowed a tier's node table, picked up by the next tier): header +
@@ -933,7 +977,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 		c->win_grid = boundByArena(wg,BP.caps.bytes,8);
 		c->retry_grid = c->win_grid; c->early_grid = 0;
 		for ( int t = 0; t < 3; ++t ) c->tier_ok[t] = 0;
-		c->tier0_ok = false; c->tierL_ok = 0;
+		c->tier0_ok = false; c->tier7_ok = false; c->tierL_ok = 0;
 		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->win_grid)*BP.caps.bytes));
 	}

@@ -83,7 +83,11 @@ template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
 template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
-enum : uint32_t { T0INST_DEFAULT = 576 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
+// tier 7 (round 6, the MIDDLE size class of shallow batches): 22.9 KB = 7 wavefronts per CU.  Four fifths of the windows tier 1 (6 per CU)
+// used to run have at most 28 strings, 704 k-mer instances, 640 nodes and 800 links (emulation, 16 piles of config 2: 4244 of 5295); the
+// pre-pass sends them here, what overflows joins tier 1's list like tier 0's hand-overs join this one.
+template<> struct FastTier<7> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 896, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 704, ncap = 640, scap = 104, lcap = 800, wcap = 896, rccap = 112, fcap = 148, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+enum : uint32_t { T0INST_DEFAULT = 576, T7INST_DEFAULT = 704 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
 // (round 4: 76 KB = 2 wavefronts per CU instead of 46.5 KB = 3, with tier 3's node capacity: at 54x more than half of what the deep tier
@@ -3721,7 +3725,7 @@ enum { FW_DONE = 0, FW_NEXT = 1, FW_GENERIC = 2 };
 // Size class of a window (pre-pass of shallow batches): 0 = small (starts in tier 0), 1 = the rest (starts in tier 1).  An
 // upper bound of the number of k-mer instances at the smallest k from the window tables: every active overlap counts (the
 // window may keep fewer, `maxalign`), so a window classed small can still overflow tier 0 and is then handed on like any other.
-DEV uint32_t classifyWindow(WindowBatch const & B, uint64_t const widx, uint32_t const t0inst)
+DEV uint32_t classifyWindow(WindowBatch const & B, uint64_t const widx, uint32_t const t0inst, uint32_t const t7inst = 0)
 {
 	// (round 6, measured and dropped: the pile index from a table filled by a pre-pass instead of this search -- no difference, profiles/r06d)
 	uint32_t lo = 0, hi = B.npiles;
@@ -3742,7 +3746,10 @@ DEV uint32_t classifyWindow(WindowBatch const & B, uint64_t const widx, uint32_t
 		}
 	uint64_t const nb = (B.P.maxalign > 0) ? (B.P.maxalign-1) : 0;
 	uint32_t const mao = 1 + static_cast<uint32_t>(nact < nb ? nact : nb);
-	return (mao <= FastTier<0>::maxs && inst <= t0inst && B.P.w <= 63) ? 0u : 1u;
+	// 0: tier 0, 1: the rest (tier 1), 2: the middle class (tier 7; only with a threshold for it)
+	if ( mao <= FastTier<0>::maxs && inst <= t0inst && B.P.w <= 63 ) return 0u;
+	if ( t7inst && mao <= FastTier<7>::maxs && inst <= t7inst && B.P.w <= 63 ) return 2u;
+	return 1u;
 }
 
 template<typename CT>

@@ -90,5 +90,6 @@ extern template __global__ void k_window_fast<2>(FastBatch, uint32_t const *, ui
 extern template __global__ void k_window_fast<3>(FastBatch, uint32_t const *, uint32_t *);
 extern template __global__ void k_window_fast<4>(FastBatch, uint32_t const *, uint32_t *);
 extern template __global__ void k_window_fast<6>(FastBatch, uint32_t const *, uint32_t *);
+extern template __global__ void k_window_fast<7>(FastBatch, uint32_t const *, uint32_t *);
 #endif
 #endif

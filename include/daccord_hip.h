@@ -181,6 +181,10 @@ typedef struct dacc_timing {
 	float tier0_ms;          /* size classes (shallow batches): pre-pass + k_window_fast<0>, the part of tier_ms[0] in front of k_window_fast<1>; 0 if tier 0 did not run */
 	uint32_t tier0_in;       /* windows the pre-pass sent to tier 0 */
 	uint32_t tier0_out;      /* windows tier 0 handed on to tier 1 */
+	float tier7_ms;          /* round 6, the middle size class: k_window_fast<7> (7 wavefronts per CU) between tier 0 and tier 1; 0 if it did not run */
+	uint32_t tier7_in;       /* windows tier 7 ran: the pre-pass's middle class + tier 0's hand-overs (tier0_out) */
+	uint32_t tier7_out;      /* windows tier 7 handed on to tier 1 */
+	uint32_t pad_;
 	uint32_t long_first_tier; /* of long_windows: the windows the FIRST tier found no LDS tier can run (they ran in k_window_long behind it; the rest are the pre-scan's) */
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);

@@ -36,7 +36,8 @@ def main():
             h.update(engine.fasta(fr[i:i + 256], ba, start_well=well).encode()); well += len(fr[i:i + 256])
         print(json.dumps({"setting": setting, "ms_per_step": round(1e3 * dt, 2), "mbase_s": round(len(ba) / dt / 1e6, 3),
                           "window_ms": round(win / steps, 2), "tier_ms": [round(x / steps, 2) for x in tier],
-                          "handed_on": [int(t.tier_out[i]) for i in range(3)], "sha": h.hexdigest()[:16]}), flush=True)
+                          "handed_on": [int(t.tier_out[i]) for i in range(3)], "t0": [round(float(t.tier0_ms), 1), int(t.tier0_in), int(t.tier0_out)],
+                          "t7": [round(float(getattr(t, "tier7_ms", 0.0)), 1), int(getattr(t, "tier7_in", 0)), int(getattr(t, "tier7_out", 0))], "sha": h.hexdigest()[:16]}), flush=True)
         del E
 
 

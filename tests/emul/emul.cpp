@@ -31,7 +31,7 @@ struct EmulCtx
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<dacc_window_result> windows;
 	std::string err;
-	bool usefast; uint64_t ntier[3], nretry, nlong, ntier0;
+	bool usefast; uint64_t ntier[3], nretry, nlong, ntier0, ntier7;
 	std::vector<uint64_t> glist;   // windows that went to the generic engine: index, flags of the last tier
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
@@ -61,16 +61,17 @@ static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 
 extern "C" {
 
-void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; c->ntier0 = 0; return c; }
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; c->ntier0 = 0; c->ntier7 = 0; return c; }
 void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
 void emul_reasons_tier(void * v, int t, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasonsT[t][i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbitsT[t][i]; }
 void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,1,r,fb); }
 void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,0,r,fb); }
-void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier0+c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
+void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier0+c->ntier7+c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
 uint64_t emul_generic_list(void * v, uint64_t * out, uint64_t cap) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( uint64_t i = 0; i < c->glist.size() && i < cap; ++i ) out[i] = c->glist[i]; return c->glist.size(); }
 uint64_t emul_count_long(void * v) { return static_cast<EmulCtx *>(v)->nlong; }
 void emul_counts4(void * v, uint64_t * n) { EmulCtx * c = static_cast<EmulCtx *>(v); n[0] = c->ntier[0]; n[1] = c->ntier[1]; n[2] = c->ntier[2]; n[3] = c->nretry; }
 uint64_t emul_count_tier0(void * v) { return static_cast<EmulCtx *>(v)->ntier0; }
+uint64_t emul_count_tier7(void * v) { return static_cast<EmulCtx *>(v)->ntier7; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
 
@@ -216,14 +217,14 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		WB.P = P; WB.T = T; WB.C = caps; WB.bps = c->bps.data(); WB.boff = c->boff.data(); WB.rlen = c->rlen.data();
 		WB.piles = BP.piles.data(); WB.npiles = BP.piles.size(); WB.ovl = BP.ovl.data(); WB.wt_b = wt_b.data(); WB.wt_e = wt_e.data();
 		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data(); WB.prof = 0; WB.pregen = 0;
-		FastBatch FB[3]; FastBatch FB0;
+		FastBatch FB[3]; FastBatch FB0, FB7;
 		// hand-over slots as in the library (DACC_HAND=0: off)
 		uint32_t const handwords = (BP.deep ? 2048u + 128u : 1024u + 64u) + 4u;
 		bool const handon = !(getenv("DACC_HAND") && getenv("DACC_HAND")[0] == '0') && c->par.klow == c->par.khigh;
 		std::vector<uint64_t> hand(handon ? static_cast<size_t>(BP.nwindows+1)*handwords : 1); uint32_t handctr = 0;
 		// (pattern in the slots that can be used first; the whole buffer is 8 KB per window of the batch and stays untouched pages otherwise)
 		std::fill(hand.begin(),hand.begin()+std::min<size_t>(hand.size(),(64u<<20)/8u),0x0101010101010101ull*arenafill);
-		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3]; std::vector<uint8_t> lds0, gslab0;
+		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3]; std::vector<uint8_t> lds0, gslab0, lds7, gslab7;
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
 		bool tierok[3];
@@ -259,7 +260,22 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		c->nretry = 0; c->glist.clear();
 		// tier 0 (size classes) in front of tier 1 of a shallow batch, as in the library (DACC_TIERS bit 3 switches it off)
 		bool const tier0ok = !BP.deep && tierok[0] && !(getenv("DACC_TIERS") && !((atoi(getenv("DACC_TIERS"))>>3)&1));
-		c->ntier0 = 0;
+		c->ntier0 = 0; c->ntier7 = 0;
+		// tier 7 (the middle size class) as in the library: DACC_TIERS bit 4 switches it off, DACC_T7INST is its threshold
+		uint32_t const t0inst = getenv("DACC_T0INST") ? static_cast<uint32_t>(atoi(getenv("DACC_T0INST"))) : static_cast<uint32_t>(T0INST_DEFAULT);
+		uint32_t const t7inst = getenv("DACC_T7INST") ? static_cast<uint32_t>(atoi(getenv("DACC_T7INST"))) : static_cast<uint32_t>(T7INST_DEFAULT);
+		bool const tier7ok = tier0ok && !(getenv("DACC_TIERS") && !((atoi(getenv("DACC_TIERS"))>>4)&1)) && t7inst > t0inst;
+		if ( tier7ok )
+		{
+			FB7.W = WB; FB7.F = BP.ftier7; FB7.dpsq_vst = c->H.dpsq_vst.data(); FB7.retry = 0; FB7.gearly = 0;
+			gslab7.assign(BP.ftier7.gbytes+64,arenafill); FB7.gslab = gslab7.data(); FB7.gstride = 0; FB7.tab32 = c->H.tab32.data();
+			FB7.hand = handon ? hand.data() : 0; FB7.handctr = &handctr; FB7.handcap = handon ? static_cast<uint32_t>(BP.nwindows) : 0u; FB7.handwords = handwords;
+#if defined(DACC_LEDGER)
+			{ char const * lm = getenv("DACC_LEDGER_MASK"); FB7.ledger = lm ? static_cast<uint32_t>(strtoul(lm,0,0)) : 0u; }
+#endif
+			lds7.assign(BP.ftier7.ldsbytes+64,arenafill);
+			wave_run([&]() { FastLds< FastTier<7> > L; L.base = lds7.data(); fast_load_tables(L,BP.ftier7.nrows,BP.ftier7.nsup,T,c->H.dpsq_vst.data()); });
+		}
 		if ( tier0ok )
 		{
 			FB0.W = WB; FB0.F = BP.ftier0; FB0.dpsq_vst = c->H.dpsq_vst.data(); FB0.retry = 0; FB0.gearly = 0;
@@ -316,23 +332,34 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			next.clear();
 			if ( t == 0 && tier0ok )
 			{
-				// k_classify + k_window_fast<0>: the small windows first; tier 1 then runs the big list followed by tier 0's hand-overs
-				std::vector<uint64_t> small, big;
-				uint32_t const t0inst = getenv("DACC_T0INST") ? static_cast<uint32_t>(atoi(getenv("DACC_T0INST"))) : static_cast<uint32_t>(T0INST_DEFAULT);
+				// k_classify + k_window_fast<0> + k_window_fast<7>: the small windows first, then the middle list followed by tier 0's hand-overs;
+				// tier 1 then runs the big list followed by tier 7's hand-overs (without tier 7: by tier 0's)
+				std::vector<uint64_t> small, mid, big;
 				for ( uint64_t wdx = 0; wdx < BP.nwindows; ++wdx )
 				{
 					if ( WB.pregen && ((WB.pregen[wdx>>5] >> (wdx&31)) & 1) ) continue;
-					uint32_t cls = 0; wave_run([&]() { uint32_t const r = classifyWindow(WB,wdx,t0inst); if ( wv_lane() == 0 ) cls = r; });
+					uint32_t cls = 0; wave_run([&]() { uint32_t const r = classifyWindow(WB,wdx,t0inst,tier7ok ? t7inst : 0u); if ( wv_lane() == 0 ) cls = r; });
 					wout[wdx].status = WS_INSUFFICIENT;
-					(cls == 0 ? small : big).push_back(wdx);
+					(cls == 0 ? small : (cls == 2 ? mid : big)).push_back(wdx);
 				}
 				for ( size_t i = 0; i < small.size(); ++i )
 				{
 					uint64_t const wdx = small[i];
 					if ( getenv("DACC_EMUL_POISON") ) { std::memset(lds0.data(),atoi(getenv("DACC_EMUL_POISON")),lds0.size()); std::memset(gslab0.data(),atoi(getenv("DACC_EMUL_POISON")),gslab0.size()); wave_run([&]() { FastLds< FastTier<0> > L; L.base = lds0.data(); fast_load_tables(L,BP.ftier0.nrows,BP.ftier0.nsup,T,c->H.dpsq_vst.data()); }); }
 					int rc = -1;
+					dacc_emul_curwin = wdx; dacc_emul_curtier = 100;
 					wave_run([&]() { int const r = processWindowFast< FastTier<0> >(FB0,wdx,lds0.data(),true); if ( wv_lane() == 0 ) rc = r; });
 					if ( rc == FW_DONE ) { ++c->ntier0; continue; }
+					if ( rc == FW_GENERIC ) gearly.push_back(wdx); else (tier7ok ? mid : big).push_back(wdx);
+				}
+				for ( size_t i = 0; i < mid.size(); ++i )
+				{
+					uint64_t const wdx = mid[i];
+					if ( getenv("DACC_EMUL_POISON") ) { std::memset(lds7.data(),atoi(getenv("DACC_EMUL_POISON")),lds7.size()); std::memset(gslab7.data(),atoi(getenv("DACC_EMUL_POISON")),gslab7.size()); wave_run([&]() { FastLds< FastTier<7> > L; L.base = lds7.data(); fast_load_tables(L,BP.ftier7.nrows,BP.ftier7.nsup,T,c->H.dpsq_vst.data()); }); }
+					int rc = -1;
+					dacc_emul_curwin = wdx; dacc_emul_curtier = 107;
+					wave_run([&]() { int const r = processWindowFast< FastTier<7> >(FB7,wdx,lds7.data(),true); if ( wv_lane() == 0 ) rc = r; });
+					if ( rc == FW_DONE ) { ++c->ntier7; continue; }
 					if ( rc == FW_GENERIC ) gearly.push_back(wdx); else big.push_back(wdx);
 				}
 				cur.swap(big); haveList = true;

@@ -80,6 +80,11 @@ class Emul:
         self.L.emul_counts4(self.h, n)
         return tuple(int(x) for x in n)
 
+    def count_tier7(self):
+        """windows that finished in tier 7 (the middle size class of shallow batches)"""
+        self.L.emul_count_tier7.restype = C.c_uint64; self.L.emul_count_tier7.argtypes = [C.c_void_p]
+        return int(self.L.emul_count_tier7(self.h))
+
     def count_tier0(self):
         """windows finished by tier 0 (size classes: the small windows of a shallow batch)"""
         self.L.emul_count_tier0.restype = C.c_uint64; self.L.emul_count_tier0.argtypes = [C.c_void_p]

@@ -114,6 +114,33 @@ def test_size_class_threshold_does_not_change_results(small_data, t0inst, monkey
     E.close()
 
 
+@pytest.mark.parametrize("t0,t7,tiers", [("200", "260", None), ("0", "300", None), ("200", "100000", None), ("200", "260", "15"), ("260", "200", None)])
+def test_middle_size_class_does_not_change_results(small_data, t0, t7, tiers, monkeypatch):
+    """tier 7 (round 6: the middle size class, 7 wavefronts per CU, between tier 0 and tier 1): whatever the two thresholds send where --
+    nothing to tier 0, everything that is not small to tier 7, the class switched off (DACC_TIERS without bit 4, or a threshold below
+    tier 0's) -- the per-window records and the FASTA are the oracle's, and the counters add up: tier 7 runs its class + tier 0's hand-overs"""
+    d, ovl, piles = small_data
+    monkeypatch.setenv("DACC_T0INST", t0); monkeypatch.setenv("DACC_T7INST", t7)
+    if tiers:
+        monkeypatch.setenv("DACC_TIERS", tiers)
+    O, E = _pair(d, k=14)
+    fo, bo = O.run(piles[:30], ovl, d.trace, nthreads=8, want_windows=True); wo = O.windows()
+    fx, bx = E(piles[:30], ovl, d.trace); wx = E.debug_windows(); t = E.timing()
+    assert windows_equal(wo, wx) == [] and frags_equal(fo, bo, fx, bx)
+    off = tiers == "15" or int(t7) <= int(t0)
+    if off:
+        assert t.tier7_in == 0 and t.tier7_ms == 0
+    else:
+        assert t.tier7_in > 0 and t.tier7_ms > 0 and t.tier7_in >= t.tier0_out and t.tier7_out <= t.tier7_in
+        if t0 == "0":
+            assert t.tier0_in == 0 and t.tier0_out == 0
+        if t7 == "100000":
+            assert t.tier7_in + t.tier0_in - t.tier0_out == len(wx) - int(t.long_windows)      # every window starts in tier 0 or tier 7
+    E.rerun(); f2, b2 = E.collect()
+    assert frags_equal(fo, bo, f2, b2)
+    E.close()
+
+
 @pytest.mark.parametrize("tspace", [126, 200, 300])
 def test_wide_trace_spacing(tspace):
     """tspace > 125: two byte trace values; > 128: k_trace_wide<4> (up to 256) / <8> (up to 512)."""
