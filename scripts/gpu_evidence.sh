@@ -1,7 +1,7 @@
-# Evidence on the current build (`gpurun --timeout 2400 -- 'bash scripts/gpu_evidence.sh <tag>'` -> gpurun_out/<tag>/, ~12 GPU minutes): full GPU suite, smoke,
+# Evidence on the current build (`gpurun --timeout 2400 -- 'bash scripts/gpu_evidence.sh <tag>'` -> gpurun_out/<tag>/, ~12 GPU minutes; the tag is mandatory): full GPU suite, smoke,
 # default bench with the CPU legs, PMC passes + diagnostics, the bench line again quoting them, rocprof kernel stats of the same command,
 # 54x / ONT bench lines with a live parity sample each
-R=$GRAFT_REPO_ROOT; TAG=${1:-r05z}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; TAG=${1:?usage: gpu_evidence.sh <tag>}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 ( timeout 900 python -m pytest tests -x -q -m gpu -rs --durations=6 ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -n 12 $O/pytest_gpu.log
 ( timeout 60 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; echo "rc=$?" >> $O/smoke.log; tail -n 2 $O/smoke.log

@@ -3,7 +3,7 @@
 #   at a smaller slice (ratios):   lane utilisation + in-flight levels | LDS / scalar activity | TCC hit / miss | TCP->TCC latency
 # -> profiles/<tag>_pmc_summary.json (scripts/pmc_summarize.py; keyed by the hash of the device sources)
 # usage: bash scripts/gpu_pmc.sh <tag> [reads=10000] [diag_reads=3000]
-R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; READS=${2:-10000}; DREADS=${3:-3000}; O=$R/gpurun_out/pmc_$TAG
+R=$GRAFT_REPO_ROOT; TAG=${1:?usage: gpu_pmc.sh <tag> [reads] [diag_reads]}; READS=${2:-10000}; DREADS=${3:-3000}; O=$R/gpurun_out/pmc_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 run_group () {  # name reads counters...

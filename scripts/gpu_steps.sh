@@ -10,7 +10,7 @@
 #         bench[:args]   python bench.py [args with , for spaces]  -> bench_<n>.log
 #         stats          rocprofv3 --kernel-trace --stats of the default bench command
 R=$GRAFT_REPO_ROOT; TAG=$1; shift; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-nb=0
+nb=0; ns=0
 for step in "$@"; do
   kind=${step%%:*}; rest=${step#*:}; [ "$rest" = "$step" ] && rest=""
   case $kind in
@@ -23,7 +23,7 @@ for step in "$@"; do
     sweep)
       IFS=: read -r reads steps settings <<< "$rest"
       IFS=';' read -r -a S <<< "$settings"; [ ${#S[@]} -eq 0 ] && S=("")
-      ( timeout 900 python scripts/sweep_env.py $reads $steps "${S[@]}" ) > $O/sweep_${reads}.log 2>&1; grep '^{' $O/sweep_${reads}.log | cut -c1-300 ;;
+      ns=$((ns+1)); ( timeout 900 python scripts/sweep_env.py $reads $steps "${S[@]}" ) > $O/sweep_${reads}_$ns.log 2>&1; grep '^{' $O/sweep_${reads}_$ns.log | cut -c1-330 ;;
     ab)
       IFS=: read -r reads steps libs <<< "$rest"
       IFS=';' read -r -a Lb <<< "$libs"

@@ -13,7 +13,8 @@ from daccord_amd.synth import SynthData
 def main():
     reads, steps = int(sys.argv[1]), int(sys.argv[2])
     cov = float(os.environ.get("SWEEP_COVERAGE", "20"))
-    d = SynthData(int(reads * 10000 / cov), reads, 10000, seed=3, nthreads=os.cpu_count() or 1)
+    skw = dict(ins_frac=1 / 3.0, del_frac=1 / 3.0, sub_frac=1 / 3.0) if os.environ.get("SWEEP_ONT") == "1" else {}      # config 5's error mix
+    d = SynthData(int(reads * 10000 / cov), reads, 10000, seed=3, nthreads=os.cpu_count() or 1, **skw)
     ovl, piles = engine.pile_select(d.ovl, d.piles)
     keys = set()
     for setting in sys.argv[3:]:

@@ -135,7 +135,7 @@ def test_middle_size_class_does_not_change_results(small_data, t0, t7, tiers, mo
         if t0 == "0":
             assert t.tier0_in == 0 and t.tier0_out == 0
         if t7 == "100000":
-            assert t.tier7_in + t.tier0_in - t.tier0_out == len(wx) - int(t.long_windows)      # every window starts in tier 0 or tier 7
+            assert t.tier7_in + t.tier0_in - t.tier0_out == len(wx) - (int(t.long_windows) - int(t.long_first_tier))      # every window the pre-scan left starts in tier 0 or tier 7
     E.rerun(); f2, b2 = E.collect()
     assert frags_equal(fo, bo, f2, b2)
     E.close()

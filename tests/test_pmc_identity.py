@@ -17,7 +17,7 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(build.LIB) and os.path.exist
 
 def test_kernel_isa_hashes_name_every_kernel():
     h = build.kernel_isa_hashes()
-    for k in ("k_window_fast<0>", "k_window_fast<1>", "k_window_fast<6>", "k_window_fast<2>", "k_window_fast<3>", "k_window_fast<4>", "k_window_long",
+    for k in ("k_window_fast<0>", "k_window_fast<7>", "k_window_fast<1>", "k_window_fast<6>", "k_window_fast<2>", "k_window_fast<3>", "k_window_fast<4>", "k_window_long",
               "k_window", "k_classify", "k_trace", "k_trace_wide<4>", "k_trace_wide<8>", "k_vote", "k_prep", "k_prescan"):
         assert k in h and len(h[k]) == 16
     assert len(set(h.values())) == len(h)
