@@ -344,7 +344,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
@@ -406,13 +406,14 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	std::memset(&c->timing,0,sizeof(c->timing));
 	// launch geometry of the LDS tiers: set by every batch that uses them; a generic-only batch (DACC_NOFAST, w >= 64, a model table no
 	// tier holds) reads retry_grid in its scratch retry and must not find an indeterminate value there
-	c->retry_grid = c->early_grid = c->win_grid = 0; c->tier0_grid = 0; c->tier0_ok = false; c->tier0_ran = false; c->tier7_grid = 0; c->tier7_ok = false; c->tier7_ran = false; c->gstride7 = 0; c->tierL_ok = 0; c->usefast = 0; c->sched = 0;
+	c->retry_grid = c->early_grid = c->win_grid = 0; c->tier0_grid = 0; c->tier0_ok = false; c->tier0_ran = false; c->tier7_grid = 0; c->tier7_ok = false; c->tier7_ran = false; c->gstride7 = 0; c->tier7_adapt_off = false; c->tierL_ok = 0; c->usefast = 0; c->sched = 0;
 	for ( int i = 0; i < 3; ++i ) { c->tier_grid[i] = 0; c->tier_ok[i] = 0; c->tier_out[i] = 0; c->gstride[i] = 0; }
 	c->gstride0 = 0; c->tr_grid = c->tr_lds = c->tr_words = c->tr_lanes = c->trace_bytes = 0;
 	{
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 31;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes), bit 4 tier 7 (the middle class; needs tier 0)
+		char const * ta = getenv("DACC_T7_ADAPT"); c->env_t7adapt = !(ta && ta[0] == '0');      // 0: tier 7 stays on whatever it hands on
 		char const * t7 = getenv("DACC_T7INST"); c->env_t7inst = t7 ? static_cast<uint32_t>(atoi(t7)) : static_cast<uint32_t>(T7INST_DEFAULT);      // size-class threshold of tier 7
 		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
 		char const * l0 = getenv("DACC_LDS_T0"); c->env_lds_t0 = l0 ? static_cast<uint32_t>(atoi(l0)) : 0u;      // the same for tier 0 (size classes)
@@ -627,15 +628,19 @@ static int runDevice(dacc_ctx * c)
 						// size classes: the small windows run in tier 0 (8 wavefronts per CU), the middle class and tier 0's hand-overs in tier 7
 						// (7 per CU), tier 7's hand-overs and all other windows in tier 1 (6 per CU)
 						HIPCHK(hipMemsetAsync(c->d_small.p,0,sizeof(uint32_t),s)); HIPCHK(hipMemsetAsync(c->d_big.p,0,sizeof(uint32_t),s));
-						if ( c->tier7_ok ) HIPCHK(hipMemsetAsync(c->d_mid.p,0,sizeof(uint32_t),s));
-						uint32_t * const midlist = c->tier7_ok ? c->d_mid.p : c->d_big.p;
-						hipLaunchKernelGGL(k_classify,dim3((BP.nwindows+255)/256),dim3(256),0,s,WB,c->d_small.p,midlist,c->d_big.p,c->env_t0inst,c->tier7_ok ? c->env_t7inst : 0u);
+						// (tier 7 switches itself off for the rest of a context's batches when it hands on more than a fifth of what it runs: on the
+						// ONT mix at k = 10 / 12 a third / a quarter of its windows overflow it late, on their stretches and pools, and the class costs
+						// 2.6 / 1.4 % instead of gaining the 3 % it gains at k = 14 and 16 and on config 2, profiles/r06j; results do not depend on it)
+						bool const use7 = c->tier7_ok && !c->tier7_adapt_off;
+						if ( use7 ) HIPCHK(hipMemsetAsync(c->d_mid.p,0,sizeof(uint32_t),s));
+						uint32_t * const midlist = use7 ? c->d_mid.p : c->d_big.p;
+						hipLaunchKernelGGL(k_classify,dim3((BP.nwindows+255)/256),dim3(256),0,s,WB,c->d_small.p,midlist,c->d_big.p,c->env_t0inst,use7 ? c->env_t7inst : 0u);
 						// (what the pre-pass itself put on the middle and the big list, before the tiers' hand-overs join them: for the counters of dacc_timing)
-						if ( c->tier7_ok ) { HIPCHK(hipMemcpyAsync(c->d_work.p+56,c->d_mid.p,sizeof(uint32_t),hipMemcpyDeviceToDevice,s)); HIPCHK(hipMemcpyAsync(c->d_work.p+57,c->d_big.p,sizeof(uint32_t),hipMemcpyDeviceToDevice,s)); }
+						if ( use7 ) { HIPCHK(hipMemcpyAsync(c->d_work.p+56,c->d_mid.p,sizeof(uint32_t),hipMemcpyDeviceToDevice,s)); HIPCHK(hipMemcpyAsync(c->d_work.p+57,c->d_big.p,sizeof(uint32_t),hipMemcpyDeviceToDevice,s)); }
 						FastBatch F0 = FB; F0.F = BP.ftier0; F0.retry = midlist; F0.gstride = c->gstride0;
 						hipLaunchKernelGGL(k_window_fast<0>,dim3(c->tier0_grid),dim3(64),F0.F.ldsbytes,s,F0,static_cast<uint32_t const *>(c->d_small.p),(c->sched&1) ? c->d_work.p+40 : static_cast<uint32_t *>(0));
 						HIPCHK(hipEventRecord(c->evT0,s)); c->tier0_ran = true;
-						if ( c->tier7_ok )
+						if ( use7 )
 						{
 							FastBatch F7 = FB; F7.F = BP.ftier7; F7.retry = c->d_big.p; F7.gstride = c->gstride7;
 							hipLaunchKernelGGL(k_window_fast<7>,dim3(c->tier7_grid),dim3(64),F7.F.ldsbytes,s,F7,static_cast<uint32_t const *>(c->d_mid.p),(c->sched&1) ? c->d_work.p+48 : static_cast<uint32_t *>(0));
@@ -742,6 +747,7 @@ static int runDevice(dacc_ctx * c)
 				uint32_t const t7out = nbig > pre[1] ? nbig - pre[1] : 0u;
 				c->timing.tier0_out = nmid > pre[0] ? nmid - pre[0] : 0u;
 				c->timing.tier7_in = nmid; c->timing.tier7_out = t7out;
+				if ( c->env_t7adapt && nmid >= 4096 && static_cast<uint64_t>(t7out)*5 > nmid ) c->tier7_adapt_off = true;
 			}
 		}
 	}

@@ -180,7 +180,7 @@ typedef struct dacc_timing {
 	uint32_t long_windows;   /* windows the second stream ran (a string of more than 64 bases, or a shape no LDS tier takes) */
 	float tier0_ms;          /* size classes (shallow batches): pre-pass + k_window_fast<0>, the part of tier_ms[0] in front of k_window_fast<1>; 0 if tier 0 did not run */
 	uint32_t tier0_in;       /* windows the pre-pass sent to tier 0 */
-	uint32_t tier0_out;      /* windows tier 0 handed on to tier 1 */
+	uint32_t tier0_out;      /* windows tier 0 handed on: to tier 7 (round 6), to tier 1 when the middle class is off */
 	float tier7_ms;          /* round 6, the middle size class: k_window_fast<7> (7 wavefronts per CU) between tier 0 and tier 1; 0 if it did not run */
 	uint32_t tier7_in;       /* windows tier 7 ran: the pre-pass's middle class + tier 0's hand-overs (tier0_out) */
 	uint32_t tier7_out;      /* windows tier 7 handed on to tier 1 */
