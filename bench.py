@@ -242,7 +242,7 @@ def main():
     t0 = time.time()
     skw = dict(ins_frac=1 / 3.0, del_frac=1 / 3.0, sub_frac=1 / 3.0) if args.ont else {}
     arange = shard.shard_range(0, total_reads, rank, world)
-    d = SynthData(genome, total_reads, args.readlen, seed=args.seed, nthreads=max(1, ncpu // max(world, 1)),
+    d = SynthData(genome, total_reads, args.readlen, seed=args.seed, nthreads=max(1, usable_cpus() // max(world, 1)),
                   aread_range=(arange if world > 1 else None), **skw)
     ovl, piles = engine.pile_select(d.ovl, d.piles)
     npiles_total = total_reads            # one pile per A read, pile index = A read id

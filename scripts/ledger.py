@@ -7,7 +7,8 @@ cost: instructions by class and wave time (SQ_WAVE_CYCLES counts quad-cycles: x 
 cannot run twice -- the lane 0 replay of the pairs into the candidate heap, candidate ranking / decoding, addNextFromHeap, hand-over
 slots -- is the remainder (total minus the phases).
 
-usage: python scripts/ledger.py <outdir> [reads=1500] [extra bench.py args...]        (needs rocprofv3; ~25 s per pass, 19 passes)"""
+usage: python scripts/ledger.py <outdir> [reads=1500] [extra bench.py args...]        (needs rocprofv3; ~25 s per pass, 19 passes)
+The library: python -c "from daccord_amd import build; build.build_variant('ledger', ['-DDACC_LEDGER'])"   (here, before the GPU call)"""
 import collections, csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASES = [(0, "gather: overlap selection, string descriptors, bases -> pattern masks"), (1, "estimateLength (f64 products over the strings)"),
@@ -45,7 +46,8 @@ def main():
     base_res, base = one_pass(out, "base", 0, reads, extra)
     sha = base_res["parity"]["gpu_fasta_sha256_all"]
     wins = base_res["roofline"]["windows_by_kernel"]; launches = 2      # first pass + one step
-    kern = {"k_window_fast<0>": wins.get("k_classify+k_window_fast<0>", 0), "k_window_fast<1>": wins.get("k_window_fast<1>", 0), "k_window_fast<6>": wins.get("k_window_fast<6>", 0)}
+    kern = {"k_window_fast<0>": wins.get("k_classify+k_window_fast<0>", 0), "k_window_fast<7>": wins.get("k_window_fast<7>", 0), "k_window_fast<1>": wins.get("k_window_fast<1>", 0),
+            "k_window_fast<6>": wins.get("k_window_fast<6>", 0)}
     rows = {}
     for bit, name in PHASES:
         res, acc = one_pass(out, "p%02d" % bit, 1 << bit, reads, extra)
