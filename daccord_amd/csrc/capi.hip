@@ -77,13 +77,14 @@ static inline uint32_t boundByArena(uint64_t grid, uint64_t const bytes, uint64_
 	return static_cast<uint32_t>(grid < 1 ? 1 : grid);
 }
 
-// safety net: every window must have been finished by some engine (status WS_RETRY = handed on and never picked up)
-// Before the LDS tiers: windows with a B string of more than 64 bases can only run in the generic engine, where one of
-// them costs as much as a few hundred thousand ordinary windows in the LDS path.  One wavefront per overlap scans its rows
-// of the window tables; such a window is flagged (the tiers skip it) and listed, and the generic engine starts on it on
-// the second stream right away instead of after the first tier.
+// Before the LDS tiers: one wavefront per overlap scans its rows of the window tables for B strings that the first slot's tiers (strings of
+// up to 64 bases) cannot hold.  Two bit maps: pregen = a string of more than 64 bases (the first slot's tiers and the size-class pre-pass skip
+// the window), pregen2 = one of more than 128 (every LDS tier skips it).  k_prescan_lists then sorts the flagged windows into two lists.
+// (Round 6: tiers 6 and 3 hold strings of up to 128 bases -- two words per pattern mask -- so a window with a string of 65 ... 128 bases joins
+// the list the second slot reads, next to the first slot's hand-overs; rounds 3-5 ran all of them in tier 5 on the second stream, the LDS of a
+// whole CU per wavefront: at -w 56 / 60 / 63 that is 21 / 65 / 88 % of the windows of PacBio-like reads, profiles/r06l.)
 __global__ void __launch_bounds__(256) k_prescan(DevOvl const * ovl, uint64_t novl, uint32_t const * ovl_pile, DevPile const * piles, uint32_t const * wt_b, uint32_t const * wt_e,
-	uint32_t * pregen, uint32_t * list)
+	uint32_t * pregen, uint32_t * pregen2)
 {
 	// one wavefront per overlap, lanes over its rows: coalesced reads of the two tables
 	uint64_t const o = static_cast<uint64_t>(blockIdx.x)*4 + (threadIdx.x>>6);
@@ -91,12 +92,33 @@ __global__ void __launch_bounds__(256) k_prescan(DevOvl const * ovl, uint64_t no
 	DevOvl const ov = ovl[o];
 	uint64_t const winbase = piles[ovl_pile[o]].winbase;
 	for ( uint32_t r = threadIdx.x & 63; r < ov.ny; r += 64 )
-		if ( wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r] > 64u )
+	{
+		uint32_t const len = wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r];
+		if ( len > 64u )
 		{
 			uint64_t const w = winbase + ov.y0 + r;
 			uint32_t const bit = 1u << (w&31);
-			if ( !(atomicOr(pregen + (w>>5),bit) & bit) ) { uint32_t const q = atomicAdd(list,1u); list[1+q] = static_cast<uint32_t>(w); }
+			atomicOr(pregen + (w>>5),bit);
+			if ( len > 128u ) atomicOr(pregen2 + (w>>5),bit);
 		}
+	}
+}
+// one thread per word of the bit maps: a flagged window goes to the second stream's list (a string of more than 128 bases: tier 5 / the generic
+// engine) or to the list the second slot's tier reads; its result record forgets what an earlier batch left (the tiers resume from it)
+__global__ void __launch_bounds__(256) k_prescan_lists(uint32_t const * pregen, uint32_t const * pregen2, uint64_t nwindows, uint32_t * list128, uint32_t * slot1list, WindowOut * wout)
+{
+	uint64_t const wi = static_cast<uint64_t>(blockIdx.x)*256 + threadIdx.x;
+	if ( wi*32 >= nwindows ) return;
+	uint32_t m = pregen[wi]; uint32_t const m2 = pregen2[wi];
+	while ( m )
+	{
+		uint32_t const b = static_cast<uint32_t>(__builtin_ctz(m)); m &= m-1;
+		uint64_t const w = wi*32 + b;
+		if ( w >= nwindows ) break;
+		wout[w].status = WS_INSUFFICIENT;
+		uint32_t * const dst = ((m2 >> b) & 1u) || !slot1list ? list128 : slot1list;
+		uint32_t const q = atomicAdd(dst,1u); dst[1+q] = static_cast<uint32_t>(w);
+	}
 }
 
 // after all engines: a window still marked as handed on is an internal error (errflag); a window the generic engine
@@ -344,11 +366,11 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
-	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_lds_t0, env_t0inst, env_t7inst;     // debugging knobs, read once in dacc_create
+	int env_nofast, env_sched, env_tiers, env_dbgretry; uint32_t env_lds_t1, env_lds_t0, env_t0inst, env_t7inst; int env_long128;     // debugging knobs, read once in dacc_create
 	std::vector<uint32_t> retry_flags;                      // DACC_DEBUG_RETRY: (window, flags) of what the last LDS tier handed on
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<int32_t> pile_status; std::vector<std::string> pile_errors; std::string pile_errors_joined;
@@ -413,6 +435,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 		char const * e = getenv("DACC_NOFAST"); c->env_nofast = (e && e[0] == '1');
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 31;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes), bit 4 tier 7 (the middle class; needs tier 0)
+		char const * l8 = getenv("DACC_LONG128"); c->env_long128 = !(l8 && l8[0] == '0');      // 0: windows with a string of 65 ... 128 bases run in tier 5 on the second stream (rounds 3-5)
 		char const * ta = getenv("DACC_T7_ADAPT"); c->env_t7adapt = !(ta && ta[0] == '0');      // 0: tier 7 stays on whatever it hands on
 		char const * t7 = getenv("DACC_T7INST"); c->env_t7inst = t7 ? static_cast<uint32_t>(atoi(t7)) : static_cast<uint32_t>(T7INST_DEFAULT);      // size-class threshold of tier 7
 		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
@@ -439,7 +462,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->d_bps.release(); c->d_boff.release(); c->d_rlen.release();
 	c->d_piles.release(); c->d_ovl.release(); c->d_ovl_pile.release(); c->d_trace.release(); c->d_blk_ovl.release(); c->d_blk_b0.release(); c->d_wt_b.release(); c->d_wt_e.release();
 	c->d_wrec.release(); c->d_wout.release(); c->d_arena.release();
-	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release(); c->d_mid.release(); c->d_hand.release(); c->d_handctr.release();
+	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregen2.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release(); c->d_mid.release(); c->d_hand.release(); c->d_handctr.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
 	hipEventDestroy(c->evT0); hipEventDestroy(c->evT7);
@@ -563,9 +586,18 @@ static int runDevice(dacc_ctx * c)
 			// windows only the generic engine can run (a string longer than 64 bases): found by a scan of the window tables and
 			// started on the second stream now, concurrently with all LDS tiers
 			HIPCHK(hipMemsetAsync(c->d_pregen.p,0,((BP.nwindows+31)/32+1)*sizeof(uint32_t),s));
+			HIPCHK(hipMemsetAsync(c->d_pregen2.p,0,((BP.nwindows+31)/32+1)*sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_pregenlist.p,0,sizeof(uint32_t),s));
+			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			if ( BP.ovl.size() )
-				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregenlist.p);
+			{
+				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregen2.p);
+				// windows with a string of 65 ... 128 bases join the first slot's hand-overs when the second slot's tier holds such strings (tiers 6 / 3;
+				// a deep batch's tier 2 does not: it hands them on to tier 3 at its length check) and the first slot runs at all
+				bool const slot1 = c->tier_ok[0] && (c->tier_ok[1] || c->tier_ok[2]) && c->env_long128;
+				hipLaunchKernelGGL(k_prescan_lists,dim3(((BP.nwindows+31)/32+255)/256),dim3(256),0,s,c->d_pregen.p,c->d_pregen2.p,static_cast<uint64_t>(BP.nwindows),c->d_pregenlist.p,
+					slot1 ? c->d_retry[0].p : static_cast<uint32_t *>(0),c->d_wout.p);
+			}
 			HIPCHK(hipEventRecord(c->evPrescan,s));
 			FastBatch FL; FL.W = WB; FL.W.arena = c->d_arena2.p; FL.W.prof = 0; FL.W.pregen = 0; FL.F = BP.ftierL; FL.dpsq_vst = c->d_vst.p; FL.retry = 0; FL.gearly = 0; FL.gslab = 0; FL.gstride = 0; FL.tab32 = c->d_tab32.p; FL.hand = 0; FL.handctr = 0; FL.handcap = 0; FL.handwords = 0;
 #if defined(DACC_LEDGER)
@@ -600,7 +632,6 @@ static int runDevice(dacc_ctx * c)
 			};
 			c->nlong[0] = c->nlong[1] = 0;
 			WB.pregen = c->d_pregen.p;
-			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
 			HIPCHK(hipMemsetAsync(c->d_handctr.p,0,sizeof(uint32_t),s));
 			bool early = false;
@@ -612,6 +643,9 @@ static int runDevice(dacc_ctx * c)
 				if ( c->tier_ok[t] )
 				{
 					FastBatch FB; FB.W = WB; FB.F = BP.ftier[t]; FB.dpsq_vst = c->d_vst.p; FB.retry = c->d_retry[t].p;
+					// the first slot's tiers skip every window with a string of more than 64 bases; the later ones only those the second stream has
+					// (without the 128-base route: all of them, as in rounds 3-5)
+					if ( t > 0 && c->tier_ok[0] && c->env_long128 ) FB.W.pregen = c->d_pregen2.p;
 					FB.gslab = c->d_gslab.p; FB.gstride = c->gstride[t]; FB.tab32 = c->d_tab32.p;
 					FB.hand = c->handcap ? c->d_hand.p : static_cast<uint64_t *>(0); FB.handctr = c->d_handctr.p; FB.handcap = c->handcap; FB.handwords = c->handwords;
 #if defined(DACC_LEDGER)
@@ -761,7 +795,7 @@ static int runDevice(dacc_ctx * c)
 		c->retry_grid = g; c->win_grid = g; if ( c->early_grid > g ) c->early_grid = g;     // later launches of this batch use the grown arenas
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(g)*BP.caps.bytes));
 		if ( c->usefast ) HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
-		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2));
+		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2)); HIPCHK(c->d_pregen2.ensure((BP.nwindows+31)/32+2));
 		HIPCHK(hipMemsetAsync(c->d_err.p,0,4*sizeof(uint32_t),s));
 		HIPCHK(hipMemsetAsync(c->d_gearly.p,0,sizeof(uint32_t),s));
 		hipLaunchKernelGGL(k_collect_overflow,dim3((BP.nwindows+255)/256),dim3(256),0,s,c->d_wout.p,BP.nwindows,c->d_gearly.p);
@@ -973,7 +1007,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 		// the 8.2 s of the LDS tiers; tier 5 takes them now)
 		c->early_grid = c->retry_grid < 256 ? c->retry_grid : 256;
 		while ( c->early_grid > 16 && static_cast<uint64_t>(c->early_grid)*BP.caps.bytes > (8ull<<30) ) c->early_grid >>= 1;
-		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2));
+		HIPCHK(c->d_gearly.ensure(BP.nwindows+2)); HIPCHK(c->d_pregenlist.ensure(BP.nwindows+2)); HIPCHK(c->d_pregen.ensure((BP.nwindows+31)/32+2)); HIPCHK(c->d_pregen2.ensure((BP.nwindows+31)/32+2));
 		HIPCHK(c->d_arena2.ensure(static_cast<size_t>(c->early_grid)*BP.caps.bytes));
 		HIPCHK(c->d_work.ensure(64));
 		HIPCHK(c->d_arena.ensure(static_cast<size_t>(c->retry_grid)*BP.caps.bytes));

@@ -101,14 +101,14 @@ template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 // (round 6: the tier sat at 34 720 B, 6 KB below what four wavefronts per CU allow (40 960 B): the bytes went to what sends its windows on to
 // tier 3 -- ONE wavefront per CU -- on the ONT mix at small k (emulation, 6 piles of config 5 at k = 10 / 12: reverse pool 73 / 130, weights 53 / 1,
 // forward pool 45 / 7 of about 200 hand-overs): reverse pool 192 -> 256 paths in chunks of two, 248 stretches, 2048 weight records)
-template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 2048, rch = 2, fch = 8, fnw = 3, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 40, precap = 1024, ncap = 1024, scap = 248, lcap = 1280, wcap = 2048, rccap = 256, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 2048, rch = 2, fch = 8, fnw = 3, fnc = 40, idmax = 250, rpstcap = 256, lstr = 128, maxs = 40, precap = 1024, ncap = 1024, scap = 248, lcap = 1280, wcap = 2048, rccap = 256, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
 // gw layout and 16 bit STRETCH ids since round 3: what the legacy tier 3 handed to the generic engine at 54x were windows with
 // more than 250 stretches (13 of 19 per 60 000 windows) or more than 2112 feasible weights (5 of 19), and each of them cost the
 // generic engine seconds (685 such windows were 92 % of a 2000-pile 54x batch, profiles/r03c_bench_54x_2000piles.log)
-template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 64, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
 // small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
@@ -345,7 +345,7 @@ struct FastLds<CT,true>
 	// sort at the start of a window is checked against it)
 	static_assert(sizeof(typename CT::id_t) > 1 || (CT::fcap <= 256 && CT::rccap <= 256),"pool slots are recorded as id_t (pout)");
 	static_assert(CT::blcap <= 128 && (CT::blcap & 7) == 0,"base length buckets: two 64 bit occupancy words, cleared 8 at a time");
-	static_assert(CT::lstr == 64,"the gw layout holds strings of up to 64 bases");
+	static_assert(CT::lstr == 64 || CT::lstr == 128,"the gw layout holds strings of up to 64 bases in one word per pattern mask, of up to 128 in two (round 6)");
 	static constexpr uint32_t pw = CT::lstr/64;
 	typedef typename CT::sid_t sid_t;      // stretch ids: 8 bits (at most 250 stretches) or 16 bits
 	// ---- P ----
@@ -775,10 +775,23 @@ struct FastEngine
 				if constexpr ( GW )
 				{
 					// symbols i ... i+k-1 from the pattern masks: low / high bit planes, reversed (symbol i is the most significant) and interleaved
-					LDSQ uint64_t const * PEQ = L.peq() + 4*j;
-					uint64_t const e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
+					enum { PW = FastLds<CT>::pw };
+					LDSQ uint64_t const * PEQ = L.peq() + 4*PW*j;
 					uint32_t const km = (1u << k) - 1u;
-					uint32_t const lo = static_cast<uint32_t>((e1|e3) >> i) & km, hi = static_cast<uint32_t>((e2|e3) >> i) & km;
+					uint32_t lo, hi;
+					if constexpr ( PW == 1 )
+					{
+						uint64_t const e1 = PEQ[1], e2 = PEQ[2], e3 = PEQ[3];
+						lo = static_cast<uint32_t>((e1|e3) >> i) & km; hi = static_cast<uint32_t>((e2|e3) >> i) & km;
+					}
+					else
+					{
+						// (two words per mask, strings of up to 128 bases: the 16 bits from position i on may straddle the words)
+						uint64_t const l0 = PEQ[1*PW] | PEQ[3*PW], l1 = PEQ[1*PW+1] | PEQ[3*PW+1], h0 = PEQ[2*PW] | PEQ[3*PW], h1 = PEQ[2*PW+1] | PEQ[3*PW+1];
+						uint64_t const sl = i < 64 ? ((l0 >> i) | (i ? (l1 << (64u-i)) : 0ull)) : (l1 >> (i-64u));
+						uint64_t const sh = i < 64 ? ((h0 >> i) | (i ? (h1 << (64u-i)) : 0ull)) : (h1 >> (i-64u));
+						lo = static_cast<uint32_t>(sl) & km; hi = static_cast<uint32_t>(sh) & km;
+					}
 					v = dacc_spread16(dacc_rev32(lo) >> (32u-k)) | (dacc_spread16(dacc_rev32(hi) >> (32u-k)) << 1);
 				}
 				else
@@ -3887,11 +3900,13 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 				if constexpr ( CT::gw != 0 )
 				{
 					// pattern masks by ballot: bit p of word c of string j <=> symbol c at position p (positions behind the string: no bit)
-					static_assert(CT::gw == 0 || CT::lstr == 64,"one 64 bit word per pattern mask");
-					uint32_t const sh = p - static_cast<uint32_t>(lane);      // (a 64-lane wavefront: 0; the 1-lane test build walks p)
+					// (words 4*PW*j + PW*symbol + word: PW = 2 holds strings of up to 128 bases, the second round of p fills word 1)
+					enum { PW = FastLds<CT>::pw };
+					uint32_t const sh0 = p - static_cast<uint32_t>(lane);      // (a 64-lane wavefront: 0 or 64; the 1-lane test build walks p)
+					uint32_t const wq = sh0 >> 6, sh = sh0 & 63u;
 					#define DACC_PM(u) if ( j0+u < mao ) { \
 						uint64_t const b0 = wv_ballot(a##u && v##u == 0) << sh, b1 = wv_ballot(a##u && v##u == 1) << sh, b2 = wv_ballot(a##u && v##u == 2) << sh, b3 = wv_ballot(a##u && v##u == 3) << sh; \
-						if ( lane == 0 ) { LDSQ uint64_t * const q = L.peq() + 4*(j0+u); if ( sh == 0 ) { q[0] = b0; q[1] = b1; q[2] = b2; q[3] = b3; } else { q[0] |= b0; q[1] |= b1; q[2] |= b2; q[3] |= b3; } } }
+						if ( lane == 0 ) { LDSQ uint64_t * const q = L.peq() + 4*PW*(j0+u) + wq; if ( sh == 0 ) { q[0] = b0; q[PW] = b1; q[2*PW] = b2; q[3*PW] = b3; } else { q[0] |= b0; q[PW] |= b1; q[2*PW] |= b2; q[3*PW] |= b3; } } }
 					DACC_PM(0) DACC_PM(1) DACC_PM(2) DACC_PM(3)
 					#undef DACC_PM
 				}

@@ -228,20 +228,24 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
 		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
 		bool tierok[3];
-		// the library's pre-scan (k_prescan): windows with an active B string of more than 64 bases are flagged (the tiers skip
-		// them) and listed for the launch on the second stream
-		std::vector<uint32_t> pregen((BP.nwindows+31)/32+1,0); std::vector<uint64_t> pregenlist;
+		// the library's pre-scan (k_prescan + k_prescan_lists): windows with an active B string of more than 64 bases are flagged (the first
+		// slot's tiers skip them); those with a string of more than 128 bases (second bit map: every tier skips them) are listed for the launch
+		// on the second stream, the others join the list the second slot's tier reads (round 6: tiers 6 and 3 hold strings of up to 128 bases;
+		// DACC_LONG128=0: all of them go to the second stream as in rounds 3-5)
+		std::vector<uint32_t> pregen((BP.nwindows+31)/32+1,0), pregen2((BP.nwindows+31)/32+1,0); std::vector<uint64_t> pregenlist, slot1list;
+		bool const long128 = !(getenv("DACC_LONG128") && getenv("DACC_LONG128")[0] == '0');
 		if ( usefast )
 		{
 			for ( size_t o = 0; o < BP.ovl.size(); ++o )
 			{
 				DevOvl const & ov = BP.ovl[o]; uint64_t const winbase = BP.piles[BP.ovl_pile[o]].winbase;
 				for ( uint32_t r = 0; r < ov.ny; ++r )
-					if ( wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r] > 64u )
-					{
-						uint64_t const w = winbase + ov.y0 + r;
-						if ( !((pregen[w>>5] >> (w&31)) & 1) ) { pregen[w>>5] |= 1u << (w&31); pregenlist.push_back(w); }
-					}
+				{
+					uint32_t const len = wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r];
+					uint64_t const w = winbase + ov.y0 + r;
+					if ( len > 64u ) pregen[w>>5] |= 1u << (w&31);
+					if ( len > 128u ) pregen2[w>>5] |= 1u << (w&31);
+				}
 			}
 			WB.pregen = pregen.data();
 		}
@@ -258,6 +262,16 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
 		c->nretry = 0; c->glist.clear();
+		{
+			bool const slot1 = usefast && tierok[0] && (tierok[1] || tierok[2]) && long128;
+			for ( uint64_t w = 0; usefast && w < BP.nwindows; ++w )
+				if ( (pregen[w>>5] >> (w&31)) & 1 )
+				{
+					wout[w].status = WS_INSUFFICIENT;
+					if ( ((pregen2[w>>5] >> (w&31)) & 1) || !slot1 ) pregenlist.push_back(w); else slot1list.push_back(w);
+				}
+			if ( usefast && tierok[0] && long128 ) for ( int t = 1; t < 3; ++t ) FB[t].W.pregen = pregen2.data();
+		}
 		// tier 0 (size classes) in front of tier 1 of a shallow batch, as in the library (DACC_TIERS bit 3 switches it off)
 		bool const tier0ok = !BP.deep && tierok[0] && !(getenv("DACC_TIERS") && !((atoi(getenv("DACC_TIERS"))>>3)&1));
 		c->ntier0 = 0; c->ntier7 = 0;
@@ -368,12 +382,13 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			for ( uint64_t i = 0; i < n; ++i )
 			{
 				uint64_t const wdx = haveList ? cur[i] : i;
-				if ( WB.pregen && ((WB.pregen[wdx>>5] >> (wdx&31)) & 1) ) continue;      // the kernels return at once for these: not counted as run by the tier
+				if ( FB[t].W.pregen && ((FB[t].W.pregen[wdx>>5] >> (wdx&31)) & 1) ) continue;      // the kernels return at once for these: not counted as run by the tier
 				int const rc = runTier(t,wdx,haveList);
 				if ( rc == FW_DONE ) { ++c->ntier[t]; continue; }
 				uint32_t const f = wout[wdx].flags; c->reasonsT[t][(f>>24)&63]++; for ( int b = 0; b < 24; ++b ) if ( (f>>b)&1 ) c->flagbitsT[t][b]++;
 				if ( rc == FW_GENERIC && !early ) gearly.push_back(wdx); else next.push_back(wdx);
 			}
+			if ( t == 0 && !slot1list.empty() ) { next.insert(next.begin(),slot1list.begin(),slot1list.end()); slot1list.clear(); }      // (k_prescan_lists appended them before the tier ran)
 			cur.swap(next); haveList = true;
 			if ( !early ) { early = true; earlysnap = gearly; }       // the early generic kernel reads its list here
 		}

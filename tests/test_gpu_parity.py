@@ -168,16 +168,28 @@ def test_deep_batch_starts_in_the_deep_tier():
     assert frags_equal(fo, bo, fx, bx)
 
 
-def test_windows_with_long_strings():
-    """w = 56 on insertion-rich reads: a quarter of the windows have a B string of more than 64 bases (k_window_long:
-    tier 5, then the generic engine)."""
+@pytest.mark.parametrize("route", ["tiers", "tier5"])
+def test_windows_with_long_strings(route, monkeypatch):
+    """w = 56 on insertion-rich reads: a quarter of the windows have a B string of more than 64 bases.  Round 6: they join the list of the
+    second slot (tiers 6 / 3 hold strings of up to 128 bases) and nothing of them takes the second stream; DACC_LONG128=0: k_window_long
+    (tier 5, then the generic engine) as in rounds 3-5."""
     d = SynthData(100000, 200, 5000, erate=0.25, seed=77, ins_frac=0.9, del_frac=0.05, sub_frac=0.05)
     ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
+    if route == "tier5":
+        monkeypatch.setenv("DACC_LONG128", "0")
     O, E = _pair(d, k=10, w=56, a=14)
     fo, bo = O.run(piles[:3], ovl, d.trace, nthreads=8, want_windows=True)
     fx, bx = E(piles[:3], ovl, d.trace)
+    t = E.timing()
     assert windows_equal(O.windows(), E.debug_windows()) == []
     assert frags_equal(fo, bo, fx, bx)
+    if route == "tier5":
+        assert t.long_windows > 20
+    else:
+        assert t.long_windows == 0 and t.tier_out[0] > 20
+    E.rerun(); f2, b2 = E.collect()
+    assert frags_equal(fo, bo, f2, b2)
+    E.close()
 
 
 @pytest.mark.parametrize("kw,erate", [(dict(w=100, a=25, k=8), 0.12), (dict(w=128, a=32, k=12), 0.15), (dict(w=65, a=16, k=8), 0.15),
