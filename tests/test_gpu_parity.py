@@ -141,6 +141,26 @@ def test_middle_size_class_does_not_change_results(small_data, t0, t7, tiers, mo
     E.close()
 
 
+@pytest.mark.parametrize("adapt", ["1", "0"])
+def test_middle_size_class_switches_itself_off_on_dense_graphs(small_data, adapt, monkeypatch):
+    """tier 7 hands on most of what it runs at k = 8 (dense graphs overflow its stretch and pool tables): a context stops using it after
+    such a batch (DACC_T7_ADAPT, default on) -- a throughput heuristic only: first pass, re-run and the pass of a second batch equal the oracle"""
+    d, ovl, piles = small_data
+    monkeypatch.setenv("DACC_T0INST", "0"); monkeypatch.setenv("DACC_T7INST", "100000"); monkeypatch.setenv("DACC_T7_ADAPT", adapt)
+    O, E = _pair(d, k=8)
+    fo, bo = O.run(piles[:24], ovl, d.trace, nthreads=8)
+    fx, bx = E(piles[:24], ovl, d.trace); t = E.timing()
+    assert frags_equal(fo, bo, fx, bx)
+    assert t.tier7_in >= 4096 and t.tier7_out * 5 > t.tier7_in, (t.tier7_in, t.tier7_out)      # the premise: it overflows
+    E.rerun(); f2, b2 = E.collect(); t2 = E.timing()
+    assert frags_equal(fo, bo, f2, b2)
+    assert (t2.tier7_in == 0) if adapt == "1" else (t2.tier7_in == t.tier7_in)
+    fo3, bo3 = O.run(piles[24:30], ovl, d.trace, nthreads=8)
+    f3, b3 = E(piles[24:30], ovl, d.trace)
+    assert frags_equal(fo3, bo3, f3, b3)
+    E.close()
+
+
 @pytest.mark.parametrize("tspace", [126, 200, 300])
 def test_wide_trace_spacing(tspace):
     """tspace > 125: two byte trace values; > 128: k_trace_wide<4> (up to 256) / <8> (up to 512)."""
