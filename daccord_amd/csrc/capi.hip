@@ -42,7 +42,7 @@ __global__ void k_prep(PrepBatch B)
 }
 
 // one lane per tspace block, one wavefront per workgroup; the column checkpoints of every lane go to the workgroup's global
-// slab, the segment the traceback is in lives in the workgroup's dynamic LDS (TRACE2_LDS = 19.6 KB: 8 wavefronts per CU)
+// slab, the segment the traceback is in lives in the workgroup's dynamic LDS (TRACE2_LDS = 10.9 KB: 14 wavefronts per CU)
 __global__ void __launch_bounds__(64) k_trace(TraceBatch B)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_trace[];
@@ -900,7 +900,9 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			else if ( c->tr_words == 4 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_wide<4>),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
 			else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_wide<8>),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
 		}
-		uint64_t percu = (160*1024) / (c->tr_lds ? c->tr_lds : 1); if ( percu > 8 ) percu = 8; if ( percu < 1 ) percu = 1;
+		// resident workgroups per CU: LDS is handed out in granules of 1280 bytes (measured, round 5); k_trace holds 92 registers = 5 wavefronts per SIMD
+		uint64_t percu = (160*1024) / ((((c->tr_lds ? c->tr_lds : 1) + 1279u)/1280u)*1280u); if ( percu > (c->tr_words == 2 ? 16u : 8u) ) percu = (c->tr_words == 2 ? 16u : 8u); if ( percu < 1 ) percu = 1;
+		if ( char const * e = getenv("DACC_TR_PERCU") ) { uint64_t const v = strtoull(e,0,10); if ( v >= 1 && v <= 32 ) percu = v; }
 		// two word kernel: exactly the resident workgroups (grid stride over the blocks), so that the checkpoint slabs
 		// (53 KB per workgroup at a B span of 160) stay in the L2 / Infinity Cache
 		uint64_t g = (BP.nblocks+c->tr_lanes-1)/c->tr_lanes, gmax = 256*percu*(c->tr_words == 2 ? 1 : 4);

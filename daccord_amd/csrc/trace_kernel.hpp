@@ -90,17 +90,31 @@ struct TCol { uint64_t pv0, mv0, pv1, mv1; uint32_t score; };
 //
 // Two word kernel (k_trace, tspace <= 128; round 3): the CHECKPOINTS of a lane go to a global scratch slab of its workgroup
 // (coalesced 512 byte rows, written once and read once per block; the slabs of all resident workgroups stay in the L2 /
-// Infinity Cache), only the segment being walked (its checkpoint + T2S recomputed columns) is in LDS: 19.6 KB per wavefront =
-// 8 wavefronts per CU.  With checkpoints AND segment in LDS (58.7 KB, rounds 1-2) two wavefronts shared a CU -- two of its
+// Infinity Cache), only the segment being walked (its first column + T2S recomputed columns) is in LDS: 19.6 KB per wavefront =
+// 8 wavefronts per CU with segments of 8 columns (rounds 3-5), 10.9 KB = 14 per CU with segments of 4 (round 6).  With checkpoints AND segment in LDS (58.7 KB, rounds 1-2) two wavefronts shared a CU -- two of its
 // four SIMDs had no wavefront at all -- and the kernel, which is a chain of dependent 64 bit VALU operations per lane, ran
 // at 39 % VALU issue per resident wavefront.
 enum { TRS = 16 };      // wide kernels (k_trace_wide): checkpoints and segment in LDS
-enum { T2S = 8 };       // two word kernel: columns per segment
+// two word kernel: T2C columns between checkpoints (global slab), T2S columns per segment (LDS).  The traceback enters a segment by
+// recomputing from the checkpoint at or before it: the columns in front of the segment are stepped over without being stored.
+// (round 6) T2S < T2C trades recomputed columns for LDS bytes = resident wavefronts: the kernel is a chain of dependent 64 bit
+// operations per lane with the SIMDs idle most of the time (VALU busy 14 % at 8 wavefronts per CU, profiles/r06i_pmc_summary.json).
+#if !defined(DACC_T2C)
+#define DACC_T2C 8
+#endif
+// Measured (profiles/r06p, 3000 reads of config 2, 5.4 M blocks): segments of 8 / 4 / 2 columns = 8 / 14 / 16 wavefronts per CU: 16.3 / 13.9 / 17.7 ms
+// (checkpoints every 4 columns with segments of 4: 15.9 ms -- twice the slab traffic for the same LDS).  With 55 % of the SIMDs' VALU slots
+// already taken at 8 per CU the kernel is near its instruction bound, so the gain is the 15 % the extra wavefronts leave after the recomputation.
+#if !defined(DACC_T2S)
+#define DACC_T2S 4
+#endif
+enum { T2C = DACC_T2C, T2S = DACC_T2S };
+static_assert(T2C % T2S == 0 && T2C <= 16,"segments tile the checkpoint groups; a group's B symbols are kept packed in 32 bits");
 // segment slots of the 64 lanes of a wavefront interleaved, word q of slot e of lane l at (e*4+q)*64 + l (no bank conflicts
 // whatever slot a lane is at); slot 0 = the segment's checkpoint column, slot u = column g*T2S+u
 struct TraceStoreGL
 {
-	enum : uint32_t { SEG = T2S };
+	enum : uint32_t { SEG = T2S, CPS = T2C };
 	uint64_t * g;                 // this workgroup's slab: word q (0-3 vectors, 4 score) of checkpoint e of lane l at (e*5+q)*64 + l
 	LDSQ uint64_t * w; LDSQ uint16_t * sc; uint32_t lane;
 	DEV void putCp(uint32_t const e, TCol const & c) const
@@ -127,7 +141,7 @@ struct TraceStoreGL
 // host emulation: plain arrays of one thread (cp: traceCheckpoints(maxcols) columns, seg: T2S+1 columns)
 struct TraceStoreMem
 {
-	enum : uint32_t { SEG = T2S };
+	enum : uint32_t { SEG = T2S, CPS = T2C };
 	TCol * cp; TCol * seg;
 	void putCp(uint32_t const e, TCol const & c) const { cp[e] = c; }
 	TCol getCp(uint32_t const e) const { return cp[e]; }
@@ -135,7 +149,7 @@ struct TraceStoreMem
 	TCol getSeg(uint32_t const u) const { return seg[u]; }
 };
 HDEV uint32_t traceSlots(uint32_t const maxcols) { return maxcols/TRS + 1 + TRS; }     // wide kernels: checkpoints 0,TRS,2*TRS,.. + one segment
-HDEV uint32_t traceCheckpoints(uint32_t const maxcols) { return maxcols/T2S + 1; }     // two word kernel: checkpoints per lane (global slab)
+HDEV uint32_t traceCheckpoints(uint32_t const maxcols) { return maxcols/T2C + 1; }     // two word kernel: checkpoints per lane (global slab)
 HDEV uint32_t traceSlabWords(uint32_t const maxcols) { return traceCheckpoints(maxcols)*5u*64u; }      // 64 bit words per workgroup
 enum : uint32_t { TRACE2_LDS = (T2S+1)*64*34 };      // LDS bytes of a wavefront of k_trace
 
@@ -199,16 +213,17 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 	bool const two = m > 64;
 	uint64_t const top = two ? (1ull<<(m-65)) : (1ull<<(m-1));
 	constexpr uint32_t TRS = ST::SEG;      // columns per segment (shadows the wide kernels' constant)
+	constexpr uint32_t CPS = ST::CPS;      // columns between checkpoints
 	TCol C; C.pv0 = mask0; C.mv0 = 0; C.pv1 = mask1; C.mv1 = 0; C.score = m;
 	st.putCp(0,C);
-	// B symbols are fetched TRS at a time (independent loads, one wait) and kept packed 2 bits each
-	#define DACC_LOADB(c0_,cnt_,dst_) { dst_ = 0; _Pragma("unroll") for ( uint32_t u = 0; u < TRS; ++u ) if ( u < (cnt_) ) dst_ |= static_cast<uint32_t>(readBase(B.bps,boffs,brl,inv,b0+(c0_)+u)) << (2*u); }
-	for ( uint32_t c0 = 0; c0 < n; c0 += TRS )
+	// B symbols are fetched CPS at a time (independent loads, one wait) and kept packed 2 bits each
+	#define DACC_LOADB(c0_,cnt_,dst_) { dst_ = 0; _Pragma("unroll") for ( uint32_t u = 0; u < CPS; ++u ) if ( u < (cnt_) ) dst_ |= static_cast<uint32_t>(readBase(B.bps,boffs,brl,inv,b0+(c0_)+u)) << (2*u); }
+	for ( uint32_t c0 = 0; c0 < n; c0 += CPS )
 	{
-		uint32_t const cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
+		uint32_t const cnt = (n-c0 < CPS) ? (n-c0) : static_cast<uint32_t>(CPS);
 		uint32_t bb; DACC_LOADB(c0,cnt,bb)
 		for ( uint32_t u = 0; u < cnt; ++u ) traceStep(peq,(bb>>(2*u))&3,C,mask0,mask1,two,top);
-		if ( cnt == TRS ) st.putCp(c0/TRS+1,C);
+		if ( cnt == CPS ) st.putCp(c0/CPS+1,C);
 	}
 	// window boundaries are rare among the A positions: x is a window start iff x % a == 0 or x == l-w, a window end iff
 	// (x-w) % a == 0 or x == l; x % a is tracked incrementally (no division per step)
@@ -225,10 +240,15 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 		if ( !(i && j && (j-1)/TRS == static_cast<uint32_t>(g)) ) continue;
 		uint32_t bseg;
 		{
-			TCol R = st.getCp(g);
+			// checkpoint at or before the segment's first column; `skip` columns between them are stepped over
+			uint32_t const cpi = (static_cast<uint32_t>(g)*TRS)/CPS, cp0 = cpi*CPS, skip = static_cast<uint32_t>(g)*TRS - cp0;
+			TCol R = st.getCp(cpi);
+			uint32_t const cntall = (n-cp0 < CPS) ? (n-cp0) : static_cast<uint32_t>(CPS);
+			uint32_t bcp; DACC_LOADB(cp0,cntall,bcp)
+			if ( CPS != TRS ) for ( uint32_t u = 0; u < skip; ++u ) traceStep(peq,(bcp>>(2*u))&3,R,mask0,mask1,two,top);
 			st.putSeg(0,R);
+			bseg = bcp >> (2*skip);
 			uint32_t const c0 = g*TRS, cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
-			DACC_LOADB(c0,cnt,bseg)
 			for ( uint32_t u = 0; u < cnt; ++u )
 			{
 				traceStep(peq,(bseg>>(2*u))&3,R,mask0,mask1,two,top);

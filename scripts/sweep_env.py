@@ -25,10 +25,10 @@ def main():
         E = engine.Engine(default_params(k=int(os.environ.get("SWEEP_K", "14"))))
         E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
         fr, ba = E(piles, ovl, d.trace)
-        t0 = time.perf_counter(); tier = [0.0, 0.0, 0.0]; win = 0.0
+        t0 = time.perf_counter(); tier = [0.0, 0.0, 0.0]; win = 0.0; trc = 0.0; vot = 0.0
         for _ in range(steps):
             E.rerun(); fr, ba = E.collect(); t = E.timing()
-            win += t.window_ms
+            win += t.window_ms; trc += t.trace_ms; vot += t.vote_ms
             for i in range(3):
                 tier[i] += t.tier_ms[i]
         dt = (time.perf_counter() - t0) / steps
@@ -36,7 +36,7 @@ def main():
         for i in range(0, len(fr), 256):
             h.update(engine.fasta(fr[i:i + 256], ba, start_well=well).encode()); well += len(fr[i:i + 256])
         print(json.dumps({"setting": setting, "ms_per_step": round(1e3 * dt, 2), "mbase_s": round(len(ba) / dt / 1e6, 3),
-                          "window_ms": round(win / steps, 2), "tier_ms": [round(x / steps, 2) for x in tier],
+                          "trace_ms": round(trc / steps, 2), "vote_ms": round(vot / steps, 2), "window_ms": round(win / steps, 2), "tier_ms": [round(x / steps, 2) for x in tier],
                           "handed_on": [int(t.tier_out[i]) for i in range(3)], "t0": [round(float(t.tier0_ms), 1), int(t.tier0_in), int(t.tier0_out)],
                           "t7": [round(float(getattr(t, "tier7_ms", 0.0)), 1), int(getattr(t, "tier7_in", 0)), int(getattr(t, "tier7_out", 0))], "sha": h.hexdigest()[:16]}), flush=True)
         del E
