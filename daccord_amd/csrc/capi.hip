@@ -42,13 +42,13 @@ __global__ void k_prep(PrepBatch B)
 }
 
 // one lane per tspace block, one wavefront per workgroup; the column checkpoints of every lane go to the workgroup's global
-// slab, the segment the traceback is in lives in the workgroup's dynamic LDS (TRACE2_LDS = 10.9 KB: 14 wavefronts per CU)
+// slab, the segment the traceback is in lives in the workgroup's dynamic LDS (TRACE2_LDS = 8 KB)
 __global__ void __launch_bounds__(64) k_trace(TraceBatch B)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds_trace[];
 	TraceStoreGL st;
 	st.g = B.slab + static_cast<size_t>(blockIdx.x)*traceSlabWords(B.maxcols);
-	st.w = (LDSQ uint64_t *)lds_trace; st.sc = (LDSQ uint16_t *)(lds_trace + static_cast<size_t>(T2S+1)*4*64*8); st.lane = threadIdx.x;
+	st.w = (LDSQ uint32_t *)lds_trace; st.lane = threadIdx.x;
 	for ( uint64_t task = static_cast<uint64_t>(blockIdx.x)*64 + threadIdx.x; task < B.nblocks; task += static_cast<uint64_t>(gridDim.x)*64 )
 		traceBlock(B,task,st);
 }
@@ -901,7 +901,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			else HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_trace_wide<8>),hipFuncAttributeMaxDynamicSharedMemorySize,c->tr_lds));
 		}
 		// resident workgroups per CU: LDS is handed out in granules of 1280 bytes (measured, round 5); k_trace holds 92 registers = 5 wavefronts per SIMD
-		uint64_t percu = (160*1024) / ((((c->tr_lds ? c->tr_lds : 1) + 1279u)/1280u)*1280u); if ( percu > (c->tr_words == 2 ? 16u : 8u) ) percu = (c->tr_words == 2 ? 16u : 8u); if ( percu < 1 ) percu = 1;
+		uint64_t percu = (160*1024) / ((((c->tr_lds ? c->tr_lds : 1) + 1279u)/1280u)*1280u); if ( percu > (c->tr_words == 2 ? 20u : 8u) ) percu = (c->tr_words == 2 ? 20u : 8u); if ( percu < 1 ) percu = 1;
 		if ( char const * e = getenv("DACC_TR_PERCU") ) { uint64_t const v = strtoull(e,0,10); if ( v >= 1 && v <= 32 ) percu = v; }
 		// two word kernel: exactly the resident workgroups (grid stride over the blocks), so that the checkpoint slabs
 		// (53 KB per workgroup at a B span of 160) stay in the L2 / Infinity Cache

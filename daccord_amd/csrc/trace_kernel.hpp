@@ -81,80 +81,89 @@ DEV void emitBoundary(TraceBatch const & B, DevPile const & pile, DevOvl const &
 	}
 }
 
-// One column of the bit-parallel alignment: vertical delta vectors (two 64-bit words for up to 128 A rows) and the score
-// of the bottom row.
-struct TCol { uint64_t pv0, mv0, pv1, mv1; uint32_t score; };
+// One column of the bit-parallel alignment: vertical delta vectors (two 64-bit words for up to 128 A rows).
+struct TCol { uint64_t pv0, mv0, pv1, mv1; };
 
-// Column stores.  The forward pass keeps only every TRS-th column (checkpoints); the traceback, which walks the columns
-// downwards, recomputes the TRS columns of a segment from its checkpoint when it enters the segment.
+// Column stores.  The forward pass keeps only every T2C-th column (checkpoints); the traceback, which walks the columns
+// downwards, recomputes the columns of a segment from the checkpoint at or before it when it enters the segment.
 //
 // Two word kernel (k_trace, tspace <= 128; round 3): the CHECKPOINTS of a lane go to a global scratch slab of its workgroup
 // (coalesced 512 byte rows, written once and read once per block; the slabs of all resident workgroups stay in the L2 /
-// Infinity Cache), only the segment being walked (its first column + T2S recomputed columns) is in LDS: 19.6 KB per wavefront =
-// 8 wavefronts per CU with segments of 8 columns (rounds 3-5), 10.9 KB = 14 per CU with segments of 4 (round 6).  With checkpoints AND segment in LDS (58.7 KB, rounds 1-2) two wavefronts shared a CU -- two of its
-// four SIMDs had no wavefront at all -- and the kernel, which is a chain of dependent 64 bit VALU operations per lane, ran
-// at 39 % VALU issue per resident wavefront.
+// Infinity Cache), only the segment being walked is in LDS.  With checkpoints AND segment in LDS (58.7 KB, rounds 1-2) two
+// wavefronts shared a CU -- two of its four SIMDs had no wavefront at all.
+//
+// (round 6) What a segment column holds is what the traceback DECIDES on, not the delta vectors: with D = the edit distance matrix,
+// vd(i,j) = D[i][j]-D[i-1][j] and hd(i,j) = D[i][j]-D[i][j-1],
+//     D[i-1][j-1] = D[i][j] - vd(i,j) - hd(i-1,j),
+// so the diagonal step (priority 1) is taken iff A[i-1] == B[j-1] (then D[i-1][j-1] == D[i][j] always) or vd(i,j) + hd(i-1,j) == 1, i.e.
+// (vd = +1 and hd = 0) or (vd = 0 and hd = +1); DEL (priority 2) iff vd(i,j) = +1.  Both are bits of the column step's own vectors (the
+// shifted horizontal deltas Ph / Mh ARE hd(i-1,j) at bit i-1), so a recomputed column stores DIAG = Eq | (Pv & ~(Ph|Mh)) | (~Pv & ~Mv & Ph)
+// and Pv: 32 bytes per lane and column as before, but a traceback step is two 32 bit LDS reads and two bit tests instead of the five reads,
+// two 64 bit shifts and twelve population counts that rebuilt D[i-1][j-1] from the bottom row's score (rounds 1-5); no score is carried at
+// all, and the segment's first column (slot 0 of the old layout) is not needed.  The decisions are the same by construction: the old test
+// `D[i-1][j-1] + (A[i-1] != B[j-1]) == D[i][j]` is the DIAG bit.  k_trace was the one kernel of the step near its instruction bound
+// (VALU 55 % of the SIMDs' slots at 8 wavefronts per CU): 64 k -> 45 k VALU instructions per wavefront and block round.
 enum { TRS = 16 };      // wide kernels (k_trace_wide): checkpoints and segment in LDS
 // two word kernel: T2C columns between checkpoints (global slab), T2S columns per segment (LDS).  The traceback enters a segment by
 // recomputing from the checkpoint at or before it: the columns in front of the segment are stepped over without being stored.
-// (round 6) T2S < T2C trades recomputed columns for LDS bytes = resident wavefronts: the kernel is a chain of dependent 64 bit
-// operations per lane with the SIMDs idle most of the time (VALU busy 14 % at 8 wavefronts per CU, profiles/r06i_pmc_summary.json).
+// T2S < T2C trades recomputed columns for LDS bytes = resident wavefronts.
+// Measured with the old column format (profiles/r06p, 3000 reads of config 2, 5.4 M blocks): segments of 8 / 4 / 2 columns = 8 / 14 / 16
+// wavefronts per CU: 16.3 / 13.9 / 17.7 ms (checkpoints every 4 columns with segments of 4: 15.9 ms -- twice the slab traffic for the same LDS).
 #if !defined(DACC_T2C)
 #define DACC_T2C 8
 #endif
-// Measured (profiles/r06p, 3000 reads of config 2, 5.4 M blocks): segments of 8 / 4 / 2 columns = 8 / 14 / 16 wavefronts per CU: 16.3 / 13.9 / 17.7 ms
-// (checkpoints every 4 columns with segments of 4: 15.9 ms -- twice the slab traffic for the same LDS).  With 55 % of the SIMDs' VALU slots
-// already taken at 8 per CU the kernel is near its instruction bound, so the gain is the 15 % the extra wavefronts leave after the recomputation.
 #if !defined(DACC_T2S)
 #define DACC_T2S 4
 #endif
 enum { T2C = DACC_T2C, T2S = DACC_T2S };
 static_assert(T2C % T2S == 0 && T2C <= 16,"segments tile the checkpoint groups; a group's B symbols are kept packed in 32 bits");
-// segment slots of the 64 lanes of a wavefront interleaved, word q of slot e of lane l at (e*4+q)*64 + l (no bank conflicts
-// whatever slot a lane is at); slot 0 = the segment's checkpoint column, slot u = column g*T2S+u
+// segment slots of the 64 lanes of a wavefront interleaved in 32 bit units: field f (0-3: DIAG bits 0-31, 32-63, 64-95, 96-127; 4-7: Pv) of
+// slot u of lane l at (u*8+f)*64 + l (no bank conflicts whatever slot and row a lane is at); slot u = column g*T2S+1+u
 struct TraceStoreGL
 {
 	enum : uint32_t { SEG = T2S, CPS = T2C };
-	uint64_t * g;                 // this workgroup's slab: word q (0-3 vectors, 4 score) of checkpoint e of lane l at (e*5+q)*64 + l
-	LDSQ uint64_t * w; LDSQ uint16_t * sc; uint32_t lane;
+	uint64_t * g;                 // this workgroup's slab: word q (Pv0, Mv0, Pv1, Mv1) of checkpoint e of lane l at (e*4+q)*64 + l
+	LDSQ uint32_t * w; uint32_t lane;
 	DEV void putCp(uint32_t const e, TCol const & c) const
 	{
-		uint64_t * p = g + (e*5)*64 + lane;
-		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1; p[256] = c.score;
+		uint64_t * p = g + (e*4)*64 + lane;
+		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1;
 	}
 	DEV TCol getCp(uint32_t const e) const
 	{
-		uint64_t const * p = g + (e*5)*64 + lane;
-		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; c.score = static_cast<uint32_t>(p[256]); return c;
+		uint64_t const * p = g + (e*4)*64 + lane;
+		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; return c;
 	}
-	DEV void putSeg(uint32_t const u, TCol const & c) const
+	DEV void putSeg(uint32_t const u, uint64_t const d0, uint64_t const d1, uint64_t const p0, uint64_t const p1) const
 	{
-		LDSQ uint64_t * p = w + (u*4)*64 + lane;
-		p[0] = c.pv0; p[64] = c.mv0; p[128] = c.pv1; p[192] = c.mv1; sc[u*64+lane] = static_cast<uint16_t>(c.score);
+		LDSQ uint32_t * p = w + (u*8)*64 + lane;
+		p[0] = static_cast<uint32_t>(d0); p[64] = static_cast<uint32_t>(d0>>32); p[128] = static_cast<uint32_t>(d1); p[192] = static_cast<uint32_t>(d1>>32);
+		p[256] = static_cast<uint32_t>(p0); p[320] = static_cast<uint32_t>(p0>>32); p[384] = static_cast<uint32_t>(p1); p[448] = static_cast<uint32_t>(p1>>32);
 	}
-	DEV TCol getSeg(uint32_t const u) const
-	{
-		LDSQ uint64_t const * p = w + (u*4)*64 + lane;
-		TCol c; c.pv0 = p[0]; c.mv0 = p[64]; c.pv1 = p[128]; c.mv1 = p[192]; c.score = sc[u*64+lane]; return c;
-	}
+	// bits 32*(r>>5) .. +31 of the DIAG / the Pv vector of slot u
+	DEV uint32_t segDiag(uint32_t const u, uint32_t const r) const { return w[(u*8 + (r>>5))*64 + lane]; }
+	DEV uint32_t segPv(uint32_t const u, uint32_t const r) const { return w[(u*8 + 4 + (r>>5))*64 + lane]; }
 };
-// host emulation: plain arrays of one thread (cp: traceCheckpoints(maxcols) columns, seg: T2S+1 columns)
+// host emulation: plain arrays of one thread (cp: traceCheckpoints(maxcols) columns, seg: 4 words (DIAG, Pv) per segment column)
 struct TraceStoreMem
 {
 	enum : uint32_t { SEG = T2S, CPS = T2C };
-	TCol * cp; TCol * seg;
+	TCol * cp; uint64_t * seg;
 	void putCp(uint32_t const e, TCol const & c) const { cp[e] = c; }
 	TCol getCp(uint32_t const e) const { return cp[e]; }
-	void putSeg(uint32_t const u, TCol const & c) const { seg[u] = c; seg[u].score = static_cast<uint16_t>(c.score); }
-	TCol getSeg(uint32_t const u) const { return seg[u]; }
+	void putSeg(uint32_t const u, uint64_t const d0, uint64_t const d1, uint64_t const p0, uint64_t const p1) const { seg[4*u] = d0; seg[4*u+1] = d1; seg[4*u+2] = p0; seg[4*u+3] = p1; }
+	uint32_t segDiag(uint32_t const u, uint32_t const r) const { return static_cast<uint32_t>(seg[4*u + (r>>6)] >> (32*((r>>5)&1))); }
+	uint32_t segPv(uint32_t const u, uint32_t const r) const { return static_cast<uint32_t>(seg[4*u + 2 + (r>>6)] >> (32*((r>>5)&1))); }
 };
 HDEV uint32_t traceSlots(uint32_t const maxcols) { return maxcols/TRS + 1 + TRS; }     // wide kernels: checkpoints 0,TRS,2*TRS,.. + one segment
 HDEV uint32_t traceCheckpoints(uint32_t const maxcols) { return maxcols/T2C + 1; }     // two word kernel: checkpoints per lane (global slab)
-HDEV uint32_t traceSlabWords(uint32_t const maxcols) { return traceCheckpoints(maxcols)*5u*64u; }      // 64 bit words per workgroup
-enum : uint32_t { TRACE2_LDS = (T2S+1)*64*34 };      // LDS bytes of a wavefront of k_trace
+HDEV uint32_t traceSlabWords(uint32_t const maxcols) { return traceCheckpoints(maxcols)*4u*64u; }      // 64 bit words per workgroup
+enum : uint32_t { TRACE2_LDS = T2S*64*32 };      // LDS bytes of a wavefront of k_trace
 
-// Myers / Hyyro column step: C = column c -> column c+1 for B symbol tc
-DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, uint64_t const mask0, uint64_t const mask1, bool const two, uint64_t const top)
+// Myers / Hyyro column step: C = column c -> column c+1 for B symbol tc.  DIAGS: also the traceback's decision bits of the new column
+// (dg0 / dg1, see above).  No masking of the rows beyond the block's m: carries only travel upwards and no row >= m is ever read.
+template<bool DIAGS>
+DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, bool const two, uint64_t & dg0, uint64_t & dg1)
 {
 	uint64_t const Eq0 = peq[2*tc], Eq1 = peq[2*tc+1];
 	uint64_t const Xv0 = Eq0 | C.mv0;
@@ -162,10 +171,10 @@ DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, uint64_t co
 	uint64_t Ph0 = C.mv0 | ~(Xh0 | C.pv0);
 	uint64_t Mh0 = C.pv0 & Xh0;
 	uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
-	if ( !two ) { if ( Ph0 & top ) ++C.score; else if ( Mh0 & top ) --C.score; }
-	Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
-	C.pv0 = (Mh0 | ~(Xv0 | Ph0)) & mask0;
-	C.mv0 = (Ph0 & Xv0) & mask0;
+	Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;      // bit r: horizontal delta of row r (row 0 = the top boundary: +1, global alignment)
+	C.pv0 = Mh0 | ~(Xv0 | Ph0);
+	C.mv0 = Ph0 & Xv0;
+	if ( DIAGS ) dg0 = Eq0 | (C.pv0 & ~(Ph0|Mh0)) | (~(C.pv0|C.mv0) & Ph0);
 	if ( two )
 	{
 		uint64_t const Eq1c = Eq1 | mhc;
@@ -173,14 +182,14 @@ DEV void traceStep(uint64_t const * peq, uint8_t const tc, TCol & C, uint64_t co
 		uint64_t const Xh1 = (((Eq1c & C.pv1) + C.pv1) ^ C.pv1) | Eq1c;
 		uint64_t Ph1 = C.mv1 | ~(Xh1 | C.pv1);
 		uint64_t Mh1 = C.pv1 & Xh1;
-		if ( Ph1 & top ) ++C.score; else if ( Mh1 & top ) --C.score;
 		Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
-		C.pv1 = (Mh1 | ~(Xv1 | Ph1)) & mask1;
-		C.mv1 = (Ph1 & Xv1) & mask1;
+		C.pv1 = Mh1 | ~(Xv1 | Ph1);
+		C.mv1 = Ph1 & Xv1;
+		if ( DIAGS ) dg1 = Eq1 | (C.pv1 & ~(Ph1|Mh1)) | (~(C.pv1|C.mv1) & Ph1);
 	}
 }
 
-// task = block id; ST = column store of this thread (traceCheckpoints(B.maxcols) checkpoints, ST::SEG+1 segment columns)
+// task = block id; ST = column store of this thread (traceCheckpoints(B.maxcols) checkpoints, ST::SEG segment columns)
 template<typename ST>
 DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 {
@@ -211,18 +220,18 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 	uint64_t const mask0 = (m >= 64) ? ~0ull : ((1ull<<m)-1);
 	uint64_t const mask1 = (m <= 64) ? 0ull : ((m == 128) ? ~0ull : ((1ull<<(m-64))-1));
 	bool const two = m > 64;
-	uint64_t const top = two ? (1ull<<(m-65)) : (1ull<<(m-1));
 	constexpr uint32_t TRS = ST::SEG;      // columns per segment (shadows the wide kernels' constant)
 	constexpr uint32_t CPS = ST::CPS;      // columns between checkpoints
-	TCol C; C.pv0 = mask0; C.mv0 = 0; C.pv1 = mask1; C.mv1 = 0; C.score = m;
+	TCol C; C.pv0 = mask0; C.mv0 = 0; C.pv1 = mask1; C.mv1 = 0;
 	st.putCp(0,C);
+	uint64_t dg0 = 0, dg1 = 0;
 	// B symbols are fetched CPS at a time (independent loads, one wait) and kept packed 2 bits each
 	#define DACC_LOADB(c0_,cnt_,dst_) { dst_ = 0; _Pragma("unroll") for ( uint32_t u = 0; u < CPS; ++u ) if ( u < (cnt_) ) dst_ |= static_cast<uint32_t>(readBase(B.bps,boffs,brl,inv,b0+(c0_)+u)) << (2*u); }
 	for ( uint32_t c0 = 0; c0 < n; c0 += CPS )
 	{
 		uint32_t const cnt = (n-c0 < CPS) ? (n-c0) : static_cast<uint32_t>(CPS);
 		uint32_t bb; DACC_LOADB(c0,cnt,bb)
-		for ( uint32_t u = 0; u < cnt; ++u ) traceStep(peq,(bb>>(2*u))&3,C,mask0,mask1,two,top);
+		for ( uint32_t u = 0; u < cnt; ++u ) traceStep<false>(peq,(bb>>(2*u))&3,C,two,dg0,dg1);
 		if ( cnt == CPS ) st.putCp(c0/CPS+1,C);
 	}
 	// window boundaries are rare among the A positions: x is a window start iff x % a == 0 or x == l-w, a window end iff
@@ -231,63 +240,35 @@ DEV void traceBlock(TraceBatch const & B, uint64_t const task, ST const & st)
 	uint32_t xa = (a0+m) % B.P.a;
 	#define DACC_EMIT(x_,b_) { uint32_t const xx_ = (x_); if ( xa == 0 || xa == wa || xx_ == lw || xx_ == pile.l ) emitBoundary(B,pile,o,xx_,b_); }
 	#define DACC_XDEC { xa = xa ? xa-1 : B.P.a-1; }
-	// traceback.  Step (i,j) with j >= 1 reads columns j and j-1 and the B symbol of step j, all of which lie in segment
-	// (j-1)/TRS or are checkpoints.  The segments are visited in a loop that is uniform over the wavefront (top segment of
-	// the batch downwards), so the lanes recompute their segments in lock step instead of one lane at a time.
-	uint32_t i = m, j = n, d = C.score;
+	// traceback.  Step (i,j) with j >= 1 reads the decision bits of column j, which lies in segment (j-1)/TRS.  The segments are visited in
+	// a loop that is uniform over the wavefront (top segment of the batch downwards), so the lanes recompute their segments in lock step
+	// instead of one lane at a time.
+	uint32_t i = m, j = n;
 	for ( int32_t g = static_cast<int32_t>((B.maxcols ? B.maxcols-1 : 0)/TRS); g >= 0; --g )
 	{
 		if ( !(i && j && (j-1)/TRS == static_cast<uint32_t>(g)) ) continue;
-		uint32_t bseg;
 		{
-			// checkpoint at or before the segment's first column; `skip` columns between them are stepped over
+			// checkpoint at or before the segment's first column; the `skip` columns between them are stepped over
 			uint32_t const cpi = (static_cast<uint32_t>(g)*TRS)/CPS, cp0 = cpi*CPS, skip = static_cast<uint32_t>(g)*TRS - cp0;
 			TCol R = st.getCp(cpi);
 			uint32_t const cntall = (n-cp0 < CPS) ? (n-cp0) : static_cast<uint32_t>(CPS);
 			uint32_t bcp; DACC_LOADB(cp0,cntall,bcp)
-			if ( CPS != TRS ) for ( uint32_t u = 0; u < skip; ++u ) traceStep(peq,(bcp>>(2*u))&3,R,mask0,mask1,two,top);
-			st.putSeg(0,R);
-			bseg = bcp >> (2*skip);
+			if ( CPS != TRS ) for ( uint32_t u = 0; u < skip; ++u ) traceStep<false>(peq,(bcp>>(2*u))&3,R,two,dg0,dg1);
+			uint32_t const bseg = bcp >> (2*skip);
 			uint32_t const c0 = g*TRS, cnt = (n-c0 < TRS) ? (n-c0) : static_cast<uint32_t>(TRS);
 			for ( uint32_t u = 0; u < cnt; ++u )
 			{
-				traceStep(peq,(bseg>>(2*u))&3,R,mask0,mask1,two,top);
-				st.putSeg(u+1,R);
+				traceStep<true>(peq,(bseg>>(2*u))&3,R,two,dg0,dg1);
+				st.putSeg(u,dg0,dg1,R.pv0,R.pv1);      // column c0+u+1
 			}
 		}
 		while ( i && j && (j-1)/TRS == static_cast<uint32_t>(g) )
 		{
-			bool done = false;
-			{
-				// D[i-1][j-1] = bottom(j-1) - sum of vertical deltas of rows i..m in column j-1
-				TCol const q = st.getSeg((j-1) - g*TRS);      // column j-1: slot 0 is the segment's checkpoint
-				uint32_t const sh = i-1;
-				int32_t sum;
-				if ( sh < 64 ) sum = dacc_popc64(q.pv0>>sh) + dacc_popc64(q.pv1) - dacc_popc64(q.mv0>>sh) - dacc_popc64(q.mv1);
-				else sum = dacc_popc64(q.pv1>>(sh-64)) - dacc_popc64(q.mv1>>(sh-64));
-				uint32_t const dd = q.score - sum;
-				// A[i-1] == B[j-1] <=> bit i-1 of the pattern mask of B's symbol
-				uint32_t const cb = (bseg >> (2*((j-1) - g*TRS))) & 3;
-				uint32_t const neq = ((peq[2*cb + (sh>>6)] >> (sh&63)) & 1) ? 0u : 1u;
-				if ( dd + neq == d )
-				{
-					DACC_EMIT(a0+i,b0+j)
-					--i; --j; d = dd; done = true; DACC_XDEC
-				}
-			}
-			if ( !done )
-			{
-				uint32_t const r = i-1;
-				uint64_t cp0, cp1;
-				{ TCol const cj = st.getSeg(j - g*TRS); cp0 = cj.pv0; cp1 = cj.pv1; }      // column j (j-1 lies in segment g, so j <= g*TRS+TRS)
-				bool const plus = (r < 64) ? ((cp0>>r)&1) : ((cp1>>(r-64))&1);
-				if ( plus )
-				{
-					DACC_EMIT(a0+i,b0+j)
-					--i; d = d-1; done = true; DACC_XDEC
-				}
-			}
-			if ( !done ) { --j; d = d-1; }
+			uint32_t const u = (j-1) - g*TRS, r = i-1;
+			uint32_t const dw = st.segDiag(u,r), pw = st.segPv(u,r);
+			bool const diag = (dw >> (r&31)) & 1, del = (pw >> (r&31)) & 1;
+			if ( diag || del ) { DACC_EMIT(a0+i,b0+j) --i; DACC_XDEC }
+			if ( diag || !del ) --j;
 		}
 	}
 	// column 0: only A symbols are left (vertical deltas of the first column are all +1)

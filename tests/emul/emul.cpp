@@ -162,7 +162,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		TB.blk_ovl = blk_ovl.data(); TB.blk_b0 = blk_b0.data(); TB.nblocks = BP.nblocks;
 		TB.wt_b = wt_b.data(); TB.wt_e = wt_e.data();
 		std::vector<uint64_t> colw(traceSlots(BP.maxcols)*4); std::vector<uint16_t> colsc(traceSlots(BP.maxcols));
-		std::vector<TCol> cps(traceCheckpoints(BP.maxcols)), segs(T2S+1);
+		std::vector<TCol> cps(traceCheckpoints(BP.maxcols)); std::vector<uint64_t> segs(4*T2S);
 		TraceStoreMem st; st.cp = cps.data(); st.seg = segs.data();
 		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag;
 		if ( P.tspace <= 128 && BP.maxcols <= 928 ) for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);   // as the library chooses (capi.hip: tr_words)
