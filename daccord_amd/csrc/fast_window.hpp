@@ -93,7 +93,16 @@ enum : uint32_t { T0INST_DEFAULT = 576, T7INST_DEFAULT = 704 };      // a window
 // (round 4: 76 KB = 2 wavefronts per CU instead of 46.5 KB = 3, with tier 3's node capacity: at 54x more than half of what the deep tier
 // hands on has more than 1024 nodes at filter frequency 1 and used to go through this tier only to be handed on again to tier 3, which
 // runs one wavefront per CU)
-template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 2048, scap = 232, lcap = 2304, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+// (round 6: 53 744 B = 42 LDS granules = THREE wavefronts per CU instead of 63.9 KB = two, with 1536 nodes and 2032 links instead of 2048 / 2304:
+// of the 65 903 windows the deep tier hands on in 1000 piles of the 54x shape 3045 went on to tier 3 before and 3329 do now, and the tier's
+// time falls from 96 to 66 ms -- 27.4 -> 30.1 Mbase/s, profiles/r06s; the node tables are 20 of its bytes per node)
+#if !defined(DACC_T2_NCAP)
+#define DACC_T2_NCAP 1536
+#endif
+#if !defined(DACC_T2_LCAP)
+#define DACC_T2_LCAP 2032
+#endif
+template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = DACC_T2_NCAP, scap = 232, lcap = DACC_T2_LCAP, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
 // tier 6 (second slot of SHALLOW batches since round 3, gw layout, 36 KB = 4 wavefronts per CU): what tier 1 hands on at 20x
 // are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
 // tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep

@@ -324,6 +324,62 @@ DEV void wv_sort_regs(PT A, uint32_t const n)
 	for ( int r = 0; r < R; ++r ) if ( base + r < n ) A[base+r] = v[r];
 	wv_sync();
 }
+// (round 6) 1024 < n <= 2048 keys with SIXTEEN registers per lane instead of 32: both halves of 1024 are sorted ascending in registers one
+// after the other, the first step of the last merge (element i against element 2047-i) takes its partners from memory, and the two halves --
+// bitonic sequences now, the lower holding the 1024 smallest keys -- are merged in registers (the half-cleaner steps at distances 512 ... 1).
+// The same number of compare-exchange steps as the 32-register network (2 x 55 + 1 + 2 x 10 passes over 16 registers against 66 over 32).
+// Built to get the deep tier (k_window_fast<4>: 302 + 46 registers) under 256; measured (profiles/r06r, 54x): the allocator takes what the
+// occupancy target leaves it either way (310 + 54 with this sort, uncapped), amdgpu_waves_per_eu(2) is what brings the kernel to 256, and
+// under that cap the 32-register network is 1 % faster (17 spilled dwords against 13).  Kept for A/B builds (-DDACC_SORT2H), not the default.
+template<int R>
+DEV void wv_sort_regs_merge_steps(uint64_t (&v)[R], uint32_t const lane, uint32_t const base, uint32_t const k, uint32_t const jfirst)
+{
+	for ( uint32_t j = jfirst; j >= static_cast<uint32_t>(R); j >>= 1 )
+	{
+		uint32_t const m = j/R;
+		bool const keepmin = ((lane & m) == 0) == ((base & k) == 0);
+		#pragma unroll
+		for ( int r = 0; r < R; ++r )
+		{
+			uint64_t const p = wv_shfl64(v[r],static_cast<int>(lane ^ m));
+			bool const plt = p < v[r];
+			v[r] = (plt == keepmin) ? p : v[r];
+		}
+	}
+	if ( R > 16 ) wv_sort_inlane<R,(R > 16 ? 16 : 1)>(v,base,k);
+	if ( R > 8 ) wv_sort_inlane<R,(R > 8 ? 8 : 1)>(v,base,k);
+	if ( R > 4 ) wv_sort_inlane<R,(R > 4 ? 4 : 1)>(v,base,k);
+	if ( R > 2 ) wv_sort_inlane<R,(R > 2 ? 2 : 1)>(v,base,k);
+	wv_sort_inlane<R,1>(v,base,k);
+}
+template<typename PT>
+DEV void wv_sort_two_halves(PT A, uint32_t const n)
+{
+	enum { R = 16, H = 64*R };
+	wv_sort_regs<R>(A,H);
+	wv_sort_regs<R>(A+H,n-H);
+	uint32_t const lane = wv_lane(), base = lane*R;
+	uint64_t v[R];
+	#pragma unroll
+	for ( int r = 0; r < R; ++r ) v[r] = A[base+r];
+	#pragma unroll
+	for ( int r = 0; r < R; ++r )
+	{
+		uint32_t const q = 2*H-1-(base+r);
+		if ( q < n ) { uint64_t const b = A[q]; if ( v[r] > b ) { A[q] = v[r]; v[r] = b; } }
+	}
+	wv_sort_regs_merge_steps<R>(v,lane,base,2*H,H/2);
+	wv_sync();
+	#pragma unroll
+	for ( int r = 0; r < R; ++r ) A[base+r] = v[r];
+	#pragma unroll
+	for ( int r = 0; r < R; ++r ) v[r] = (H+base+r < n) ? A[H+base+r] : ~0ull;
+	wv_sort_regs_merge_steps<R>(v,lane,base,2*H,H/2);
+	wv_sync();
+	#pragma unroll
+	for ( int r = 0; r < R; ++r ) if ( H+base+r < n ) A[H+base+r] = v[r];
+	wv_sync();
+}
 #endif
 // ascending sort of n distinct 64-bit keys in memory (all lanes call); cap = compile time bound of n
 // R32: also keep up to 2048 keys in registers (32 per lane); only the deep tier asks for it
@@ -335,7 +391,11 @@ DEV void wv_sort_keys(PT A, uint32_t const n)
 	if ( CAP <= 256 || n <= 256 ) { wv_sort_regs<4>(A,n); return; }
 	if ( CAP <= 512 || n <= 512 ) { wv_sort_regs<8>(A,n); return; }
 	if ( CAP <= 1024 || n <= 1024 ) { wv_sort_regs<16>(A,n); return; }
+#if defined(DACC_SORT2H)
+	if ( R32 && (CAP <= 2048 || n <= 2048) ) { wv_sort_two_halves(A,n); return; }      // (A/B builds: two halves of 16 keys per lane)
+#else
 	if ( R32 && (CAP <= 2048 || n <= 2048) ) { wv_sort_regs<32>(A,n); return; }      // deep piles: 55 strings carry 1500 k-mer instances
+#endif
 #endif
 	wv_bitonic_sort_n(A,n);
 }

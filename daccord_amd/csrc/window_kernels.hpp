@@ -46,8 +46,14 @@ __global__ void __launch_bounds__(64) k_window_long(FastBatch FB, uint32_t * err
 #define DACC_WPE(T) __attribute__((amdgpu_waves_per_eu((T) <= 1 ? 2 : 1)))
 #elif defined(DACC_NUMVGPR_CAP)
 #define DACC_WPE(T) __attribute__((amdgpu_num_vgpr((T) <= 1 ? 256 : 512)))
-#else
+#elif defined(DACC_T4_NOWPE)
 #define DACC_WPE(T)
+#else
+// (round 6) the deep tier, k_window_fast<4>: its 31.5 KB of LDS allow FIVE wavefronts per CU, its 302 + 46 registers allowed four (one per
+// SIMD).  Unlike tiers 0 / 1 -- which sit a few registers below 256 on their own and lose 5 % under a cap -- it is nowhere near the bound by
+// itself: amdgpu_waves_per_eu(2) brings it to 256 registers with 17 spilled dwords (72 bytes of scratch) and the fifth wavefront is worth
+// -18 % on the tier, 24.4 -> 27.7 Mbase/s on the 54x shape (profiles/r06r).  amdgpu_num_vgpr(256) does not compile (allocation fails).
+#define DACC_WPE(T) __attribute__((amdgpu_waves_per_eu((T) == 4 ? 2 : 1)))
 #endif
 template<int TIER>
 __global__ void __launch_bounds__(64) DACC_WPE(TIER) k_window_fast(FastBatch FB, uint32_t const * list, uint32_t * work)
