@@ -49,6 +49,21 @@ __global__ void __launch_bounds__(64) k_trace(TraceBatch B)
 	TraceStoreGL st;
 	st.g = B.slab + static_cast<size_t>(blockIdx.x)*traceSlabWords(B.maxcols);
 	st.w = (LDSQ uint32_t *)lds_trace; st.lane = threadIdx.x;
+	if ( B.work )
+	{
+		// (round 6) rounds of 64 consecutive blocks drawn from a counter: with a fixed stride the workgroups whose blocks have long B spans
+		// were still running when the others had left (11.8 of 18 wavefronts per CU resident on average, profiles/r06t_pmc_summary.json)
+		while ( true )
+		{
+			uint32_t b = 0;
+			if ( threadIdx.x == 0 ) b = atomicAdd(B.work,64u);
+			b = __builtin_amdgcn_readfirstlane(b);
+			if ( b >= B.nblocks ) break;
+			uint64_t const task = static_cast<uint64_t>(b) + threadIdx.x;
+			if ( task < B.nblocks ) traceBlock(B,task,st);
+		}
+		return;
+	}
 	for ( uint64_t task = static_cast<uint64_t>(blockIdx.x)*64 + threadIdx.x; task < B.nblocks; task += static_cast<uint64_t>(gridDim.x)*64 )
 		traceBlock(B,task,st);
 }
@@ -366,7 +381,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; int env_trdyn; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
@@ -436,6 +451,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 31;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes), bit 4 tier 7 (the middle class; needs tier 0)
 		char const * l8 = getenv("DACC_LONG128"); c->env_long128 = !(l8 && l8[0] == '0');      // 0: windows with a string of 65 ... 128 bases run in tier 5 on the second stream (rounds 3-5)
+		{ char const * td = getenv("DACC_TRACE_DYN"); c->env_trdyn = !(td && td[0] == '0'); }      // 0: k_trace walks its blocks with a fixed stride (rounds 1-5)
 		char const * ta = getenv("DACC_T7_ADAPT"); c->env_t7adapt = !(ta && ta[0] == '0');      // 0: tier 7 stays on whatever it hands on
 		char const * t7 = getenv("DACC_T7INST"); c->env_t7inst = t7 ? static_cast<uint32_t>(atoi(t7)) : static_cast<uint32_t>(T7INST_DEFAULT);      // size-class threshold of tier 7
 		char const * l1 = getenv("DACC_LDS_T1"); c->env_lds_t1 = l1 ? static_cast<uint32_t>(atoi(l1)) : 0u;      // measurement only: LDS bytes requested for the first tier (more than it needs = fewer wavefronts per CU)
@@ -564,6 +580,8 @@ static int runDevice(dacc_ctx * c)
 		TB.piles = c->d_piles.p; TB.ovl = c->d_ovl.p; TB.ovl_pile = c->d_ovl_pile.p; TB.trace = c->d_trace.p;
 		TB.blk_ovl = c->d_blk_ovl.p; TB.blk_b0 = c->d_blk_b0.p; TB.nblocks = BP.nblocks; TB.wt_b = c->d_wt_b.p; TB.wt_e = c->d_wt_e.p;
 		TB.maxcols = BP.maxcols; TB.trace_bytes = c->trace_bytes; TB.errflag = c->d_err.p + 2; TB.slab = c->d_trslab.p;
+		TB.work = (c->env_trdyn && BP.nblocks < 0xFFFFFF00ull) ? c->d_work.p + 60 : static_cast<uint32_t *>(0);
+		if ( TB.work ) HIPCHK(hipMemsetAsync(TB.work,0,sizeof(uint32_t),s));
 		if ( c->tr_words == 2 ) hipLaunchKernelGGL(k_trace,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB);
 		else if ( c->tr_words == 4 ) hipLaunchKernelGGL(k_trace_wide<4>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);
 		else hipLaunchKernelGGL(k_trace_wide<8>,dim3(c->tr_grid),dim3(64),c->tr_lds,s,TB,c->tr_lanes);

@@ -37,6 +37,7 @@ struct TraceBatch
 	uint32_t trace_bytes; // 1 (tspace <= 125) or 2 bytes per trace value
 	uint32_t * errflag;
 	uint64_t * slab;      // two word kernel: checkpoint slabs, traceSlabWords(maxcols) 64 bit words per workgroup
+	uint32_t * work;      // two word kernel: counter the workgroups draw their rounds of 64 blocks from (0: grid stride)
 };
 
 // write P(x) into the window tables of overlap o where x is a window start / end

@@ -164,7 +164,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		std::vector<uint64_t> colw(traceSlots(BP.maxcols)*4); std::vector<uint16_t> colsc(traceSlots(BP.maxcols));
 		std::vector<TCol> cps(traceCheckpoints(BP.maxcols)); std::vector<uint64_t> segs(4*T2S);
 		TraceStoreMem st; st.cp = cps.data(); st.seg = segs.data();
-		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag;
+		TB.maxcols = BP.maxcols; TB.trace_bytes = trace_bytes; TB.errflag = &errflag; TB.work = 0; TB.slab = 0;
 		if ( P.tspace <= 128 && BP.maxcols <= 928 ) for ( uint64_t t = 0; t < BP.nblocks; ++t ) traceBlock(TB,t,st);   // as the library chooses (capi.hip: tr_words)
 		else
 		{
