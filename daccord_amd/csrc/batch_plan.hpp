@@ -64,6 +64,7 @@ struct BatchPlan
 	FastCaps ftierL;          // tier 5: windows with a string of 65..128 bases (second stream, before the generic engine)
 	uint64_t ndeepwin;        // windows with more strings / k-mer instances than the first tier of shallow batches holds
 	bool deep;                // most windows are deep: the first tier is FastTier<4> (many strings, small graph) instead of FastTier<1>
+	bool wide;                // window size 64 ... 127: the LDS tiers of the batch are FastTier<8> (second slot) and FastTier<9> (third slot) in front of the generic engine (round 6)
 
 	// Per pile results of the parallel pass of plan(): everything that does not depend on the piles in front of it
 	struct PileTmp
@@ -231,7 +232,7 @@ struct BatchPlan
 		uint32_t const tab_nrows = 0, uint32_t const tab_nsup = 0)
 	{
 		piles.clear(); ovl.clear(); ovl_pile.clear(); fragbase.clear(); pile_status.assign(np,DACC_OK); pile_errors.clear();
-		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0; maxspan = 0; ndeepwin = 0; deep = false;
+		nwindows = nblocks = nwt = npos = nfragslots = algo_bytes = 0; maxdepth = 0; maxcols = 0; maxspan = 0; ndeepwin = 0; deep = false; wide = false;
 		if ( trace_bytes != 1 && trace_bytes != 2 ) { err = "trace values are 1 byte (tspace <= 125) or 2 bytes"; return DACC_EINVAL; }
 		if ( par.tspace <= 0 || par.tspace > 512 ) { err = "tspace must be in [1,512] (column vectors of the trace kernels: 2, 4 or 8 64-bit words)"; return DACC_ENOTSUP; }
 		std::vector<PileTmp> PT(np);
@@ -320,11 +321,13 @@ struct BatchPlan
 		// A batch whose windows are mostly too deep for tier 1 (coverage of 40x and more) starts in the deep tier instead
 		deep = 2*ndeepwin > nwindows;
 		ftier[0] = deep ? fastCapsOf< FastTier<4> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<1> >(tab_nrows,tab_nsup);
-		ftier[1] = deep ? fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<6> >(tab_nrows,tab_nsup);
+		// (round 6) wide windows: tier 8 (second slot, no hand-over list in front of it = all windows), tier 9, then the generic engine
+		wide = par.w > 63 && par.w <= 127;
+		ftier[1] = wide ? fastCapsOf< FastTier<8> >(tab_nrows,tab_nsup) : (deep ? fastCapsOf< FastTier<2> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<6> >(tab_nrows,tab_nsup));
 		ftier0 = fastCapsOf< FastTier<0> >(tab_nrows,tab_nsup);
 		ftier7 = fastCapsOf< FastTier<7> >(tab_nrows,tab_nsup);
 		ftierL = fastCapsOf< FastTier<5> >(tab_nrows,tab_nsup);
-		ftier[2] = fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
+		ftier[2] = wide ? fastCapsOf< FastTier<9> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;
 	}
 };

@@ -99,7 +99,7 @@ static inline uint32_t boundByArena(uint64_t grid, uint64_t const bytes, uint64_
 // the list the second slot reads, next to the first slot's hand-overs; rounds 3-5 ran all of them in tier 5 on the second stream, the LDS of a
 // whole CU per wavefront: at -w 56 / 60 / 63 that is 21 / 65 / 88 % of the windows of PacBio-like reads, profiles/r06l.)
 __global__ void __launch_bounds__(256) k_prescan(DevOvl const * ovl, uint64_t novl, uint32_t const * ovl_pile, DevPile const * piles, uint32_t const * wt_b, uint32_t const * wt_e,
-	uint32_t * pregen, uint32_t * pregen2)
+	uint32_t * pregen, uint32_t * pregen2, uint32_t const thr1)
 {
 	// one wavefront per overlap, lanes over its rows: coalesced reads of the two tables
 	uint64_t const o = static_cast<uint64_t>(blockIdx.x)*4 + (threadIdx.x>>6);
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_prescan(DevOvl const * ovl, uint64_t no
 	for ( uint32_t r = threadIdx.x & 63; r < ov.ny; r += 64 )
 	{
 		uint32_t const len = wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r];
-		if ( len > 64u )
+		if ( len > thr1 )      // 64; a wide batch (tier 8: strings of up to 128 bases): 128
 		{
 			uint64_t const w = winbase + ov.y0 + r;
 			uint32_t const bit = 1u << (w&31);
@@ -381,7 +381,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; int env_trdyn; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; int env_trdyn; int env_widetier; bool widetier; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
@@ -451,6 +451,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 		char const * sc = getenv("DACC_SCHED"); c->env_sched = sc ? atoi(sc) : 1;      // bit 0: LDS tiers pull work from a counter, bit 1: generic engine too
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 31;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes), bit 4 tier 7 (the middle class; needs tier 0)
 		char const * l8 = getenv("DACC_LONG128"); c->env_long128 = !(l8 && l8[0] == '0');      // 0: windows with a string of 65 ... 128 bases run in tier 5 on the second stream (rounds 3-5)
+		{ char const * wt = getenv("DACC_WIDE_TIER"); c->env_widetier = !(wt && wt[0] == '0'); c->widetier = false; }
 		{ char const * td = getenv("DACC_TRACE_DYN"); c->env_trdyn = !(td && td[0] == '0'); }      // 0: k_trace walks its blocks with a fixed stride (rounds 1-5)
 		char const * ta = getenv("DACC_T7_ADAPT"); c->env_t7adapt = !(ta && ta[0] == '0');      // 0: tier 7 stays on whatever it hands on
 		char const * t7 = getenv("DACC_T7INST"); c->env_t7inst = t7 ? static_cast<uint32_t>(atoi(t7)) : static_cast<uint32_t>(T7INST_DEFAULT);      // size-class threshold of tier 7
@@ -609,7 +610,7 @@ static int runDevice(dacc_ctx * c)
 			for ( int i = 0; i < 3; ++i ) HIPCHK(hipMemsetAsync(c->d_retry[i].p,0,sizeof(uint32_t),s));
 			if ( BP.ovl.size() )
 			{
-				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregen2.p);
+				hipLaunchKernelGGL(k_prescan,dim3((BP.ovl.size()+3)/4),dim3(256),0,s,c->d_ovl.p,static_cast<uint64_t>(BP.ovl.size()),c->d_ovl_pile.p,c->d_piles.p,c->d_wt_b.p,c->d_wt_e.p,c->d_pregen.p,c->d_pregen2.p,c->widetier ? 128u : 64u);
 				// windows with a string of 65 ... 128 bases join the first slot's hand-overs when the second slot's tier holds such strings (tiers 6 / 3;
 				// a deep batch's tier 2 does not: it hands them on to tier 3 at its length check) and the first slot runs at all
 				bool const slot1 = c->tier_ok[0] && (c->tier_ok[1] || c->tier_ok[2]) && c->env_long128;
@@ -664,6 +665,7 @@ static int runDevice(dacc_ctx * c)
 					// the first slot's tiers skip every window with a string of more than 64 bases; the later ones only those the second stream has
 					// (without the 128-base route: all of them, as in rounds 3-5)
 					if ( t > 0 && c->tier_ok[0] && c->env_long128 ) FB.W.pregen = c->d_pregen2.p;
+					if ( c->widetier ) { FB.W.pregen = c->d_pregen2.p; FB.hand = 0; }      // (its hand-overs go to the generic engine, which sorts for itself)
 					FB.gslab = c->d_gslab.p; FB.gstride = c->gstride[t]; FB.tab32 = c->d_tab32.p;
 					FB.hand = c->handcap ? c->d_hand.p : static_cast<uint64_t *>(0); FB.handctr = c->d_handctr.p; FB.handcap = c->handcap; FB.handwords = c->handwords;
 #if defined(DACC_LEDGER)
@@ -701,8 +703,10 @@ static int runDevice(dacc_ctx * c)
 						hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,static_cast<uint32_t const *>(c->d_big.p),work);
 					}
 					else if ( t == 0 ) hipLaunchKernelGGL(k_window_fast<1>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( t == 1 && c->widetier ) hipLaunchKernelGGL(k_window_fast<8>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 && BP.deep ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<6>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( c->widetier ) hipLaunchKernelGGL(k_window_fast<9>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					list = c->d_retry[t].p;
 					if ( !early )
@@ -948,7 +952,10 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 		c->usefast = !c->env_nofast;
 		c->sched = c->env_sched;
 		for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) c->usefast = 0; // table must fit 32 bits
-		if ( c->H.nrows > 64 || c->H.nsup > FSUPCAP || c->par.w > 63 ) c->usefast = 0;     // (w = 64 and the wide windows, 65..128: generic engine)
+		// (round 6) wide windows, w = 64 ... 127 (model table of up to 128 rows): tier 8 in the second slot and tier 9 in the third in front of the generic engine
+		// (DACC_WIDE_TIER=0: the generic engine only, as in rounds 4-5; w = 128 always)
+		c->widetier = BP.wide && c->env_widetier && c->H.nrows <= 128 && c->H.nsup <= FSUPCAPW;
+		if ( !c->widetier && (c->H.nrows > 64 || c->H.nsup > FSUPCAP || c->par.w > 63) ) c->usefast = 0;
 	}
 	if ( c->usefast )
 	{
@@ -959,6 +966,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			FastCaps const & F = BP.ftier[t];
 			c->tier_ok[t] = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= F.tabcap) && F.ldsbytes <= 160*1024;
 			if ( !((c->env_tiers>>t)&1) ) c->tier_ok[t] = 0;
+			if ( c->widetier && t == 0 ) c->tier_ok[t] = 0;
 			uint64_t percu = (160*1024) / (F.ldsbytes ? F.ldsbytes : 1);
 			if ( percu > 8 ) percu = 8;
 			if ( percu < 1 ) percu = 1;
@@ -1010,6 +1018,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			if ( he && he[0] == '0' ) cap = 0;
 			if ( c->par.klow != c->par.khigh ) cap = 0;
 			if ( c->nohand ) cap = 0;      // a retry after an allocation failure: no optional buffer (dacc_drop_hand)
+			if ( c->widetier ) cap = 0;    // a wide batch has one LDS tier: nothing to hand the sorted instances to
 			c->handwant = cap;
 			HIPCHK(c->d_handctr.ensure(4));
 			if ( c->d_hand.cap < static_cast<size_t>(cap)*c->handwords ) c->handcap = static_cast<uint32_t>(c->d_hand.cap / c->handwords);     // what an earlier batch left
@@ -1018,8 +1027,8 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 		if ( BP.ftier[0].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<4>) : reinterpret_cast<const void *>(k_window_fast<1>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[0].ldsbytes));
 		c->tierL_ok = (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierL.tabcap) && BP.ftierL.ldsbytes <= 160*1024 && ((c->env_tiers>>2)&1);
 		if ( c->tierL_ok && BP.ftierL.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_long),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftierL.ldsbytes));
-		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<2>) : reinterpret_cast<const void *>(k_window_fast<6>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
-		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
+		if ( BP.ftier[1].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(c->widetier ? reinterpret_cast<const void *>(k_window_fast<8>) : (BP.deep ? reinterpret_cast<const void *>(k_window_fast<2>) : reinterpret_cast<const void *>(k_window_fast<6>)),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[1].ldsbytes));
+		if ( BP.ftier[2].ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(c->widetier ? reinterpret_cast<const void *>(k_window_fast<9>) : reinterpret_cast<const void *>(k_window_fast<3>),hipFuncAttributeMaxDynamicSharedMemorySize,BP.ftier[2].ldsbytes));
 		c->retry_grid = boundByArena(wg < 512 ? wg : 512,BP.caps.bytes,8);
 		c->win_grid = c->retry_grid;
 		// generic engine on the second stream (windows with a string of more than 64 bases): a wavefront per window as far

@@ -50,7 +50,7 @@ namespace dacc {
 
 enum { WS_RETRY = 4 };
 enum { FNOPAR = 0xFF };
-enum { FSUPCAP = 128 };
+enum { FSUPCAP = 128, FSUPCAPW = 192 };      // (W: the wide tier -- the table of w = 127 covers 165 read offsets)
 enum { FSEQCAP = 48 };      // max stretches of one candidate path     // max width (read offsets) of the model table copy in LDS
 
 // run time description of a capacity tier (host planning, launch parameters)
@@ -79,14 +79,14 @@ template<int TIER> struct FastTier;
 #if !defined(DACC_RCH01)
 #define DACC_RCH01 2
 #endif
-template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 776, scap = 112, lcap = 960, wcap = 1024, rccap = 144, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+template<> struct FastTier<1> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 1024, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 32, precap = 1024, ncap = 776, scap = 112, lcap = 960, wcap = 1024, rccap = 144, fcap = 192, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048, wide = 0 }; };
 // tier 0 (size classes): the windows a pre-pass (classifyWindow, k_classify) finds small -- few strings, at most T0INST k-mer
 // instances -- in 20 KB = 8 wavefronts per CU (two on every SIMD).  What overflows it joins the other windows in tier 1.
-template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+template<> struct FastTier<0> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 768, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 576, ncap = 524, scap = 88, lcap = 640, wcap = 768, rccap = 96, fcap = 128, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048, wide = 0 }; };
 // tier 7 (round 6, the MIDDLE size class of shallow batches): 22.9 KB = 7 wavefronts per CU.  Four fifths of the windows tier 1 (6 per CU)
 // used to run have at most 28 strings, 704 k-mer instances, 640 nodes and 800 links (emulation, 16 piles of config 2: 4244 of 5295); the
 // pre-pass sends them here, what overflows joins tier 1's list like tier 0's hand-overs join this one.
-template<> struct FastTier<7> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 896, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 704, ncap = 640, scap = 104, lcap = 800, wcap = 896, rccap = 112, fcap = 148, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048 }; };
+template<> struct FastTier<7> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 896, rch = DACC_RCH01, fch = 4, fnw = 2, fnc = 32, idmax = 250, rpstcap = 256, lstr = 64, maxs = 28, precap = 704, ncap = 640, scap = 104, lcap = 800, wcap = 896, rccap = 112, fcap = 148, siqcap = 56, blcap = 96, seqcap = 32, psiq = 8, consrow = 64, lscrids = 2048, wide = 0 }; };
 enum : uint32_t { T0INST_DEFAULT = 576, T7INST_DEFAULT = 704 };      // a window with more k-mer instances (upper bound of the pre-pass) starts in tier 1; run-time
                                                // argument of the pre-pass (DACC_T0INST overrides it for sweeps)
 // tier 2: gw layout as well since round 3 (43 KB: 3 wavefronts per CU; the legacy layout was 80.5 KB: 2 per CU)
@@ -102,7 +102,7 @@ enum : uint32_t { T0INST_DEFAULT = 576, T7INST_DEFAULT = 704 };      // a window
 #if !defined(DACC_T2_LCAP)
 #define DACC_T2_LCAP 2032
 #endif
-template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = DACC_T2_NCAP, scap = 232, lcap = DACC_T2_LCAP, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 3072, rch = 4, fch = 4, fnw = 4, fnc = 64, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = DACC_T2_NCAP, scap = 232, lcap = DACC_T2_LCAP, wcap = 3072, rccap = 256, fcap = 192, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
 // tier 6 (second slot of SHALLOW batches since round 3, gw layout, 36 KB = 4 wavefronts per CU): what tier 1 hands on at 20x
 // are windows with more than its 608 nodes (82 % of the hand-overs) or fuller pools, not more strings or instances, so this
 // tier keeps tier 1's string / instance capacities and spends its LDS on nodes, stretches and pools.  Deep batches keep
@@ -110,24 +110,36 @@ template<> struct FastTier<2> { typedef uint8_t id_t; typedef uint8_t sid_t; enu
 // (round 6: the tier sat at 34 720 B, 6 KB below what four wavefronts per CU allow (40 960 B): the bytes went to what sends its windows on to
 // tier 3 -- ONE wavefront per CU -- on the ONT mix at small k (emulation, 6 piles of config 5 at k = 10 / 12: reverse pool 73 / 130, weights 53 / 1,
 // forward pool 45 / 7 of about 200 hand-overs): reverse pool 192 -> 256 paths in chunks of two, 248 stretches, 2048 weight records)
-template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 2048, rch = 2, fch = 8, fnw = 3, fnc = 40, idmax = 250, rpstcap = 256, lstr = 128, maxs = 40, precap = 1024, ncap = 1024, scap = 248, lcap = 1280, wcap = 2048, rccap = 256, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<6> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 2048, rch = 2, fch = 8, fnw = 3, fnc = 40, idmax = 250, rpstcap = 256, lstr = 128, maxs = 40, precap = 1024, ncap = 1024, scap = 248, lcap = 1280, wcap = 2048, rccap = 256, fcap = 256, siqcap = 96, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
 
 // tier 3 (one wavefront per CU): 16 bit path ids, so that an enumeration may hold more than 250 paths; sized for deep piles
 // too (BASELINE config 4, 54x: up to 96 strings with 4096 k-mer instances, 72 first / last k-mer candidates)
 // gw layout and 16 bit STRETCH ids since round 3: what the legacy tier 3 handed to the generic engine at 54x were windows with
 // more than 250 stretches (13 of 19 per 60 000 windows) or more than 2112 feasible weights (5 of 19), and each of them cost the
 // generic engine seconds (685 such windows were 92 % of a 2000-pile 54x batch, profiles/r03c_bench_54x_2000piles.log)
-template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<3> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 1000, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 96, precap = 4096, ncap = 2048, scap = 1024, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
 
 // tier 4 (three wavefronts per CU, takes the place of tier 1 in batches of deep piles): many strings and k-mer instances,
 // small graph.  At 54x (BASELINE config 4) 96 % of the windows find their consensus at filter frequency 2, where the graph
 // has about a hundred nodes, while the 55 strings of a window carry 1500 k-mer instances.
-template<> struct FastTier<4> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 608, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<4> { typedef uint8_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 608, rch = 4, fch = 4, fnw = 2, fnc = 40, idmax = 250, rpstcap = 256, lstr = 64, maxs = 96, precap = 2048, ncap = 256, scap = 48, lcap = 256, wcap = 608, rccap = 128, fcap = 96, siqcap = 56, blcap = 96, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
 
 // tier 5 (one wavefront per CU, only for the windows the pre-scan found): B strings of up to 128 bases (string stride 128,
 // two words per pattern mask); everything else as tier 3 with 64 strings.  Window strings of more than 64 bases are rare
 // at the default window (a few per ten million windows of config 2) but each of them costs the generic engine seconds.
-template<> struct FastTier<5> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560 }; };
+template<> struct FastTier<5> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 0, wcapg = 0, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 1792, scap = 250, lcap = 2048, wcap = 2040, rccap = 512, fcap = 512, siqcap = 256, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
+
+// tier 8 (round 6, two wavefronts per CU): WIDE windows, -w 64 ... 127 (the reference takes any -w, daccord.cpp:1282-1305; rounds 4-5 ran them in the generic
+// engine, two orders of magnitude slower per window).  What a wide window needs beyond tier 6's two-word pattern masks: feasible start positions
+// of a stretch up to nrows = w+1 <= 128 (two words per position mask: maskF / maskFh), candidates and a consensus of up to 128 symbols, the
+// two-word consensus -> A alignment and the wide window record (dev_types.hpp: WRECW).  A batch with w > 63 runs this tier alone in front of the
+// generic engine (BatchPlan::wide); sized for 20x piles at w = 64 ... 96 (20 strings of 83 k-mers at w = 96, k = 14).
+template<> struct FastTier<8> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 6144, rch = 4, fch = 8, fnw = 4, fnc = 64, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 40, precap = 3072, ncap = 2304, scap = 248, lcap = 3072, wcap = 6144, rccap = 512, fcap = 512, siqcap = 96, blcap = 128, seqcap = 96, psiq = 10, consrow = 128, lscrids = 2560, wide = 1 }; };
+
+// tier 9 (round 6, one wavefront per CU): what overflows tier 8 -- its reverse pool (512 paths), forward pool, score intervals -- before the generic
+// engine, which recomputes both enumerations for every (first, last) k-mer pair and takes seconds for such a window (30 of 37 000 windows at
+// w = 64 were 6.2 of a step's 6.7 s, profiles/r06v).  Tier 3's pools with the wide tier's masks, alignment and record.
+template<> struct FastTier<9> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 3072, scap = 248, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 1024, siqcap = 256, blcap = 128, seqcap = 96, psiq = 10, consrow = 128, lscrids = 2560, wide = 1 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -226,6 +238,8 @@ struct FastLds<CT,false>
 	FLD(posL,uint8_t,CT::fnc,e_parL)
 	FLD(pieF,uint8_t,CT::fnc,e_posL)      // first piece id of candidate i (second = +1), FNOPAR if none
 	FLD(pieL,uint8_t,CT::fnc,e_pieF)
+	static constexpr uint32_t consmax = MAXCONS;
+	static_assert(CT::wide == 0,"the wide tier needs the gw layout");
 	FLD(bestL,uint8_t,MAXCONS,e_pieL)      // best consensus so far (survives the tries)
 	FLD(cdh,FCC,16,e_bestL)
 	static_assert(uA <= o_cdh,"the model table copy (from o_cdh on) is loaded for gap filling while the instance array is live");
@@ -359,8 +373,9 @@ struct FastLds<CT,true>
 	typedef typename CT::sid_t sid_t;      // stretch ids: 8 bits (at most 250 stretches) or 16 bits
 	// ---- P ----
 	FLD(slen,uint8_t,CT::maxs,0)
-	FLD(suplo8,uint8_t,FSUPCAP,e_slen)
-	FLD(suphi8,uint8_t,FSUPCAP,e_suplo8)
+	static constexpr uint32_t supcap = CT::wide ? static_cast<uint32_t>(FSUPCAPW) : static_cast<uint32_t>(FSUPCAP);
+	FLD(suplo8,uint8_t,supcap,e_slen)
+	FLD(suphi8,uint8_t,supcap,e_suplo8)
 	FLD(vrem,uint8_t,8,e_suphi8)
 	FLD(vadd,uint8_t,8,e_vrem)
 	FLD(vapos,uint8_t,8,e_vadd)
@@ -373,7 +388,10 @@ struct FastLds<CT,true>
 	FLD(midB,uint8_t,8,e_midA)
 	FLD(nv,uint32_t,CT::ncap,e_midB)
 	FLD(npred,sid_t,CT::ncap,e_nv)
-	FLD(bestL,uint8_t,MAXCONS,e_npred)
+	// longest consensus / candidate of this tier: MAXCONS, 128 in the wide tier (consensus of a window of up to 127 bases)
+	static constexpr uint32_t consmax = CT::wide ? 128u : static_cast<uint32_t>(MAXCONS);
+	static constexpr uint32_t alw = CT::wide ? 2u : 1u;      // 64 bit words per column of the consensus -> A alignment
+	FLD(bestL,uint8_t,consmax,e_npred)
 	static constexpr uint32_t sbase = (e_bestL + 15u) & ~15u;
 	// ---- S (spilled while the pools are live) ----
 	// (round 5: no string array -- the pattern masks ARE the strings: symbol c at position p of string j <=> bit p of peq[4*j+c]; they are
@@ -443,7 +461,9 @@ struct FastLds<CT,true>
 	FLD(slink,uint16_t,CT::scap,e_sslen)
 	FLD(maskF,uint64_t,CT::scap,e_slink)
 	FLD(maskR,uint64_t,CT::scap,e_maskF)
-	FLD(woffF,uint16_t,CT::scap,e_maskR)
+	FLD(maskFh,uint64_t,(CT::wide ? CT::scap : 0u),e_maskR)      // wide tier: start positions 64 ... 127
+	FLD(maskRh,uint64_t,(CT::wide ? CT::scap : 0u),e_maskFh)
+	FLD(woffF,uint16_t,CT::scap,e_maskRh)
 	FLD(woffR,uint16_t,CT::scap,e_woffF)
 	FLD(links,uint16_t,CT::lcap,e_woffR)
 	FLD(lhead,sid_t,CT::ncap,e_links)
@@ -472,7 +492,8 @@ struct FastLds<CT,true>
 	FLD(siq,FSI,CT::siqcap,e_cseq)
 	static_assert(sizeof(FSI)*CT::siqcap <= lscrbytes,"the serial score interval heap shares the lane scratch");
 	// (the scratch tables of the stretch construction need 3 bytes per node: the region is at least that long)
-	static constexpr uint32_t uB = fcmax(fcmax(fcmax(e_consL,e_lscr),xbase + 3u*CT::ncap + 16u),xbase + (2u*CT::scap+2u)*2u + 8u + 8u*CT::scap + 16u);
+	static constexpr uint32_t alnbytes = 2u*8u*alw*(consmax+1u) + 2u*(consmax+1u) + 8u + (2u*consmax + 2u*64u + 8u) + 16u;      // alpv, almv, albot, alops
+	static constexpr uint32_t uB = fcmax(fcmax(fcmax(fcmax(e_consL,e_lscr),xbase + 3u*CT::ncap + 16u),xbase + (2u*CT::scap+2u)*2u + 8u + 8u*CT::scap + 16u),CT::wide ? xbase + alnbytes : 0u);
 	static constexpr uint32_t xbytes = uB - xbase;
 	// raw stretches: over the pattern masks and weight offsets, which the feasibility writes later
 	FLD(tfirst,uint16_t,CT::scap,o_maskF)
@@ -482,10 +503,10 @@ struct FastLds<CT,true>
 	FLD(skey,uint64_t,fcpow2(CT::scap),e_tlink)
 	static_assert(e_skey <= o_links,"raw stretches must fit the mask / offset arrays they borrow");
 	// scratch over [xbase,uB): candidate heap, sequences and lane scratch are written by the enumerations only
-	FLD(alpv,uint64_t,MAXCONS+1,xbase)
-	FLD(almv,uint64_t,MAXCONS+1,e_alpv)
-	FLD(albot,uint16_t,MAXCONS+1,e_almv)
-	FLD(alops,uint8_t,2*MAXCONS+2*64+8,e_albot)
+	FLD(alpv,uint64_t,alw*(consmax+1),xbase)
+	FLD(almv,uint64_t,alw*(consmax+1),e_alpv)
+	FLD(albot,uint16_t,consmax+1,e_almv)
+	FLD(alops,uint8_t,2*consmax+2*64+8,e_albot)
 	static_assert(e_alops <= uB,"final alignment scratch");
 	FLD(toff,uint16_t,2*CT::scap+2,xbase)
 	FLD(urec,uint32_t,2*CT::scap,e_toff)      // unit at position q of the processing order: lo | unit << 7
@@ -1498,6 +1519,7 @@ struct FastEngine
 				w = static_cast<uint32_t>(hi-lo); lo_ = static_cast<uint32_t>(lo);
 				cls = len >= 49 ? 0u : len >= 33 ? 1u : len >= 25 ? 2u : len >= 17 ? 3u : len >= 13 ? 4u : len >= 9 ? 5u : len >= 7 ? 6u : len >= 5 ? 7u : len == 4 ? 8u : len == 3 ? 9u : len == 2 ? 10u : 11u;
 				if ( rev ) { L.maskR()[s] = 0; L.woffR()[s] = 0; } else { L.maskF()[s] = 0; L.woffF()[s] = 0; }
+				if constexpr ( CT::wide != 0 ) { if ( rev ) L.maskRh()[s] = 0; else L.maskFh()[s] = 0; }
 			}
 			ulo_r[cc] = lo_; uw_r[cc] = w; ucls_r[cc] = cls; upos_r[cc] = 0;
 		}
@@ -1615,8 +1637,18 @@ struct FastEngine
 					uint32_t const tend = L.toff()[u+1];
 					uint32_t const lastlane = (tend-c < WSZ) ? (tend-c) : static_cast<uint32_t>(WSZ);     // exclusive
 					uint64_t const span = (lastlane-firstlane >= 64) ? ~0ull : ((1ull << (lastlane-firstlane))-1ull);
+					if constexpr ( CT::wide != 0 )
+					{
+						// start positions up to 127: the round's bits (at most 64, from position P on) may straddle the two words
+						uint64_t const seg = (okb >> firstlane) & span;
+						uint64_t const blo = P < 64u ? (seg << P) : 0ull, bhi = P < 64u ? (P ? (seg >> (64u-P)) : 0ull) : (seg << (P-64u));
+						if ( rev ) { L.maskR()[s] |= blo; L.maskRh()[s] |= bhi; } else { L.maskF()[s] |= blo; L.maskFh()[s] |= bhi; }
+					}
+					else
+					{
 					uint64_t const bits = ((okb >> firstlane) & span) << P;
 					if ( rev ) L.maskR()[s] |= bits; else L.maskF()[s] |= bits;
+					}
 					if ( t == t0 ) { uint32_t const wo = base + dacc_popc64(okb & mydir & ltmask); if ( rev ) L.woffR()[s] = wo; else L.woffF()[s] = wo; }
 				}
 			}
@@ -1705,8 +1737,21 @@ struct FastEngine
 		for ( uint32_t q = 0; q < f; ++q ) u += tabR(static_cast<uint32_t>(IP[i0+q])*(nrows+1) + p);
 		return u;
 	}
+	// (wide tier) is position p set in the two-word mask (m0: positions 0-63, m1: 64-127), and how many positions below it are
+	DEV static bool mask2Test(uint64_t const m0, uint64_t const m1, uint32_t const p) { return p < 64u ? ((m0 >> p) & 1ull) != 0 : ((m1 >> (p-64u)) & 1ull) != 0; }
+	DEV static uint32_t mask2Rank(uint64_t const m0, uint64_t const m1, uint32_t const p)
+	{
+		return p < 64u ? dacc_popc64(m0 & ((1ull<<p)-1ull)) : dacc_popc64(m0) + dacc_popc64(m1 & ((1ull<<(p-64u))-1ull));
+	}
 	DEV int32_t sfFind(uint32_t const s, uint32_t const p) const
 	{
+		if constexpr ( CT::wide != 0 )
+		{
+			if ( p >= 128 ) return -1;
+			uint64_t const m0 = L.maskF()[s], m1 = L.maskFh()[s];
+			if ( !mask2Test(m0,m1,p) ) return -1;
+			return L.woffF()[s] + mask2Rank(m0,m1,p);
+		}
 		if ( p >= 64 ) return -1;
 		uint64_t const m = L.maskF()[s];
 		if ( !((m>>p)&1) ) return -1;
@@ -1714,6 +1759,13 @@ struct FastEngine
 	}
 	DEV int32_t csfFind(uint32_t const s, uint32_t const p) const
 	{
+		if constexpr ( CT::wide != 0 )
+		{
+			if ( p >= 128 ) return -1;
+			uint64_t const m0 = L.maskR()[s], m1 = L.maskRh()[s];
+			if ( !mask2Test(m0,m1,p) ) return -1;
+			return L.woffR()[s] + mask2Rank(m0,m1,p);
+		}
 		if ( p >= 64 ) return -1;
 		uint64_t const m = L.maskR()[s];
 		if ( !((m>>p)&1) ) return -1;
@@ -1723,6 +1775,28 @@ struct FastEngine
 	DEV bool linkOk(uint32_t const i, uint32_t const b) const
 	{
 		uint32_t const shift = L.sslen()[b]-1;
+		if constexpr ( CT::wide != 0 )
+		{
+			if ( shift >= 128 ) return false;
+			uint64_t const a0 = L.maskR()[i], a1 = L.maskRh()[i], b0 = L.maskR()[b], b1 = L.maskRh()[b];
+			// (b0,b1) << shift over 128 bits
+			uint64_t const s0 = shift < 64u ? (b0 << shift) : 0ull;
+			uint64_t const s1 = shift < 64u ? ((b1 << shift) | (shift ? (b0 >> (64u-shift)) : 0ull)) : (b0 << (shift-64u));
+			uint64_t c0 = a0 & s0, c1 = a1 & s1;
+			uint64_t weight = 0;
+			while ( c0 | c1 )
+			{
+				uint32_t pa;
+				if ( c0 ) { pa = __builtin_ctzll(c0); c0 &= c0-1; } else { pa = 64u + static_cast<uint32_t>(__builtin_ctzll(c1)); c1 &= c1-1; }
+				uint32_t const ia = L.woffR()[i] + mask2Rank(a0,a1,pa);
+				uint32_t const pb = pa-shift;
+				uint32_t const ib = L.woffR()[b] + mask2Rank(b0,b1,pb);
+				WR const ra = recR(ia);
+				uint64_t const lweight = wuR(ib) + (ra.w - ra.w1);
+				weight = lweight > weight ? lweight : weight;
+			}
+			return weight >= FW_THRES_01;
+		}
 		if ( shift >= 64 ) return false;
 		uint64_t const mA = L.maskR()[i], mB = L.maskR()[b];
 		uint64_t common = mA & (mB<<shift);
@@ -2391,7 +2465,7 @@ struct FastEngine
 	// ================= combining a forward tree with a reverse block (score intervals) =================
 	// capacities of this tier that rounds 1-4 had as globals (tier 0 trades them for nodes, round 5): stretches of a candidate, bytes of a decoded candidate's row
 	enum : uint32_t { FSEQCAP = CT::seqcap, CONSROW = CT::consrow };
-	static_assert(CONSROW <= MAXCONS && (CONSROW & 7u) == 0,"rows of the decoded candidates: read as 64 bit words");
+	static_assert(CONSROW <= FastLds<CT>::consmax && (CONSROW & 7u) == 0,"rows of the decoded candidates: read as 64 bit words");
 	uint32_t cfree;   // free candidate sequence slots
 	// A candidate is kept as its sequence of view stretches (forward chain, then reverse chain).  Within one view two
 	// candidates spell the same string iff their sequences are equal (nodes are distinct k-mers and every edge lies on
@@ -3646,8 +3720,75 @@ struct FastEngine
 	// cons is 8 byte aligned and readable up to the next multiple of 8 behind n (bestL).  The pattern masks of the A window
 	// and the consensus (2 bits per symbol) stay in registers: the forward pass only stores its columns, the traceback
 	// loads a column when it moves to it (A[i-1] == cons[j-1] <=> bit i-1 of the pattern mask of cons[j-1]).
+	// the same for a wide window (w in 65 ... 127, wide tier): two words per column (rows 0-63 / 64-m-1; column c at alpv[2c], alpv[2c+1]),
+	// the horizontal delta leaving word 0 enters word 1 (as in the two-word distance kernel); same traceback priority
+	// (diagonal > DEL > INS), same steps as the generic engine's alignAndEmitWide (dbg_window.hpp)
+	DEV uint32_t alignAndEmitWide(LDSQ uint8_t const * cons, uint32_t const n)
+	{
+		if constexpr ( CT::wide != 0 )
+		{
+		uint32_t const m = P.w;
+		enum { PW = FastLds<CT>::pw };
+		static_assert(PW == 2,"the A window of a wide tier has two words per pattern mask");
+		LDSQ uint64_t const * PEQ = L.peq();      // string 0 = the A window: word q of symbol c at PW*c + q
+		uint64_t const mask1 = (m == 128) ? ~0ull : ((1ull<<(m-64))-1);
+		uint64_t Pv0 = ~0ull, Mv0 = 0, Pv1 = mask1, Mv1 = 0; uint32_t score = m;
+		L.alpv()[0] = Pv0; L.alpv()[1] = Pv1; L.almv()[0] = Mv0; L.almv()[1] = Mv1; L.albot()[0] = m;
+		uint64_t const top = 1ull<<(m-65);
+		for ( uint32_t c = 0; c < n; ++c )
+		{
+			uint32_t const ch = cons[c] & 3u;
+			uint64_t const Eq0 = PEQ[PW*ch], Eq1 = PEQ[PW*ch+1];
+			uint64_t const Xv0 = Eq0 | Mv0;
+			uint64_t const Xh0 = (((Eq0 & Pv0) + Pv0) ^ Pv0) | Eq0;
+			uint64_t Ph0 = Mv0 | ~(Xh0 | Pv0);
+			uint64_t Mh0 = Pv0 & Xh0;
+			uint64_t const phc = Ph0>>63, mhc = Mh0>>63;
+			Ph0 = (Ph0<<1) | 1ull; Mh0 <<= 1;
+			Pv0 = Mh0 | ~(Xv0 | Ph0);
+			Mv0 = Ph0 & Xv0;
+			uint64_t const Eq1c = Eq1 | mhc;
+			uint64_t const Xv1 = Eq1 | Mv1;
+			uint64_t const Xh1 = (((Eq1c & Pv1) + Pv1) ^ Pv1) | Eq1c;
+			uint64_t Ph1 = Mv1 | ~(Xh1 | Pv1);
+			uint64_t Mh1 = Pv1 & Xh1;
+			if ( Ph1 & top ) ++score; else if ( Mh1 & top ) --score;
+			Ph1 = (Ph1<<1) | phc; Mh1 = (Mh1<<1) | mhc;
+			Pv1 = (Mh1 | ~(Xv1 | Ph1)) & mask1;
+			Mv1 = (Ph1 & Xv1) & mask1;
+			L.alpv()[2*c+2] = Pv0; L.alpv()[2*c+3] = Pv1; L.almv()[2*c+2] = Mv0; L.almv()[2*c+3] = Mv1; L.albot()[c+1] = score;
+		}
+		uint32_t i = m, j = n; uint32_t d = score; uint32_t nops = 0;
+		while ( i || j )
+		{
+			uint32_t op = 2; bool done = false;
+			if ( i && j )
+			{
+				uint32_t const sh = i-1;
+				uint64_t const p0 = L.alpv()[2*(j-1)], p1 = L.alpv()[2*(j-1)+1], q0 = L.almv()[2*(j-1)], q1 = L.almv()[2*(j-1)+1];
+				uint32_t const np_ = sh < 64 ? (dacc_popc64(p0>>sh) + dacc_popc64(p1)) : dacc_popc64(p1>>(sh-64));
+				uint32_t const nm_ = sh < 64 ? (dacc_popc64(q0>>sh) + dacc_popc64(q1)) : dacc_popc64(q1>>(sh-64));
+				uint32_t const dd = L.albot()[j-1] - np_ + nm_;
+				uint32_t const cj = cons[j-1] & 3u;
+				uint32_t const neq = ((PEQ[PW*cj + (sh>>6)] >> (sh&63u)) & 1ull) ? 0u : 1u;      // A[i-1] != cons[j-1]
+				if ( dd + neq == d ) { op = neq ? 1 : 0; --i; --j; d = dd; done = true; }
+			}
+			if ( !done && i )
+			{
+				uint32_t const r = i-1;
+				uint64_t const pv = L.alpv()[2*j+(r>>6)];
+				if ( (pv >> (r&63u)) & 1ull ) { op = 3; --i; d = d-1; done = true; }
+			}
+			if ( !done ) { op = 2; --j; d = d-1; }
+			L.alops()[nops++] = op;
+		}
+		return nops;
+		}
+		else return 0;
+	}
 	DEV uint32_t alignAndEmit(LDSQ uint8_t const * cons, uint32_t const n)
 	{
+		if constexpr ( CT::wide != 0 ) { if ( DACC_WIDE_W(P.w) ) return alignAndEmitWide(cons,n); }
 		uint32_t const m = P.w;
 		LDSQ uint64_t const * PEQ = L.peq();
 		enum { PW = FastLds<CT>::pw };      // the A window has at most 63 bases: word 0 of every symbol
@@ -3723,6 +3864,32 @@ struct FastEngine
 	DEV void emitRecord(LDSQ uint8_t const * cons, uint32_t const nops, uint8_t * rec)
 	{
 		uint32_t const m = P.w;
+		if constexpr ( CT::wide != 0 )
+		{
+			if ( DACC_WIDE_W(m) )
+			{
+				// wide record (dev_types.hpp): 16 bit group offsets from rec[2] on, symbols behind the m+2 offsets
+				uint8_t * const off = rec+2; uint8_t * const sym = rec + 2 + 2*(m+2);
+				if ( lane == 0 ) { rec[0] = 1; rec[1] = 0; off[0] = 0; off[1] = 0; off[2*(m+1)] = nops & 0xFFu; off[2*(m+1)+1] = nops >> 8; }
+				uint32_t cbase = 0, abase = 0;
+				for ( uint32_t c0 = 0; c0 < nops; c0 += WSZ )
+				{
+					uint32_t const q = c0 + lane;
+					bool const act = q < nops;
+					uint32_t const op = act ? L.alops()[nops-1-q] : 2u;
+					uint32_t ctot, atot;
+					uint32_t const cpos = cbase + wv_scan_flag(act && op != 3,ctot);
+					uint32_t const arank = abase + wv_scan_flag(act && op != 2,atot);
+					if ( act )
+					{
+						sym[q] = (op == 3) ? 4 : cons[cpos];
+						if ( op != 2 ) { off[2*(arank+1)] = (q+1) & 0xFFu; off[2*(arank+1)+1] = (q+1) >> 8; }
+					}
+					cbase += ctot; abase += atot;
+				}
+				return;
+			}
+		}
 		uint8_t * off = rec+1; uint8_t * sym = rec + 1 + (m+2);
 		if ( lane == 0 ) { rec[0] = 1; off[0] = 0; off[m+1] = nops; }
 		uint32_t cbase = 0, abase = 0;
@@ -3838,9 +4005,9 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 	windowInterval(pile.l,B.P.a,B.P.w,y,astart,aend);
 
 	WindowOut out; out.status = WS_INSUFFICIENT; out.mao = 0; out.elength = 0; out.k = 0; out.filterfreq = -1; out.conslen = 0; out.minrate = 0; out.flags = 0;
-	uint8_t * rec = B.wrec + widx*WREC;
+	uint8_t * rec = B.wrec + widx*(CT::wide ? DACC_WREC_OF(B.P.w) : static_cast<uint32_t>(WREC));
 	if ( lane == 0 ) rec[0] = 0;
-	if ( B.P.w > 63 ) { FFAIL(1) }
+	if ( B.P.w > (CT::wide ? 127u : 63u) ) { FFAIL(1) }
 
 	DevOvl const * ov = B.ovl + pile.first_ovl;
 	uint32_t nact = 0, mao = 0, toolong = 0;
@@ -4010,7 +4177,7 @@ DEV int processWindowFast(FastBatch const & FB, uint64_t const widx, LDSQ uint8_
 						{
 							lconsok = true; minrate = err; haveMin = true;
 							bestlen = L.acc()[0].l;
-							if ( bestlen > MAXCONS ) { FFAIL(9) }
+							if ( bestlen > ((CT::wide && B.P.w > 64u) ? FastLds<CT>::consmax : static_cast<uint32_t>(MAXCONS)) ) { FFAIL(9) }
 							for ( uint32_t i = lane; i < bestlen; i += WSZ ) best[i] = L.consL()[L.acc()[0].o+i];
 							out.k = k; out.filterfreq = ff;
 							wv_sync();

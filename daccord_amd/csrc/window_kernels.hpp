@@ -97,5 +97,7 @@ extern template __global__ void k_window_fast<3>(FastBatch, uint32_t const *, ui
 extern template __global__ void k_window_fast<4>(FastBatch, uint32_t const *, uint32_t *);
 extern template __global__ void k_window_fast<6>(FastBatch, uint32_t const *, uint32_t *);
 extern template __global__ void k_window_fast<7>(FastBatch, uint32_t const *, uint32_t *);
+extern template __global__ void k_window_fast<8>(FastBatch, uint32_t const *, uint32_t *);
+extern template __global__ void k_window_fast<9>(FastBatch, uint32_t const *, uint32_t *);
 #endif
 #endif

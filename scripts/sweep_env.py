@@ -22,7 +22,10 @@ def main():
             os.environ.pop(k, None)
         for kv in [x for x in setting.split(",") if x]:
             k, v = kv.split("="); os.environ[k] = v; keys.add(k)
-        E = engine.Engine(default_params(k=int(os.environ.get("SWEEP_K", "14"))))
+        pkw = dict(k=int(os.environ.get("SWEEP_K", "14")))
+        if os.environ.get("SWEEP_W"):      # window size / advance (wide windows: SWEEP_W=80 SWEEP_A=20)
+            pkw["w"] = int(os.environ["SWEEP_W"]); pkw["a"] = int(os.environ.get("SWEEP_A", str(max(1, pkw["w"] // 4))))
+        E = engine.Engine(default_params(**pkw))
         E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
         fr, ba = E(piles, ovl, d.trace)
         t0 = time.perf_counter(); tier = [0.0, 0.0, 0.0]; win = 0.0; trc = 0.0; vot = 0.0

@@ -219,14 +219,16 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		WB.nwindows = BP.nwindows; WB.wrec = wrec.data(); WB.wout = wout.data(); WB.arena = arena.data(); WB.prof = 0; WB.pregen = 0;
 		FastBatch FB[3]; FastBatch FB0, FB7;
 		// hand-over slots as in the library (DACC_HAND=0: off)
-		uint32_t const handwords = (BP.deep ? 2048u + 128u : 1024u + 64u) + 4u;
+		uint32_t const handwords = (BP.wide ? 4096u + 128u : (BP.deep ? 2048u + 128u : 1024u + 64u)) + 4u;
 		bool const handon = !(getenv("DACC_HAND") && getenv("DACC_HAND")[0] == '0') && c->par.klow == c->par.khigh;
 		std::vector<uint64_t> hand(handon ? static_cast<size_t>(BP.nwindows+1)*handwords : 1); uint32_t handctr = 0;
 		// (pattern in the slots that can be used first; the whole buffer is 8 KB per window of the batch and stays untouched pages otherwise)
 		std::fill(hand.begin(),hand.begin()+std::min<size_t>(hand.size(),(64u<<20)/8u),0x0101010101010101ull*arenafill);
 		std::vector<uint8_t> lds[3]; std::vector<uint8_t> gslab[3]; std::vector<uint8_t> lds0, gslab0, lds7, gslab7;
 		bool big = false; for ( size_t i = 0; i < c->H.dpsq_vst.size(); ++i ) if ( c->H.dpsq_vst[i] >> 32 ) big = true;
-		bool const usefast = c->usefast && !big && c->H.nrows <= 64 && c->H.nsup <= FSUPCAP;
+		// (round 6) wide windows (w 64 ... 127: nrows = w+1 <= 128) run in tier 8, the second slot, alone; DACC_WIDE_TIER=0: generic engine only (rounds 4-5)
+		bool const widetier = BP.wide && !(getenv("DACC_WIDE_TIER") && getenv("DACC_WIDE_TIER")[0] == '0');
+		bool const usefast = c->usefast && !big && (widetier ? (c->H.nrows <= 128 && c->H.nsup <= FSUPCAPW) : (c->H.nrows <= 64 && c->H.nsup <= FSUPCAP && c->par.w <= 63));
 		bool tierok[3];
 		// the library's pre-scan (k_prescan + k_prescan_lists): windows with an active B string of more than 64 bases are flagged (the first
 		// slot's tiers skip them); those with a string of more than 128 bases (second bit map: every tier skips them) are listed for the launch
@@ -243,7 +245,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				{
 					uint32_t const len = wt_e[ov.wtoff+r] - wt_b[ov.wtoff+r];
 					uint64_t const w = winbase + ov.y0 + r;
-					if ( len > 64u ) pregen[w>>5] |= 1u << (w&31);
+					if ( len > (widetier ? 128u : 64u) ) pregen[w>>5] |= 1u << (w&31);
 					if ( len > 128u ) pregen2[w>>5] |= 1u << (w&31);
 				}
 			}
@@ -259,6 +261,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 #endif
 			lds[t].assign(BP.ftier[t].ldsbytes+64,arenafill);
 			tierok[t] = usefast && static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftier[t].tabcap;
+			if ( widetier && t == 0 ) tierok[t] = false;
 			c->ntier[t] = 0; for ( int i = 0; i < 64; ++i ) c->reasonsT[t][i] = 0; for ( int i = 0; i < 24; ++i ) c->flagbitsT[t][i] = 0;
 		}
 		c->nretry = 0; c->glist.clear();
@@ -271,6 +274,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 					if ( ((pregen2[w>>5] >> (w&31)) & 1) || !slot1 ) pregenlist.push_back(w); else slot1list.push_back(w);
 				}
 			if ( usefast && tierok[0] && long128 ) for ( int t = 1; t < 3; ++t ) FB[t].W.pregen = pregen2.data();
+			if ( usefast && widetier ) { FB[1].W.pregen = pregen2.data(); FB[2].W.pregen = pregen2.data(); }
 		}
 		// tier 0 (size classes) in front of tier 1 of a shallow batch, as in the library (DACC_TIERS bit 3 switches it off)
 		bool const tier0ok = !BP.deep && tierok[0] && !(getenv("DACC_TIERS") && !((atoi(getenv("DACC_TIERS"))>>3)&1));
@@ -306,8 +310,10 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 			wave_run([&]() {
 				if ( t == 0 && BP.deep ) { FastLds< FastTier<4> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
 				else if ( t == 0 ) { FastLds< FastTier<1> > L; L.base = lds[0].data(); fast_load_tables(L,BP.ftier[0].nrows,BP.ftier[0].nsup,T,c->H.dpsq_vst.data()); }
+				else if ( t == 1 && BP.wide ) { FastLds< FastTier<8> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 				else if ( t == 1 && BP.deep ) { FastLds< FastTier<2> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
 				else if ( t == 1 ) { FastLds< FastTier<6> > L; L.base = lds[1].data(); fast_load_tables(L,BP.ftier[1].nrows,BP.ftier[1].nsup,T,c->H.dpsq_vst.data()); }
+				else if ( BP.wide ) { FastLds< FastTier<9> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 				else { FastLds< FastTier<3> > L; L.base = lds[2].data(); fast_load_tables(L,BP.ftier[2].nrows,BP.ftier[2].nsup,T,c->H.dpsq_vst.data()); }
 			});
 		};
@@ -331,8 +337,10 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				int r;
 				if ( t == 0 && BP.deep ) r = processWindowFast< FastTier<4> >(FB[0],wdx,lds[0].data(),resume);
 				else if ( t == 0 ) r = processWindowFast< FastTier<1> >(FB[0],wdx,lds[0].data(),resume);
+				else if ( t == 1 && BP.wide ) r = processWindowFast< FastTier<8> >(FB[1],wdx,lds[1].data(),resume);
 				else if ( t == 1 && BP.deep ) r = processWindowFast< FastTier<2> >(FB[1],wdx,lds[1].data(),resume);
 				else if ( t == 1 ) r = processWindowFast< FastTier<6> >(FB[1],wdx,lds[1].data(),resume);
+				else if ( BP.wide ) r = processWindowFast< FastTier<9> >(FB[2],wdx,lds[2].data(),resume);
 				else r = processWindowFast< FastTier<3> >(FB[2],wdx,lds[2].data(),resume);
 				if ( wv_lane() == 0 ) rc = r;
 			});
