@@ -134,12 +134,12 @@ template<> struct FastTier<5> { typedef uint16_t id_t; typedef uint8_t sid_t; en
 // of a stretch up to nrows = w+1 <= 128 (two words per position mask: maskF / maskFh), candidates and a consensus of up to 128 symbols, the
 // two-word consensus -> A alignment and the wide window record (dev_types.hpp: WRECW).  A batch with w > 63 runs this tier alone in front of the
 // generic engine (BatchPlan::wide); sized for 20x piles at w = 64 ... 96 (20 strings of 83 k-mers at w = 96, k = 14).
-template<> struct FastTier<8> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 6144, rch = 4, fch = 8, fnw = 4, fnc = 64, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 40, precap = 3072, ncap = 2304, scap = 248, lcap = 3072, wcap = 6144, rccap = 512, fcap = 512, siqcap = 96, blcap = 128, seqcap = 96, psiq = 10, consrow = 128, lscrids = 2560, wide = 1 }; };
+template<> struct FastTier<8> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 6144, rch = 4, fch = 8, fnw = 4, fnc = 64, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 40, precap = 3072, ncap = 2304, scap = 248, lcap = 3072, wcap = 6144, rccap = 640, fcap = 512, siqcap = 96, blcap = 128, seqcap = 96, psiq = 10, consrow = 128, lscrids = 2560, wide = 1 }; };
 
 // tier 9 (round 6, one wavefront per CU): what overflows tier 8 -- its reverse pool (512 paths), forward pool, score intervals -- before the generic
 // engine, which recomputes both enumerations for every (first, last) k-mer pair and takes seconds for such a window (30 of 37 000 windows at
 // w = 64 were 6.2 of a step's 6.7 s, profiles/r06v).  Tier 3's pools with the wide tier's masks, alignment and record.
-template<> struct FastTier<9> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 8192, rch = 8, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 3072, scap = 248, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 1024, siqcap = 256, blcap = 128, seqcap = 96, psiq = 10, consrow = 128, lscrids = 2560, wide = 1 }; };
+template<> struct FastTier<9> { typedef uint16_t id_t; typedef uint16_t sid_t; enum : uint32_t { smax = 500, gw = 1, wcapg = 8192, rch = 16, fch = 16, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 4096, ncap = 3072, scap = 512, lcap = 4096, wcap = 8192, rccap = 2048, fcap = 1024, siqcap = 256, blcap = 128, seqcap = 96, psiq = 10, consrow = 128, lscrids = 2560, wide = 1 }; };
 
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -2309,7 +2309,36 @@ struct FastEngine
 	// (an extension is strictly longer than its parent and the buckets are drained in increasing base length), so a
 	// bucket's heap is rebuilt right before it is drained by pushing its paths in creation order: one 12 entry heap per
 	// enumeration instead of one per base length, same heap arrays, same pop order among equal weights.
-	struct FEnum { ChunkList<FNW> C; uint32_t np, nfpop; uint64_t fmaxw, ffm, m0, m1; };
+	// (m0, m1: base lengths with pending paths, a bit per length; wide tiers: m2 for 128 ... 191 -- a forward path of a window of 100 bases and more
+	// ends beyond 127 when its last stretch is long, profiles/r06w: 364 of 120 000 windows at w = 104 went to the generic engine on this)
+	template<bool W, int DUMMY = 0> struct FEnumHi { }; template<int DUMMY> struct FEnumHi<true,DUMMY> { uint64_t m2; };
+	struct FEnum : FEnumHi<(CT::wide != 0)> { ChunkList<FNW> C; uint32_t np, nfpop; uint64_t fmaxw, ffm, m0, m1; };
+	enum : uint32_t { FBLMAX = CT::wide ? 191u : 127u };
+	DEV static void fblSet(FEnum & F, uint32_t const nbl)
+	{
+		// (wide tiers only; the other tiers keep their two-word statements in place: moved into a function, the compiler turns their
+		// branch into selects -- a different instruction stream than the measured one.  Unconditional updates here: a three-way choice of
+		// the word makes the compiler address F in scratch memory)
+		if constexpr ( CT::wide != 0 )
+		{
+			uint64_t const b = 1ull << (nbl & 63u); uint32_t const wd = nbl >> 6;
+			F.m0 |= wd == 0 ? b : 0ull; F.m1 |= wd == 1 ? b : 0ull; F.m2 |= wd == 2 ? b : 0ull;
+		}
+	}
+	DEV static bool fblAny(FEnum const & F) { if constexpr ( CT::wide != 0 ) return (F.m0 | F.m1 | F.m2) != 0; else return (F.m0 | F.m1) != 0; }
+	// lowest pending base length, removed from the masks
+	DEV static uint32_t fblPop(FEnum & F)
+	{
+		if constexpr ( CT::wide == 0 ) return 0;
+		else
+		{
+			uint32_t const wd = F.m0 ? 0u : (F.m1 ? 1u : 2u);
+			uint64_t const m = wd == 0 ? F.m0 : (wd == 1 ? F.m1 : F.m2);
+			uint64_t const c = m & (m-1);
+			F.m0 = wd == 0 ? c : F.m0; F.m1 = wd == 1 ? c : F.m1; F.m2 = wd == 2 ? c : F.m2;
+			return 64u*wd + static_cast<uint32_t>(__builtin_ctzll(m));
+		}
+	}
 	DEV int32_t extendPath(FEnum & F, uint32_t const parent, uint32_t const s, uint32_t const ppos, uint32_t const plen, uint64_t const pw, uint32_t const pbl,
 		int32_t const sfo, uint64_t const wf, uint64_t const wf1, uint32_t & npos, uint32_t & nbl, uint64_t & nw)
 	{
@@ -2320,7 +2349,7 @@ struct FastEngine
 		if ( plen == 0 ) { baselen = slen+k-1; weight = sfo >= 0 ? wf : 0; }
 		else { baselen += slen-1; if ( sfo >= 0 ) weight += wf - wf1; }
 		npos = ppos + (slen-1); nbl = baselen; nw = weight;
-		if ( baselen > 127 || npos > 255 || plen+1 > 255 ) { over(2048); return -1; }
+		if ( baselen > FBLMAX || npos > 255 || plen+1 > 255 ) { over(2048); return -1; }
 		++F.np;
 		L.f_parent()[slot] = parent; L.f_stretch()[slot] = s; L.f_len()[slot] = plen+1; L.f_pos()[slot] = npos;
 		L.f_w()[slot] = weight; L.f_baselen()[slot] = baselen;
@@ -2328,7 +2357,7 @@ struct FastEngine
 	}
 	DEV void forwardEnumerateLane(FEnum & F, LDSQ uint8_t * chunkrow, View const & V, int32_t const firstnode, int64_t const lmax, LDSQ id_t * hp)
 	{
-		clInit(F.C,chunkrow); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
+		clInit(F.C,chunkrow); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0; if constexpr ( CT::wide != 0 ) F.m2 = 0;
 		if ( firstnode < 0 ) return;
 		PROFX_T0      // profiling builds: lane 0's tree, split into filling the bucket heap (19) and draining it (20)
 		SITE_T0
@@ -2341,17 +2370,22 @@ struct FastEngine
 				uint32_t npos, nbl; uint64_t nw;
 				int32_t const id = extendPath(F,0,sx,0,0,0,0,sfo,wf,0,npos,nbl,nw);
 				if ( id < 0 ) return;
-				if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64);
+				if constexpr ( CT::wide == 0 ) { if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64); } else fblSet(F,nbl);
 			}
 		}
 		LDSQ uint64_t const * W = L.f_w();
 		SITE(11)      // forward tree: the root's extensions
 		// (round 6, measured and dropped: starting a bucket's scan behind the leading entries whose base lengths are already drained -- three
 		// more registers and a compare per group of four made the window kernels 0.6 % slower, profiles/r06d)
-		while ( F.m0 | F.m1 )
+		while ( fblAny(F) )
 		{
-			uint32_t const zz = F.m0 ? static_cast<uint32_t>(__builtin_ctzll(F.m0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(F.m1));
-			if ( zz < 64 ) F.m0 &= F.m0-1; else F.m1 &= F.m1-1;
+			uint32_t zz;
+			if constexpr ( CT::wide == 0 )
+			{
+				zz = F.m0 ? static_cast<uint32_t>(__builtin_ctzll(F.m0)) : 64u + static_cast<uint32_t>(__builtin_ctzll(F.m1));
+				if ( zz < 64 ) F.m0 &= F.m0-1; else F.m1 &= F.m1-1;
+			}
+			else zz = fblPop(F);
 			uint32_t hn = 0;
 			for ( uint32_t i0 = 0; i0 < F.np; i0 += 64 )
 			{
@@ -2417,7 +2451,7 @@ struct FastEngine
 							if ( ep < 0 ) return;
 							if ( nw >= FW_THRES_01 && static_cast<int64_t>(npos) + k <= lmax )
 							{
-								if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64);
+								if constexpr ( CT::wide == 0 ) { if ( nbl < 64 ) F.m0 |= 1ull << nbl; else F.m1 |= 1ull << (nbl-64); } else fblSet(F,nbl);
 							}
 							else --F.np;
 						}
@@ -3377,7 +3411,7 @@ struct FastEngine
 			{
 			if ( lane == 0 ) L.ctr()[1] = 0;
 			wv_sync();
-			clInit(F.C,L.fchb() + 8*FNW*(fi < nF ? fi : static_cast<uint32_t>(FNC))); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0;
+			clInit(F.C,L.fchb() + 8*FNW*(fi < nF ? fi : static_cast<uint32_t>(FNC))); F.np = 0; F.nfpop = 0; F.fmaxw = 0; F.ffm = 0; F.m0 = 0; F.m1 = 0; if constexpr ( CT::wide != 0 ) F.m2 = 0;
 			firstnode = -1;
 			fover = 0;
 			if ( fact )

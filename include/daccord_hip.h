@@ -43,7 +43,7 @@ extern "C" {
 /* Run parameters: the daccord command line options that shape the path
  * (src/daccord.cpp:101-169 defaults, :1282-1305 parsing). */
 typedef struct dacc_params {
-	uint32_t w;              /* -w window size            (default 40); 1 <= w <= 128 (w <= 63: LDS tiers; 64..128: generic engine) */
+	uint32_t w;              /* -w window size            (default 40); 1 <= w <= 128 (w <= 63: LDS tiers; 64..127: the wide LDS tiers; 128: generic engine) */
 	uint32_t a;              /* -a advance size           (default 10) */
 	uint32_t klow, khigh;    /* -k single value or lo,hi  (default 8,8); 3 <= k <= 16 */
 	int32_t  minfilterfreq;  /* --minfilterfreq           (default 0) */

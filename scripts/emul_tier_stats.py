@@ -29,7 +29,10 @@ k = int(args[2]) if len(args) > 2 else 14
 cname = args[3] if len(args) > 3 else "cfg2"
 case = dict(CASES[cname]); case["first"] = first; case["npiles"] = npiles
 d, ovl, piles, sel = make_case(case, pyoracle.pile_select)
-E = emul_lib.Emul(default_params(k=k)); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
+pkw = dict(k=k)
+if os.environ.get("STAT_W"):      # wide windows: STAT_W=80 (advance w/4 unless STAT_A)
+    pkw["w"] = int(os.environ["STAT_W"]); pkw["a"] = int(os.environ.get("STAT_A", str(max(1, pkw["w"] // 4))))
+E = emul_lib.Emul(default_params(**pkw)); E.set_error_profile(*d.error_profile()); E.load_db(d.bps, d.boff, d.rlen)
 t0 = time.time()
 fr, ba = E.run(sel, ovl, d.trace)
 w = E.windows()

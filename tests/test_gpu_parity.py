@@ -213,10 +213,12 @@ def test_windows_with_long_strings(route, monkeypatch):
 
 
 @pytest.mark.parametrize("kw,erate", [(dict(w=100, a=25, k=8), 0.12), (dict(w=128, a=32, k=12), 0.15), (dict(w=65, a=16, k=8), 0.15),
-                                      (dict(w=96, a=24, k=9, producefull=1), 0.2), (dict(w=128, a=10, klow=13, khigh=14), 0.12), (dict(w=64, a=16, k=8), 0.12)])
+                                      (dict(w=96, a=24, k=9, producefull=1), 0.2), (dict(w=128, a=10, klow=13, khigh=14), 0.12), (dict(w=64, a=16, k=8), 0.12),
+                                      (dict(w=104, a=26, k=14), 0.15), (dict(w=88, a=22, k=12), 0.18)])
 def test_wide_windows(kw, erate):
-    """-w 64..128 (free in the reference, src/daccord.cpp:1282-1305): generic engine, two-word consensus -> A alignment, 640 byte
-    window records with 16 bit group offsets, the vote over them (the emulation runs the same cases: test_emul_parity.py)"""
+    """-w 64..128 (free in the reference, src/daccord.cpp:1282-1305): two-word consensus -> A alignment, 640 byte window records with
+    16 bit group offsets, the vote over them (the emulation runs the same cases: test_emul_parity.py).  Round 6: w = 64 ... 127 run in
+    the wide LDS tiers (k_window_fast<8>, then <9>) in front of the generic engine, which still takes w = 128 alone."""
     d = SynthData(60000, 150, 3000, seed=kw["w"] + kw.get("k", 13), erate=erate)
     ovl, piles = pyoracle.pile_select(d.ovl, d.piles)
     O, E = _pair(d, **kw)
@@ -228,6 +230,11 @@ def test_wide_windows(kw, erate):
     assert bad == [], (len(bad), bad[:5])
     assert len(bo) > 8000 and frags_equal(fo, bo, fx, bx)
     assert engine.fasta(fx, bx) == pyoracle.fasta(fo, bo)
+    t = E.timing()
+    if kw["w"] < 128:      # the wide tiers ran and finished most of the windows (w = 100 at k = 8, dense graphs: 641 of 702, a third of them in tier 8)
+        assert t.tier_ms[1] > 0 and t.tier_out[1] < len(wo) and t.tier_out[2] + t.long_windows < len(wo) // 4, (t.tier_ms[1], t.tier_out[1], t.tier_out[2], t.long_windows, len(wo))
+    else:
+        assert t.tier_ms[1] == 0 and t.tier_ms[2] == 0
     # and once more on the same context (buffers sized for the wide records are reused)
     fy, by = E(piles[2:5], ovl, d.trace)
     f2, b2 = O.run(piles[2:5], ovl, d.trace, nthreads=8)
