@@ -36,7 +36,7 @@ class DaccTiming(C.Structure):
                 ("algo_bytes", C.c_uint64), ("tier_ms", C.c_float * 3), ("tier_out", C.c_uint32 * 3),
                 ("first_tier", C.c_uint32), ("long_windows", C.c_uint32), ("tier0_ms", C.c_float), ("tier0_in", C.c_uint32),
                 ("tier0_out", C.c_uint32), ("tier7_ms", C.c_float), ("tier7_in", C.c_uint32), ("tier7_out", C.c_uint32), ("pad_", C.c_uint32),
-                ("long_first_tier", C.c_uint32)]
+                ("long_first_tier", C.c_uint32), ("tier10_ms", C.c_float), ("tier10_out", C.c_uint32), ("tier10_ran", C.c_uint32), ("pad2_", C.c_uint32)]
 
 
 class DaccWindowResult(C.Structure):

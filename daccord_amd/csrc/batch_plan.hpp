@@ -61,6 +61,7 @@ struct BatchPlan
 	FastCaps ftier[NTIER];    // LDS fast path capacity tiers: 3, 2, 1 wavefronts per CU
 	FastCaps ftier0;          // tier 0: small windows of shallow batches (size classes), runs in the first slot in front of tier 1
 	FastCaps ftier7;          // tier 7: the middle size class (7 wavefronts per CU), between tier 0 and tier 1
+	FastCaps ftierD;          // tier 10 (round 6): the dense-graph tier of shallow batches, between the second slot's tier 6 and tier 3
 	FastCaps ftierL;          // tier 5: windows with a string of 65..128 bases (second stream, before the generic engine)
 	uint64_t ndeepwin;        // windows with more strings / k-mer instances than the first tier of shallow batches holds
 	bool deep;                // most windows are deep: the first tier is FastTier<4> (many strings, small graph) instead of FastTier<1>
@@ -327,6 +328,7 @@ struct BatchPlan
 		ftier0 = fastCapsOf< FastTier<0> >(tab_nrows,tab_nsup);
 		ftier7 = fastCapsOf< FastTier<7> >(tab_nrows,tab_nsup);
 		ftierL = fastCapsOf< FastTier<5> >(tab_nrows,tab_nsup);
+		ftierD = fastCapsOf< FastTier<10> >(tab_nrows,tab_nsup);
 		ftier[2] = wide ? fastCapsOf< FastTier<9> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;
 	}

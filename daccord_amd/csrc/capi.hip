@@ -381,7 +381,7 @@ struct dacc_ctx
 	DevBuf<uint8_t> d_wrec; DevBuf<WindowOut> d_wout; DevBuf<uint8_t> d_arena;
 	DevBuf<uint8_t> d_has, d_oc, d_outsym, d_pilebad; DevBuf<uint16_t> d_ld0; DevBuf<uint32_t> d_ocs, d_nfrag, d_err;
 	DevBuf<VoteFragment> d_frags; DevBuf<uint64_t> d_fragbase; DevBuf<uint64_t> d_prof;
-	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; int env_trdyn; int env_widetier; bool widetier; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
+	DevBuf<uint64_t> d_vst; DevBuf<uint32_t> d_tab32; DevBuf<uint8_t> d_gslab; DevBuf<uint32_t> d_retry[3], d_work, d_gearly, d_pregen, d_pregen2, d_pregenlist; DevBuf<uint8_t> d_arena2; DevBuf<uint64_t> d_trslab; DevBuf<uint32_t> d_small, d_big, d_mid; DevBuf<uint64_t> d_hand; DevBuf<uint32_t> d_handctr; uint32_t handcap, handwords; uint64_t handwant, nruns; bool nohand, oom; bool tier0_ok; uint32_t tier0_grid; uint64_t gstride0; bool tier7_ok, tier7_ran, tier7_adapt_off; int env_t7adapt; int env_trdyn; int env_widetier; bool widetier; int env_dense; bool tier10_ok, tier10_ran; uint32_t tier10_grid, tier10_out; uint64_t gstride10; DevBuf<uint32_t> d_dense; hipEvent_t evT10; uint32_t tier7_grid; uint64_t gstride7; hipEvent_t evT7;
 	uint32_t nlong[2];      // windows on the two lists of the second stream in the current pass (pre-scan, first tier's generic-only windows)
 	uint32_t tier_grid[3], retry_grid, early_grid; uint64_t gstride[3]; int tier_ok[3]; int tierL_ok; int usefast; int sched; uint32_t tier_out[3];
 	uint32_t tr_grid, tr_lds, tr_words, tr_lanes, trace_bytes, win_grid;
@@ -452,6 +452,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 		char const * tm = getenv("DACC_TIERS"); c->env_tiers = tm ? atoi(tm) : 31;      // bit t enables LDS tier t+1, bit 3 tier 0 (size classes), bit 4 tier 7 (the middle class; needs tier 0)
 		char const * l8 = getenv("DACC_LONG128"); c->env_long128 = !(l8 && l8[0] == '0');      // 0: windows with a string of 65 ... 128 bases run in tier 5 on the second stream (rounds 3-5)
 		{ char const * wt = getenv("DACC_WIDE_TIER"); c->env_widetier = !(wt && wt[0] == '0'); c->widetier = false; }
+		{ char const * dt = getenv("DACC_DENSE_TIER"); c->env_dense = !(dt && dt[0] == '0'); c->tier10_ok = false; c->tier10_ran = false; c->tier10_grid = 0; c->tier10_out = 0; c->gstride10 = 0; }      // 0: tier 6 hands on to tier 3 directly (before round 6's dense tier)
 		{ char const * td = getenv("DACC_TRACE_DYN"); c->env_trdyn = !(td && td[0] == '0'); }      // 0: k_trace walks its blocks with a fixed stride (rounds 1-5)
 		char const * ta = getenv("DACC_T7_ADAPT"); c->env_t7adapt = !(ta && ta[0] == '0');      // 0: tier 7 stays on whatever it hands on
 		char const * t7 = getenv("DACC_T7INST"); c->env_t7inst = t7 ? static_cast<uint32_t>(atoi(t7)) : static_cast<uint32_t>(T7INST_DEFAULT);      // size-class threshold of tier 7
@@ -465,7 +466,7 @@ int dacc_create(dacc_ctx ** out, dacc_params const * p)
 	hipEventCreateWithFlags(&c->evFirstTier,hipEventDisableTiming); hipEventCreateWithFlags(&c->evEarlyGeneric,hipEventDisableTiming); hipEventCreateWithFlags(&c->evPrescan,hipEventDisableTiming);
 	for ( int i = 0; i < 6; ++i ) hipEventCreate(&c->ev[i]);
 	for ( int i = 0; i < 3; ++i ) hipEventCreate(&c->evtier[i]);
-	hipEventCreate(&c->evT0); c->tier0_ran = false; hipEventCreate(&c->evT7);
+	hipEventCreate(&c->evT0); c->tier0_ran = false; hipEventCreate(&c->evT7); hipEventCreate(&c->evT10);
 	*out = c;
 	return DACC_OK;
 }
@@ -482,7 +483,7 @@ void dacc_destroy(dacc_ctx * c)
 	c->h_outsym.release(); c->d_pilebad.release(); c->d_has.release(); c->d_oc.release(); c->d_outsym.release(); c->d_ld0.release(); c->d_ocs.release(); c->d_nfrag.release(); c->d_err.release(); c->d_frags.release(); c->d_fragbase.release(); c->d_prof.release(); c->d_vst.release(); c->d_tab32.release(); c->d_gslab.release(); for ( int i = 0; i < 3; ++i ) c->d_retry[i].release(); c->d_work.release(); c->d_gearly.release(); c->d_pregen.release(); c->d_pregen2.release(); c->d_pregenlist.release(); c->d_arena2.release(); c->d_trslab.release(); c->d_small.release(); c->d_big.release(); c->d_mid.release(); c->d_hand.release(); c->d_handctr.release();
 	for ( int i = 0; i < 6; ++i ) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream); hipStreamDestroy(c->stream2); hipEventDestroy(c->evFirstTier); hipEventDestroy(c->evEarlyGeneric); hipEventDestroy(c->evPrescan); for ( int i = 0; i < 3; ++i ) hipEventDestroy(c->evtier[i]);
-	hipEventDestroy(c->evT0); hipEventDestroy(c->evT7);
+	hipEventDestroy(c->evT0); hipEventDestroy(c->evT7); hipEventDestroy(c->evT10); c->d_dense.release();
 	delete c;
 }
 
@@ -599,7 +600,7 @@ static int runDevice(dacc_ctx * c)
 		// no LDS tier usable (DACC_TIERS=0 or a model table no tier's overlay holds): everything runs in the generic engine on
 		// the main stream; the pre-scan / second stream would hand the same windows to two kernels
 		bool const anytier = c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2];
-		c->tier0_ran = false; c->tier7_ran = false;
+		c->tier0_ran = false; c->tier7_ran = false; c->tier10_ran = false;
 		if ( c->usefast && anytier )
 		{
 			// windows only the generic engine can run (a string longer than 64 bases): found by a scan of the window tables and
@@ -707,6 +708,16 @@ static int runDevice(dacc_ctx * c)
 					else if ( t == 1 && BP.deep ) hipLaunchKernelGGL(k_window_fast<2>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( t == 1 ) hipLaunchKernelGGL(k_window_fast<6>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					else if ( c->widetier ) hipLaunchKernelGGL(k_window_fast<9>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
+					else if ( c->tier10_ok && list )
+					{
+						// (round 6) the dense-graph tier in front of tier 3: two wavefronts per CU with 16 bit path ids take what the second slot
+						// handed on; tier 3 (one per CU) gets what overflows them
+						HIPCHK(hipMemsetAsync(c->d_dense.p,0,sizeof(uint32_t),s));
+						FastBatch FD = FB; FD.F = BP.ftierD; FD.retry = c->d_dense.p; FD.gstride = c->gstride10;
+						hipLaunchKernelGGL(k_window_fast<10>,dim3(c->tier10_grid),dim3(64),FD.F.ldsbytes,s,FD,list,(c->sched&1) ? c->d_work.p+24 : static_cast<uint32_t *>(0));
+						HIPCHK(hipEventRecord(c->evT10,s)); c->tier10_ran = true;
+						hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,static_cast<uint32_t const *>(c->d_dense.p),work);
+					}
 					else hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,list,work);
 					list = c->d_retry[t].p;
 					if ( !early )
@@ -775,6 +786,8 @@ static int runDevice(dacc_ctx * c)
 	{ int const rc = voteAndFetch(); if ( rc ) return rc; }
 	for ( int i = 0; i < 3; ++i ) c->tier_out[i] = 0;
 	if ( c->usefast && BP.nwindows ) for ( int i = 0; i < 3; ++i ) if ( c->tier_ok[i] ) HIPCHK(hipMemcpy(&c->tier_out[i],c->d_retry[i].p,sizeof(uint32_t),hipMemcpyDeviceToHost));
+	c->tier10_out = 0;
+	if ( c->tier10_ran ) HIPCHK(hipMemcpy(&c->tier10_out,c->d_dense.p,sizeof(uint32_t),hipMemcpyDeviceToHost));
 	c->timing.tier0_in = 0; c->timing.tier0_out = 0; c->timing.tier7_in = 0; c->timing.tier7_out = 0;
 	if ( c->usefast && BP.nwindows && (c->tier_ok[0] || c->tier_ok[1] || c->tier_ok[2]) )
 	{
@@ -869,6 +882,8 @@ static int runDevice(dacc_ctx * c)
 	if ( c->tier0_ran ) { hipEventElapsedTime(&ms,c->ev[1],c->evT0); c->timing.tier0_ms = ms; }
 	c->timing.tier7_ms = 0; c->timing.pad_ = 0;
 	if ( c->tier7_ran ) { hipEventElapsedTime(&ms,c->evT0,c->evT7); c->timing.tier7_ms = ms; }
+	c->timing.tier10_ms = 0; c->timing.tier10_out = c->tier10_out; c->timing.tier10_ran = c->tier10_ran ? 1u : 0u;
+	if ( c->tier10_ran ) { hipEventElapsedTime(&ms,c->evtier[1],c->evT10); c->timing.tier10_ms = ms; }
 	hipEventElapsedTime(&ms,c->ev[2],c->ev[3]); c->timing.vote_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[3],c->ev[4]); c->timing.d2h_ms = ms;
 	hipEventElapsedTime(&ms,c->ev[0],c->ev[3]); c->timing.total_ms = ms;
@@ -1002,6 +1017,18 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			{
 				HIPCHK(c->d_mid.ensure(BP.nwindows+2));
 				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fg7)*F7.gbytes + 256));
+			}
+			// tier 10 (the dense-graph tier, two wavefronts per CU) between the second slot's tier 6 and tier 3 of a shallow batch: DACC_DENSE_TIER=0 switches it off
+			FastCaps const & FD = BP.ftierD;
+			c->tier10_ok = !BP.deep && !c->widetier && c->env_dense && c->tier_ok[1] && c->tier_ok[2] && FD.ldsbytes <= 160*1024 && (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= FD.tabcap);
+			uint64_t percuD = (160*1024) / (FD.ldsbytes ? FD.ldsbytes : 1); if ( percuD > 8 ) percuD = 8; if ( percuD < 1 ) percuD = 1;
+			uint64_t fgD = ((BP.nwindows+7)/8)*8; if ( fgD > 256*percuD ) fgD = 256*percuD; if ( fgD < 8 ) fgD = 8;
+			c->tier10_grid = static_cast<uint32_t>(fgD); c->gstride10 = FD.gbytes;
+			if ( c->tier10_ok )
+			{
+				HIPCHK(c->d_dense.ensure(BP.nwindows+2));
+				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fgD)*FD.gbytes + 256));
+				if ( FD.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<10>),hipFuncAttributeMaxDynamicSharedMemorySize,FD.ldsbytes));
 			}
 		}
 		{

@@ -186,6 +186,10 @@ typedef struct dacc_timing {
 	uint32_t tier7_out;      /* windows tier 7 handed on to tier 1 */
 	uint32_t pad_;
 	uint32_t long_first_tier; /* of long_windows: the windows the FIRST tier found no LDS tier can run (they ran in k_window_long behind it; the rest are the pre-scan's) */
+	float tier10_ms;         /* round 6, the dense-graph tier of shallow batches: k_window_fast<10> (2 wavefronts per CU) between tier 6 and tier 3, the part of tier_ms[2] in front of k_window_fast<3>; 0 if it did not run */
+	uint32_t tier10_out;     /* windows tier 10 handed on to tier 3 (it ran tier_out[1] windows) */
+	uint32_t tier10_ran;     /* 1: tier 10 ran in this pass (tier_out[1] went to it, not to tier 3) */
+	uint32_t pad2_;
 } dacc_timing;
 int  dacc_last_timing(dacc_ctx *ctx, dacc_timing *t);
 

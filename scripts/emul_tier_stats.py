@@ -36,5 +36,5 @@ E = emul_lib.Emul(default_params(**pkw)); E.set_error_profile(*d.error_profile()
 t0 = time.time()
 fr, ba = E.run(sel, ovl, d.trace)
 w = E.windows()
-print("piles=%d windows=%d tiers(t1,t2,t3,generic)=%s  %.1fs  ff=%s" % (npiles, len(w), E.counts(), time.time() - t0,
+print("piles=%d windows=%d tiers(t1,t2,t3,generic)=%s tier0/7/10=%s  %.1fs  ff=%s" % (npiles, len(w), E.counts(), (E.count_tier0(), E.count_tier7(), E.count_tier10()), time.time() - t0,
       dict(zip(*np.unique(w["filterfreq"], return_counts=True)))), file=sys.stderr)

@@ -41,7 +41,7 @@ def main():
         print(json.dumps({"setting": setting, "ms_per_step": round(1e3 * dt, 2), "mbase_s": round(len(ba) / dt / 1e6, 3),
                           "trace_ms": round(trc / steps, 2), "vote_ms": round(vot / steps, 2), "window_ms": round(win / steps, 2), "tier_ms": [round(x / steps, 2) for x in tier],
                           "handed_on": [int(t.tier_out[i]) for i in range(3)], "t0": [round(float(t.tier0_ms), 1), int(t.tier0_in), int(t.tier0_out)],
-                          "t7": [round(float(getattr(t, "tier7_ms", 0.0)), 1), int(getattr(t, "tier7_in", 0)), int(getattr(t, "tier7_out", 0))], "sha": h.hexdigest()[:16]}), flush=True)
+                          "t7": [round(float(getattr(t, "tier7_ms", 0.0)), 1), int(getattr(t, "tier7_in", 0)), int(getattr(t, "tier7_out", 0))], "t10": [round(float(getattr(t, "tier10_ms", 0.0)), 1), int(getattr(t, "tier10_out", 0))], "sha": h.hexdigest()[:16]}), flush=True)
         del E
 
 

@@ -31,7 +31,7 @@ struct EmulCtx
 	std::vector<dacc_fragment> frags; std::string bases;
 	std::vector<dacc_window_result> windows;
 	std::string err;
-	bool usefast; uint64_t ntier[3], nretry, nlong, ntier0, ntier7;
+	bool usefast; uint64_t ntier[3], nretry, nlong, ntier0, ntier7, ntier10;
 	std::vector<uint64_t> glist;   // windows that went to the generic engine: index, flags of the last tier
 	uint64_t reasonsT[3][64]; uint64_t flagbitsT[3][24];
 };
@@ -61,17 +61,18 @@ static void fillDev(EmulCtx & c, DevParams & P, DevTables & T)
 
 extern "C" {
 
-void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; c->ntier0 = 0; c->ntier7 = 0; return c; }
+void * emul_create(dacc_params const * p) { EmulCtx * c = new EmulCtx; c->par = *p; c->haveprofile = false; c->est_cor = 0; c->usefast = true; c->ntier[0] = c->ntier[1] = c->ntier[2] = c->nretry = 0; c->nlong = 0; c->ntier0 = 0; c->ntier7 = 0; c->ntier10 = 0; return c; }
 void emul_set_fast(void * v, int on) { static_cast<EmulCtx *>(v)->usefast = on; }
 void emul_reasons_tier(void * v, int t, uint64_t * r, uint64_t * fb) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( int i = 0; i < 64; ++i ) r[i] = c->reasonsT[t][i]; for ( int i = 0; i < 24; ++i ) fb[i] = c->flagbitsT[t][i]; }
 void emul_reasons2(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,1,r,fb); }
 void emul_reasons(void * v, uint64_t * r, uint64_t * fb) { emul_reasons_tier(v,0,r,fb); }
-void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier0+c->ntier7+c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
+void emul_counts(void * v, uint64_t * nf, uint64_t * nr) { EmulCtx * c = static_cast<EmulCtx *>(v); *nf = c->ntier0+c->ntier7+c->ntier10+c->ntier[0]+c->ntier[1]+c->ntier[2]; *nr = c->nretry; }
 uint64_t emul_generic_list(void * v, uint64_t * out, uint64_t cap) { EmulCtx * c = static_cast<EmulCtx *>(v); for ( uint64_t i = 0; i < c->glist.size() && i < cap; ++i ) out[i] = c->glist[i]; return c->glist.size(); }
 uint64_t emul_count_long(void * v) { return static_cast<EmulCtx *>(v)->nlong; }
 void emul_counts4(void * v, uint64_t * n) { EmulCtx * c = static_cast<EmulCtx *>(v); n[0] = c->ntier[0]; n[1] = c->ntier[1]; n[2] = c->ntier[2]; n[3] = c->nretry; }
 uint64_t emul_count_tier0(void * v) { return static_cast<EmulCtx *>(v)->ntier0; }
 uint64_t emul_count_tier7(void * v) { return static_cast<EmulCtx *>(v)->ntier7; }
+uint64_t emul_count_tier10(void * v) { return static_cast<EmulCtx *>(v)->ntier10; }
 void emul_destroy(void * v) { delete static_cast<EmulCtx *>(v); }
 char const * emul_error(void * v) { return static_cast<EmulCtx *>(v)->err.c_str(); }
 
@@ -278,7 +279,7 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		}
 		// tier 0 (size classes) in front of tier 1 of a shallow batch, as in the library (DACC_TIERS bit 3 switches it off)
 		bool const tier0ok = !BP.deep && tierok[0] && !(getenv("DACC_TIERS") && !((atoi(getenv("DACC_TIERS"))>>3)&1));
-		c->ntier0 = 0; c->ntier7 = 0;
+		c->ntier0 = 0; c->ntier7 = 0; c->ntier10 = 0;
 		// tier 7 (the middle size class) as in the library: DACC_TIERS bit 4 switches it off, DACC_T7INST is its threshold
 		uint32_t const t0inst = getenv("DACC_T0INST") ? static_cast<uint32_t>(atoi(getenv("DACC_T0INST"))) : static_cast<uint32_t>(T0INST_DEFAULT);
 		uint32_t const t7inst = getenv("DACC_T7INST") ? static_cast<uint32_t>(atoi(getenv("DACC_T7INST"))) : static_cast<uint32_t>(T7INST_DEFAULT);
@@ -304,6 +305,17 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 #endif
 			lds0.assign(BP.ftier0.ldsbytes+64,arenafill);
 			wave_run([&]() { FastLds< FastTier<0> > L; L.base = lds0.data(); fast_load_tables(L,BP.ftier0.nrows,BP.ftier0.nsup,T,c->H.dpsq_vst.data()); });
+		}
+		// tier 10 (the dense-graph tier) between the second slot's tier 6 and tier 3 of a shallow batch, as in the library (DACC_DENSE_TIER=0 switches it off)
+		FastBatch FBD; std::vector<uint8_t> ldsD, gslabD;
+		bool const tier10ok = usefast && !BP.deep && !widetier && tierok[1] && tierok[2] && !(getenv("DACC_DENSE_TIER") && getenv("DACC_DENSE_TIER")[0] == '0')
+			&& static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierD.tabcap;
+		if ( tier10ok )
+		{
+			FBD = FB[2]; FBD.F = BP.ftierD;
+			gslabD.assign(BP.ftierD.gbytes+64,arenafill); FBD.gslab = gslabD.data();
+			ldsD.assign(BP.ftierD.ldsbytes+64,arenafill);
+			wave_run([&]() { FastLds< FastTier<10> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); });
 		}
 		auto loadTables = [&](int const t)
 		{
@@ -385,6 +397,23 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 					if ( rc == FW_GENERIC ) gearly.push_back(wdx); else big.push_back(wdx);
 				}
 				cur.swap(big); haveList = true;
+			}
+			if ( t == 2 && tier10ok && haveList )
+			{
+				// k_window_fast<10> over the second slot's hand-overs; tier 3 then runs what it hands on
+				std::vector<uint64_t> cur10;
+				for ( size_t i = 0; i < cur.size(); ++i )
+				{
+					uint64_t const wdx = cur[i];
+					if ( FBD.W.pregen && ((FBD.W.pregen[wdx>>5] >> (wdx&31)) & 1) ) { cur10.push_back(wdx); continue; }      // (skipped by tier 3 as well)
+					if ( getenv("DACC_EMUL_POISON") ) { std::memset(ldsD.data(),atoi(getenv("DACC_EMUL_POISON")),ldsD.size()); std::memset(gslabD.data(),atoi(getenv("DACC_EMUL_POISON")),gslabD.size()); wave_run([&]() { FastLds< FastTier<10> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); }); }
+					int rc = -1;
+					dacc_emul_curwin = wdx; dacc_emul_curtier = 110;
+					wave_run([&]() { int const r = processWindowFast< FastTier<10> >(FBD,wdx,ldsD.data(),true); if ( wv_lane() == 0 ) rc = r; });
+					if ( rc == FW_DONE ) { ++c->ntier10; continue; }
+					cur10.push_back(wdx);
+				}
+				cur.swap(cur10);
 			}
 			uint64_t const n = haveList ? cur.size() : BP.nwindows;
 			for ( uint64_t i = 0; i < n; ++i )

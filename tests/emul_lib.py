@@ -85,6 +85,11 @@ class Emul:
         self.L.emul_count_tier7.restype = C.c_uint64; self.L.emul_count_tier7.argtypes = [C.c_void_p]
         return int(self.L.emul_count_tier7(self.h))
 
+    def count_tier10(self):
+        """windows that finished in tier 10 (the dense-graph tier between tier 6 and tier 3 of shallow batches)"""
+        self.L.emul_count_tier10.restype = C.c_uint64; self.L.emul_count_tier10.argtypes = [C.c_void_p]
+        return int(self.L.emul_count_tier10(self.h))
+
     def count_tier0(self):
         """windows finished by tier 0 (size classes: the small windows of a shallow batch)"""
         self.L.emul_count_tier0.restype = C.c_uint64; self.L.emul_count_tier0.argtypes = [C.c_void_p]

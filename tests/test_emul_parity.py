@@ -62,13 +62,16 @@ def test_empty_and_shallow_piles(small_data):
     assert len(fo) == 1 and fo[0]["aread"] == p[1]["aread"] and bo == bo.lower() and frags_equal(fo, bo, fe, be)
 
 
-def test_capacity_tiers_and_generic_engine_agree(small_data):
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_capacity_tiers_and_generic_engine_agree(small_data, dense, monkeypatch):
     """k=8 on 20x piles overflows the small LDS layouts for some windows: every capacity tier has to be exercised, and
-    the generic engine alone (fast path off) has to give the same bits."""
+    the generic engine alone (fast path off) has to give the same bits.  Round 6: what the second slot hands on goes through the
+    dense-graph tier (FastTier<10>, two wavefronts per CU) before tier 3 (one per CU); DACC_DENSE_TIER=0 = straight to tier 3."""
+    monkeypatch.setenv("DACC_DENSE_TIER", dense)
     d, ovl, piles = small_data
     O, E, (fo, bo), (fe, be) = _both(d, ovl, piles, slice(0, 4), k=8)
     t1, t2, t3, gen = E.counts()
-    assert t1 > 0 and t2 > 0 and t3 > 0, (t1, t2, t3, gen)
+    assert t1 > 0 and t2 > 0 and ((t3 > 0 and E.count_tier10() == 0) if dense == "0" else E.count_tier10() > 0), (t1, t2, t3, gen, E.count_tier10())
     assert windows_equal(O.windows(), E.windows()) == [] and frags_equal(fo, bo, fe, be)
     G = emul_lib.Emul(default_params(k=8)); G.set_fast(False)
     G.set_error_profile(*d.error_profile()); G.load_db(d.bps, d.boff, d.rlen)

@@ -270,6 +270,28 @@ def test_ont_like_profile_k_sweep():
         assert frags_equal(fo, bo, fx, bx)
 
 
+@pytest.mark.parametrize("dense", ["1", "0"])
+def test_dense_graph_tier_between_the_second_slot_and_tier_3(small_data, dense, monkeypatch):
+    """Round 6: what the second slot's tier (k_window_fast<6>) hands on runs in the dense-graph tier k_window_fast<10> (two wavefronts
+    per CU, 16 bit path ids) before tier 3 (one per CU); DACC_DENSE_TIER=0 = straight to tier 3.  k = 8 on 20x piles: dense graphs,
+    every tier is exercised (the emulation runs the same case: test_capacity_tiers_and_generic_engine_agree)."""
+    monkeypatch.setenv("DACC_DENSE_TIER", dense)
+    d, ovl, piles = small_data
+    O, E = _pair(d, k=8)
+    fo, bo = O.run(piles[:4], ovl, d.trace, nthreads=8, want_windows=True)
+    fx, bx = E(piles[:4], ovl, d.trace)
+    assert windows_equal(O.windows(), E.debug_windows()) == []
+    assert frags_equal(fo, bo, fx, bx)
+    t = E.timing()
+    assert t.tier_out[1] > 0, list(t.tier_out)
+    if dense == "1":
+        assert t.tier10_ran == 1 and t.tier10_ms > 0 and t.tier10_out < t.tier_out[1], (t.tier10_ran, t.tier10_ms, t.tier10_out, list(t.tier_out))
+    else:
+        assert t.tier10_ran == 0 and t.tier10_ms == 0
+    E.rerun(); fy, by = E.collect()
+    assert frags_equal(fo, bo, fy, by)
+
+
 def test_empty_shallow_and_rerun(small_data):
     d, ovl, piles = small_data
     p = piles[:3].copy()
