@@ -438,6 +438,8 @@ def main():
             if not os.path.exists(gold):
                 return None
             GG = json.load(open(gold)); G = GG["runs"][0]; spec = GG["spec"]
+            if G.get("params") != {"k": args.k}:      # a fixture of the same data set under other run parameters (window size ...) is not this run's oracle
+                return None
             ranges = spec.get("pile_ranges") or [[spec["first"], spec["first"] + spec["npiles"]]]
             idx = np.concatenate([np.arange(a, b) for a, b in ranges])
             areads = idx                 # pile index = A read id in the synthetic sets

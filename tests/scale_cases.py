@@ -48,7 +48,7 @@ CASES = {
                  first=0, npiles=100, params=[dict(k=k) for k in (10, 11, 12, 13, 14, 15, 16)]),
     # config 2 with WIDE windows (round 6: the wide LDS tiers, k_window_fast<8> / <9>): 48 piles from the middle of the headline batch at
     # -w 64, 80 and 96 (advance w / 4; -w is free in the reference, daccord.cpp:1282-1305)
-    "cfg2wide": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=2000, npiles=48,
+    "wide_cfg2": dict(genome_len=5000000, nreads=10000, read_len=10000, seed=3, synth={}, first=2000, npiles=48,
                      params=[dict(k=14, w=64, a=16), dict(k=14, w=80, a=20), dict(k=14, w=96, a=24)]),
     # config 4 shape: 54x depth slice
     "cfg4": dict(genome_len=111111, nreads=600, read_len=10000, seed=4, synth={}, first=0, npiles=50,
@@ -80,7 +80,7 @@ def _complement_cases(nparts=12):
 
 
 _complement_cases()
-CFG2W = sorted(n for n in CASES if n.startswith("cfg2w"))
+CFG2W = sorted(n for n in CASES if n.startswith("cfg2w") and n[5:].isdigit())
 
 
 def make_case(case, pile_select):

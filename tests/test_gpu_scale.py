@@ -24,7 +24,7 @@ def _golden(name):
         return json.load(f)
 
 
-@pytest.mark.parametrize("name", ["cfg1k8", "cfg4", "cfg4b", "cfg5", "cfg3", "cfg3b", "cfg2", "cfg2s", "cfg2t", "cfg2u", "cfg2v", "cfg2wide"])
+@pytest.mark.parametrize("name", ["cfg1k8", "cfg4", "cfg4b", "cfg5", "cfg3", "cfg3b", "cfg2", "cfg2s", "cfg2t", "cfg2u", "cfg2v", "wide_cfg2"])
 def test_scale_case_matches_oracle_digests(name):
     G = _golden(name)
     case = CASES[name]
@@ -47,7 +47,7 @@ def test_scale_case_matches_oracle_digests(name):
             # shallow batches: the size classes ran -- the pre-pass sent a good part of the windows to tier 0 (8 wavefronts per CU),
             # which finished most of them (a fifth is handed on at the default threshold: node overflows; round 4)
             assert t.tier0_in > 0.25 * len(w) and t.tier0_out < 0.35 * t.tier0_in and t.tier0_ms > 0, (t.tier0_in, t.tier0_out, t.tier0_ms)
-        if name == "cfg2wide":
+        if name == "wide_cfg2":
             # wide windows (round 6): the first slot does not run, tier 8 takes every window and hands a minority on to tier 9; what the
             # generic engine is left with is a handful (none at w = 64 ... 96 on the emulation)
             assert t.tier0_in == 0 and t.tier_ms[1] > 0 and t.tier_out[1] < 0.25 * len(w) and t.tier_out[2] + t.long_windows <= 0.002 * len(w) + 2, (list(t.tier_ms), list(t.tier_out), t.long_windows)
