@@ -29,6 +29,8 @@ CASES = [
     ("long", dict(genome_len=100000, nreads=200, read_len=5000, erate=0.25, seed=77, ins_frac=0.9, del_frac=0.05, sub_frac=0.05),
      dict(k=10, w=56, a=14), ["-k10", "-w56", "-a14"], (0, 2)),
     ("deep", dict(genome_len=30000, nreads=300, read_len=5000, seed=7), dict(k=14), ["-k14"], (10, 12)),
+    # (round 6) a wide window through the command line: the wide LDS tiers k_window_fast<8|9>
+    ("wide", dict(genome_len=100000, nreads=200, read_len=5000, seed=11), dict(k=12, w=80, a=20), ["-k12", "-w80", "-a20"], (0, 3)),
     ("base", dict(genome_len=100000, nreads=200, read_len=5000, seed=1), dict(k=8), ["-k8"], (0, 5)),
     # badly aligned trace blocks: B window strings of 129..256 bases (generic engine, LSTR = 256)
     ("warp", dict(genome_len=100000, nreads=200, read_len=5000, seed=1), dict(k=8, w=63, a=16), ["-k8", "-w63", "-a16"], (0, 1)),
