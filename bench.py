@@ -351,8 +351,9 @@ def main():
                 first_kernel: (tsums[0] - t0sum - t7sum) / args.steps, second_kernel: tsums[1] / args.steps,
                 "k_window_fast<3>": (tsums[2] - t10sum) / args.steps, "k_window": (wsum - sum(tsums)) / args.steps}
         t10ran = int(getattr(t, "tier10_ran", 0)) == 1; t10out = int(getattr(t, "tier10_out", 0))
+        dense_kernel = "k_window_fast<11>" if deep else "k_window_fast<10>"      # the dense tier of deep / shallow batches
         if t10ran:
-            kern["k_window_fast<10>"] = t10sum / args.steps      # round 6: the dense-graph tier (2 wavefronts per CU) between the second slot's tier and tier 3
+            kern[dense_kernel] = t10sum / args.steps      # round 6: the dense-graph tier (2 wavefronts per CU) between the second slot's tier and tier 3
         if t0sum > 0:
             kern["k_classify+k_window_fast<0>"] = t0sum / args.steps
         if t7sum > 0:
@@ -369,7 +370,7 @@ def main():
         # tier 7 ran the pre-pass's middle class + tier 0's hand-overs; tier 1 the pre-pass's big class + tier 7's hand-overs (without tier 7: + tier 0's)
         first_in = (nwin - t0in - n1 - (t7in - t0out) + t7out) if t7in else (nwin - t0in - n1 + t0out)
         wins = {"k_trace": nwin, "k_vote": nwin, first_kernel: max(0, first_in), second_kernel: touts[0],
-                "k_window_fast<3>": (t10out if t10ran else touts[1]), "k_window_fast<10>": (touts[1] if t10ran else 0), "k_window": touts[2], "k_window_long": nlong, "k_classify+k_window_fast<0>": t0in, "k_window_fast<7>": t7in}
+                "k_window_fast<3>": (t10out if t10ran else touts[1]), dense_kernel: (touts[1] if t10ran else 0), "k_window": touts[2], "k_window_long": nlong, "k_classify+k_window_fast<0>": t0in, "k_window_fast<7>": t7in}
         bpw = t.algo_bytes / max(1, nwin)
         dom_bytes = bpw * wins.get(dom, nwin)
         achieved = dom_bytes / (kern[dom] * 1e-3) / 1e9 if kern[dom] > 0 else 0.0
@@ -382,7 +383,7 @@ def main():
                 "windows_by_kernel": {k: int(v) for k, v in wins.items() if k in kern or k == "k_window_long"},
                 "kernel_ms": {k: round(v, 3) for k, v in kern.items()},
                 "window_ms_all_tiers": round(wsum / args.steps, 3),
-                "windows_handed_on": dict({first_kernel: touts[0], second_kernel: touts[1], "k_window_fast<3>_to_generic": touts[2]}, **({"k_window_fast<10>": t10out} if t10ran else {})),
+                "windows_handed_on": dict({first_kernel: touts[0], second_kernel: touts[1], "k_window_fast<3>_to_generic": touts[2]}, **({dense_kernel: t10out} if t10ran else {})),
                 "size_classes": {"windows_sent_to_tier0": int(getattr(t, "tier0_in", 0)), "handed_on_by_tier0": int(getattr(t, "tier0_out", 0)),
                                  "windows_run_by_tier7": t7in, "handed_on_by_tier7": t7out},
                 "windows_on_second_stream": int(getattr(t, "long_windows", 0))}

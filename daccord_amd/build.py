@@ -74,7 +74,7 @@ def _newer(target, srcs):
     return (not os.path.exists(target)) or os.path.getmtime(target) < max(os.path.getmtime(s) for s in srcs)
 
 
-HIP_UNITS = ["capi.hip", "k_generic.hip", "k_fast_0.hip", "k_fast_7.hip", "k_fast_1.hip", "k_fast_6.hip", "k_fast_2.hip", "k_fast_3.hip", "k_fast_4.hip", "k_fast_8.hip", "k_fast_9.hip", "k_fast_10.hip"]
+HIP_UNITS = ["capi.hip", "k_generic.hip", "k_fast_0.hip", "k_fast_7.hip", "k_fast_1.hip", "k_fast_6.hip", "k_fast_2.hip", "k_fast_3.hip", "k_fast_4.hip", "k_fast_8.hip", "k_fast_9.hip", "k_fast_10.hip", "k_fast_11.hip"]
 HOST_UNITS = ["host_tables.cpp", "host_piles.cpp", "host_io.cpp", "host_eprof.cpp"]
 
 

@@ -328,7 +328,7 @@ struct BatchPlan
 		ftier0 = fastCapsOf< FastTier<0> >(tab_nrows,tab_nsup);
 		ftier7 = fastCapsOf< FastTier<7> >(tab_nrows,tab_nsup);
 		ftierL = fastCapsOf< FastTier<5> >(tab_nrows,tab_nsup);
-		ftierD = fastCapsOf< FastTier<10> >(tab_nrows,tab_nsup);
+		ftierD = deep ? fastCapsOf< FastTier<11> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<10> >(tab_nrows,tab_nsup);      // (deep batches: tier 11)
 		ftier[2] = wide ? fastCapsOf< FastTier<9> >(tab_nrows,tab_nsup) : fastCapsOf< FastTier<3> >(tab_nrows,tab_nsup);
 		return DACC_OK;
 	}

@@ -714,7 +714,8 @@ static int runDevice(dacc_ctx * c)
 						// handed on; tier 3 (one per CU) gets what overflows them
 						HIPCHK(hipMemsetAsync(c->d_dense.p,0,sizeof(uint32_t),s));
 						FastBatch FD = FB; FD.F = BP.ftierD; FD.retry = c->d_dense.p; FD.gstride = c->gstride10;
-						hipLaunchKernelGGL(k_window_fast<10>,dim3(c->tier10_grid),dim3(64),FD.F.ldsbytes,s,FD,list,(c->sched&1) ? c->d_work.p+24 : static_cast<uint32_t *>(0));
+						if ( BP.deep ) hipLaunchKernelGGL(k_window_fast<11>,dim3(c->tier10_grid),dim3(64),FD.F.ldsbytes,s,FD,list,(c->sched&1) ? c->d_work.p+24 : static_cast<uint32_t *>(0));      // (deep batches: tier 11)
+						else hipLaunchKernelGGL(k_window_fast<10>,dim3(c->tier10_grid),dim3(64),FD.F.ldsbytes,s,FD,list,(c->sched&1) ? c->d_work.p+24 : static_cast<uint32_t *>(0));
 						HIPCHK(hipEventRecord(c->evT10,s)); c->tier10_ran = true;
 						hipLaunchKernelGGL(k_window_fast<3>,dim3(c->tier_grid[t]),dim3(64),FB.F.ldsbytes,s,FB,static_cast<uint32_t const *>(c->d_dense.p),work);
 					}
@@ -1020,7 +1021,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			}
 			// tier 10 (the dense-graph tier, two wavefronts per CU) between the second slot's tier 6 and tier 3 of a shallow batch: DACC_DENSE_TIER=0 switches it off
 			FastCaps const & FD = BP.ftierD;
-			c->tier10_ok = !BP.deep && !c->widetier && c->env_dense && c->tier_ok[1] && c->tier_ok[2] && FD.ldsbytes <= 160*1024 && (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= FD.tabcap);
+			c->tier10_ok = !c->widetier && c->env_dense && c->tier_ok[1] && c->tier_ok[2] && FD.ldsbytes <= 160*1024 && (static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= FD.tabcap);
 			uint64_t percuD = (160*1024) / (FD.ldsbytes ? FD.ldsbytes : 1); if ( percuD > 8 ) percuD = 8; if ( percuD < 1 ) percuD = 1;
 			uint64_t fgD = ((BP.nwindows+7)/8)*8; if ( fgD > 256*percuD ) fgD = 256*percuD; if ( fgD < 8 ) fgD = 8;
 			c->tier10_grid = static_cast<uint32_t>(fgD); c->gstride10 = FD.gbytes;
@@ -1028,7 +1029,7 @@ static int dacc_submit_piles_body(dacc_ctx * c, dacc_pile const * piles, uint64_
 			{
 				HIPCHK(c->d_dense.ensure(BP.nwindows+2));
 				HIPCHK(c->d_gslab.ensure(static_cast<size_t>(fgD)*FD.gbytes + 256));
-				if ( FD.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_window_fast<10>),hipFuncAttributeMaxDynamicSharedMemorySize,FD.ldsbytes));
+				if ( FD.ldsbytes > 64*1024 ) HIPCHK(hipFuncSetAttribute(BP.deep ? reinterpret_cast<const void *>(k_window_fast<11>) : reinterpret_cast<const void *>(k_window_fast<10>),hipFuncAttributeMaxDynamicSharedMemorySize,FD.ldsbytes));
 			}
 		}
 		{

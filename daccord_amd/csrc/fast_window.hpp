@@ -147,6 +147,11 @@ template<> struct FastTier<9> { typedef uint16_t id_t; typedef uint16_t sid_t; e
 // "more than 1 % in tier 3: add a dense-graph tier").  Tier 8's pools and 16 bit ids without its wide parts.
 template<> struct FastTier<10> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 6144, rch = 4, fch = 8, fnw = 4, fnc = 64, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 64, precap = 2560, ncap = 2048, scap = 248, lcap = 3072, wcap = 6144, rccap = 896, fcap = 512, siqcap = 128, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
 
+// tier 11 (round 6, two wavefronts per CU): tier 10's place in batches of DEEP piles, between tier 2 (three per CU, 2048 k-mer instances) and tier 3 (one per CU).
+// At 54x what tier 2 hands on are windows of more than 2048 k-mer instances (75 strings and more: 186 of 208 hand-overs in 12 piles of config 4), a few node
+// tables and pools; tier 3 needs 6.8 % of the step for them (profiles/r06zz/bench_54x_2000piles.log).  Tier 3's string / instance capacities with tier 10's pools.
+template<> struct FastTier<11> { typedef uint16_t id_t; typedef uint8_t sid_t; enum : uint32_t { smax = 250, gw = 1, wcapg = 4096, rch = 4, fch = 8, fnw = 4, fnc = 72, idmax = 4000, rpstcap = 768, lstr = 128, maxs = 96, precap = 4096, ncap = 1536, scap = 248, lcap = 2048, wcap = 4096, rccap = 640, fcap = 384, siqcap = 128, blcap = 128, seqcap = 48, psiq = 10, consrow = 96, lscrids = 2560, wide = 0 }; };
+
 HDEV constexpr uint32_t fcpow2(uint32_t v) { uint32_t p = 1; while ( p < v ) p <<= 1; return p; }
 HDEV constexpr uint32_t fcmax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 

@@ -100,5 +100,6 @@ extern template __global__ void k_window_fast<7>(FastBatch, uint32_t const *, ui
 extern template __global__ void k_window_fast<8>(FastBatch, uint32_t const *, uint32_t *);
 extern template __global__ void k_window_fast<9>(FastBatch, uint32_t const *, uint32_t *);
 extern template __global__ void k_window_fast<10>(FastBatch, uint32_t const *, uint32_t *);
+extern template __global__ void k_window_fast<11>(FastBatch, uint32_t const *, uint32_t *);
 #endif
 #endif

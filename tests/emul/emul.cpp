@@ -308,14 +308,14 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 		}
 		// tier 10 (the dense-graph tier) between the second slot's tier 6 and tier 3 of a shallow batch, as in the library (DACC_DENSE_TIER=0 switches it off)
 		FastBatch FBD; std::vector<uint8_t> ldsD, gslabD;
-		bool const tier10ok = usefast && !BP.deep && !widetier && tierok[1] && tierok[2] && !(getenv("DACC_DENSE_TIER") && getenv("DACC_DENSE_TIER")[0] == '0')
+		bool const tier10ok = usefast && !widetier && tierok[1] && tierok[2] && !(getenv("DACC_DENSE_TIER") && getenv("DACC_DENSE_TIER")[0] == '0')
 			&& static_cast<uint64_t>(c->H.nrows+1)*(c->H.nsup+1) <= BP.ftierD.tabcap;
 		if ( tier10ok )
 		{
 			FBD = FB[2]; FBD.F = BP.ftierD;
 			gslabD.assign(BP.ftierD.gbytes+64,arenafill); FBD.gslab = gslabD.data();
 			ldsD.assign(BP.ftierD.ldsbytes+64,arenafill);
-			wave_run([&]() { FastLds< FastTier<10> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); });
+			wave_run([&]() { if ( BP.deep ) { FastLds< FastTier<11> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); } else { FastLds< FastTier<10> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); } });
 		}
 		auto loadTables = [&](int const t)
 		{
@@ -406,10 +406,10 @@ int emul_run(void * v, dacc_pile const * piles, uint64_t npiles, dacc_overlap co
 				{
 					uint64_t const wdx = cur[i];
 					if ( FBD.W.pregen && ((FBD.W.pregen[wdx>>5] >> (wdx&31)) & 1) ) { cur10.push_back(wdx); continue; }      // (skipped by tier 3 as well)
-					if ( getenv("DACC_EMUL_POISON") ) { std::memset(ldsD.data(),atoi(getenv("DACC_EMUL_POISON")),ldsD.size()); std::memset(gslabD.data(),atoi(getenv("DACC_EMUL_POISON")),gslabD.size()); wave_run([&]() { FastLds< FastTier<10> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); }); }
+					if ( getenv("DACC_EMUL_POISON") ) { std::memset(ldsD.data(),atoi(getenv("DACC_EMUL_POISON")),ldsD.size()); std::memset(gslabD.data(),atoi(getenv("DACC_EMUL_POISON")),gslabD.size()); wave_run([&]() { if ( BP.deep ) { FastLds< FastTier<11> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); } else { FastLds< FastTier<10> > L; L.base = ldsD.data(); fast_load_tables(L,BP.ftierD.nrows,BP.ftierD.nsup,T,c->H.dpsq_vst.data()); } }); }
 					int rc = -1;
 					dacc_emul_curwin = wdx; dacc_emul_curtier = 110;
-					wave_run([&]() { int const r = processWindowFast< FastTier<10> >(FBD,wdx,ldsD.data(),true); if ( wv_lane() == 0 ) rc = r; });
+					wave_run([&]() { int const r = BP.deep ? processWindowFast< FastTier<11> >(FBD,wdx,ldsD.data(),true) : processWindowFast< FastTier<10> >(FBD,wdx,ldsD.data(),true); if ( wv_lane() == 0 ) rc = r; });
 					if ( rc == FW_DONE ) { ++c->ntier10; continue; }
 					cur10.push_back(wdx);
 				}

@@ -56,6 +56,8 @@ def test_scale_case_matches_oracle_digests(name):
 
             # deep piles start in the deep tier; only windows with more than 250 stretches are left to the generic engine
             assert t.tier_out[0] < 0.2 * len(w) and t.tier_out[2] <= 100 * max(1, len(w) // 50000), list(t.tier_out)
+            # (round 6) what tier 2 hands on runs in the deep batches' dense tier (k_window_fast<11>, two wavefronts per CU) before tier 3
+            assert t.tier10_ran == 1 and t.tier10_out <= t.tier_out[1], (t.tier10_ran, t.tier10_out, list(t.tier_out))
         pd = pile_digests(fx, bx, sel, engine.fasta)
         badp = [i for i, (a, b) in enumerate(zip(pd, run["pile_sha256"])) if a != b]
         assert badp == [], ("piles whose FASTA differs from the oracle's", run["params"], len(badp), badp[:10])
